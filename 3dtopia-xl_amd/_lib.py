@@ -1,0 +1,87 @@
+"""ctypes binding of ``libprimx_hip.so`` (the C ABI declared in ``include/primx_hip.h``).
+
+There is exactly one compute backend.  If the library has not been built (``__graft_entry__.build()``
+or ``python 3dtopia-xl_amd/csrc/build.py``) every op raises - nothing falls back to PyTorch or the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libprimx_hip.so")
+
+F32, F16, BF16 = 0, 1, 2
+ACT_NONE, ACT_GELU_TANH = 0, 1
+HEADS_ROWS, HEADS_VT = 0, 1
+ABI_VERSION = 4
+
+_p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> argument ctypes (return type is always int unless listed in _RESTYPES)
+SIGNATURES = {
+    "primx_abi_version": [],
+    "primx_last_error": [],
+    "primx_padded_head_dim": [_i],
+    "primx_layernorm_modulate": [_p, _p, _p, _l, _p, _i, _i, _i, _i, _f, _p],
+    "primx_timestep_embedding": [_p, _p, _i, _i, _f, _p],
+    "primx_silu_cast": [_p, _p, _i, _l, _p],
+    "primx_cast16": [_p, _p, _i, _l, _p],
+    "primx_linear_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "primx_linear": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "primx_linear_gate_residual": [_p, _p, _p, _p, _l, _p, _i, _i, _i, _i, _i, _p],
+    "primx_linear_heads": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _f, _i, _p],
+    "primx_attention": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
+    "primx_pack_heads": [_p, _l, _l, _l, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "primx_cfg_combine": [_p, _p, _i, _l, _f, _p],
+    "primx_diffusion_step": [_p, _p, _i, _l, _i, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
+    "primx_groupnorm_silu": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p],
+    "primx_conv3d_k3": [_p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "primx_linear_residual": [_p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _p],
+    "primx_conv_in": [_p, _f, _f, _p, _p, _p, _i, _i, _i, _i, _p],
+    "primx_convtranspose_k2s2": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "primx_vae_output": [_p, _p, _i, _i, _i, _i, _f, _i, _p],
+}
+_RESTYPES = {"primx_last_error": C.c_char_p}
+
+_lib: Optional[C.CDLL] = None
+
+
+class PrimxError(RuntimeError):
+    """A C-ABI entry point returned a non-zero status."""
+
+
+def load(path: Optional[str] = None) -> C.CDLL:
+    """dlopen the library and attach prototypes.  Raises if it is missing or ABI-mismatched."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP library is not built. Run `python __graft_entry__.py` "
+            "(build()) first - there is no PyTorch/CPU fallback for this path."
+        )
+    # make sure the HIP runtime PyTorch uses is the one already mapped (same SONAME libamdhip64.so.7)
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - symbol-table checks work without torch
+        pass
+    lib = C.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    got = lib.primx_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"libprimx_hip.so ABI {got} != expected {ABI_VERSION}; rebuild it")
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def check(status: int, name: str) -> None:
+    if status != 0:
+        msg = load().primx_last_error()
+        raise PrimxError(f"{name} failed ({status}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,60 @@
+"""Build libprimx_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python 3dtopia-xl_amd/csrc/build.py [--force]
+
+One translation unit per .hip file, objects cached by source mtime, linked against the HIP runtime
+(SONAME libamdhip64.so.7 - at run time the copy PyTorch already mapped is the one that binds).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["rowops.hip", "gemm.hip", "attention.hip", "vae.hip"]
+HEADERS = ["common.h", os.path.join("..", "..", "include", "primx_hip.h")]
+LIB = os.path.join(HERE, "libprimx_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = _hipcc()
+    hdrs = [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    objs, jobs = [], []
+    for src in SOURCES:
+        s = os.path.join(HERE, src)
+        o = os.path.join(HERE, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=HERE)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,280 @@
+"""PrimX diffusion transformer on the HIP path - drop-in for ``models.dit_crossattn.DiT``.
+
+Same constructor kwargs, same ``state_dict`` keys (515 tensors for the shipped config), same
+``forward`` / ``forward_with_cfg`` signatures and return shapes as the reference
+(models/dit_crossattn.py:111-213).  The compute is re-designed for MI355X:
+
+* the fp32 residual stream ``h`` [B*N, D] stays resident; every projection that adds into it is ONE
+  GEMM whose epilogue applies bias, 16-bit rounding, the adaLN gate and the residual add in place;
+* LayerNorm + modulate + cast is one row kernel producing the 16-bit GEMM operand;
+* q/k/v projections write the attention operand layouts (padded head-major Q/K, transposed
+  quad-permuted V) straight from the GEMM epilogue - there is no reshape/unbind/permute pass;
+* the adaLN Linear of all blocks + final layer is ONE weight-streaming GEMM per forward
+  ([B, D] x [D, depth*9D + 2D]) instead of depth+1 GEMV-shaped launches;
+* rounding points follow the reference's fp16/bf16 autocast topology (fp32 residual stream and
+  LayerNorm, 16-bit Linear/attention outputs, 16-bit modulation vectors, 16-bit CFG combine), see
+  DESIGN.md "Numerics".
+
+Only the autocast path is accelerated (``enable_amp=True`` with fp16 or bf16); the fp32
+(``enable_amp=False``) variant raises NotImplementedError - gfx950 has no TF32 and exact-fp32 MFMA
+runs at 1/16 rate (out of scope for this round).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import ACT_GELU_TANH, HEADS_ROWS, HEADS_VT
+from .attention import MemEffAttention, MemEffCrossAttention, _c16
+
+
+def modulate(x, shift, scale):
+    """Reference formula (models/utils.py:19-20); kept for API parity, the HIP path fuses it."""
+    return x * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
+
+
+class TimestepEmbedder(nn.Module):
+    """Sinusoid(256) -> Linear -> SiLU -> Linear, fp32 (models/utils.py:27-64)."""
+
+    def __init__(self, hidden_size: int, frequency_embedding_size: int = 256):
+        super().__init__()
+        self.mlp = nn.Sequential(
+            nn.Linear(frequency_embedding_size, hidden_size, bias=True),
+            nn.SiLU(),
+            nn.Linear(hidden_size, hidden_size, bias=True),
+        )
+        self.frequency_embedding_size = frequency_embedding_size
+
+    @staticmethod
+    def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000) -> torch.Tensor:
+        if dim % 2:
+            raise NotImplementedError("odd embedding sizes are not used on this path")
+        return ops.timestep_embedding(t, dim, float(max_period))
+
+    def forward(self, t: torch.Tensor) -> torch.Tensor:
+        f = self.timestep_embedding(t, self.frequency_embedding_size)
+        h = ops.linear_f32(f, self.mlp[0].weight.detach(), self.mlp[0].bias.detach(), act_out=1)
+        return ops.linear_f32(h, self.mlp[2].weight.detach(), self.mlp[2].bias.detach())
+
+
+class Mlp(nn.Module):
+    """fc1 -> GELU(tanh) -> fc2 parameter container (models/utils.py:66-101; dropouts are p=0)."""
+
+    def __init__(self, in_features: int, hidden_features: Optional[int] = None, out_features: Optional[int] = None,
+                 act_layer=None, norm_layer=None, bias: bool = True, drop: float = 0.0, use_conv: bool = False):
+        super().__init__()
+        if use_conv or norm_layer is not None or drop:
+            raise NotImplementedError("only the Linear / no-norm / no-dropout Mlp of the DiT block is supported")
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features, bias=bias)
+        self.fc2 = nn.Linear(hidden_features, out_features, bias=bias)
+
+
+class DiTBlock(nn.Module):
+    """adaLN-Zero block: cross-attn, self-attn, MLP, each gated (models/dit_crossattn.py:25-58).
+    Parameter container; the fused per-block schedule lives in ``DiT._run_block``."""
+
+    def __init__(self, hidden_size, cross_attn_cond_dim, num_heads, mlp_ratio=4.0, proj_bias=False,
+                 gradient_checkpointing=False, **block_kwargs):
+        super().__init__()
+        self.gradient_checkpointing = gradient_checkpointing
+        self.crossattn = MemEffCrossAttention(dim=hidden_size, dim_q=hidden_size, dim_k=cross_attn_cond_dim,
+                                              dim_v=cross_attn_cond_dim, num_heads=num_heads, qkv_bias=True,
+                                              proj_bias=proj_bias, **block_kwargs)
+        self.attn = MemEffAttention(dim=hidden_size, num_heads=num_heads, qkv_bias=True, proj_bias=proj_bias,
+                                    **block_kwargs)
+        self.mlp = Mlp(in_features=hidden_size, hidden_features=int(hidden_size * mlp_ratio))
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 9 * hidden_size, bias=True))
+
+
+class FinalLayer(nn.Module):
+    """adaLN(2) -> LN -> modulate -> Linear (models/dit_crossattn.py:61-78).  Parameter container."""
+
+    def __init__(self, hidden_size, seq_length, out_channels):
+        super().__init__()
+        self.linear = nn.Linear(hidden_size, out_channels, bias=True)
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 2 * hidden_size, bias=True))
+
+
+class DiT(nn.Module):
+    """Diffusion transformer over primitive tokens (models/dit_crossattn.py:111-213)."""
+
+    LN_EPS = 1e-6
+
+    def __init__(self, seq_length=2, in_channels=4, condition_channels=512, hidden_size=1152, depth=28,
+                 num_heads=16, mlp_ratio=4.0, cond_drop_prob=0.0, attn_proj_bias=False, learn_sigma=True,
+                 gradient_checkpointing=False):
+        super().__init__()
+        self.gradient_checkpointing = gradient_checkpointing
+        self.learn_sigma = learn_sigma
+        self.in_channels = in_channels
+        self.out_channels = in_channels * 2 if learn_sigma else in_channels
+        self.seq_length = seq_length
+        self.num_heads = num_heads
+        self.hidden_size = hidden_size
+        self.depth = depth
+        self.condition_channels = condition_channels
+        self.cond_drop_prob = cond_drop_prob
+        if self.cond_drop_prob > 0:
+            self.null_cond_embedding = nn.Parameter(torch.randn(condition_channels))
+        self.x_embedder = nn.Linear(in_channels, hidden_size)
+        self.t_embedder = TimestepEmbedder(hidden_size)
+        self.blocks = nn.ModuleList([
+            DiTBlock(hidden_size, condition_channels, num_heads, mlp_ratio=mlp_ratio, proj_bias=attn_proj_bias,
+                     gradient_checkpointing=gradient_checkpointing) for _ in range(depth)
+        ])
+        self.final_layer = FinalLayer(hidden_size, seq_length, self.out_channels)
+        self.initialize_weights()
+        self._pack: Dict = {}
+        self._heads_ws: Dict = {}
+
+    # ------------------------------------------------------------------ init (dit_crossattn.py:153-182)
+    def initialize_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+        nn.init.normal_(self.t_embedder.mlp[0].weight, std=0.02)
+        nn.init.normal_(self.t_embedder.mlp[2].weight, std=0.02)
+        for blk in self.blocks:  # adaLN-Zero
+            nn.init.zeros_(blk.adaLN_modulation[-1].weight)
+            nn.init.zeros_(blk.adaLN_modulation[-1].bias)
+        nn.init.zeros_(self.final_layer.adaLN_modulation[-1].weight)
+        nn.init.zeros_(self.final_layer.adaLN_modulation[-1].bias)
+        nn.init.zeros_(self.final_layer.linear.weight)
+        nn.init.zeros_(self.final_layer.linear.bias)
+
+    # ------------------------------------------------------------------ packed 16-bit weights
+    def repack(self) -> None:
+        self._pack = {}
+        self._heads_ws = {}
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__["_pack"] = {}
+        self.__dict__["_heads_ws"] = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.repack()
+        return super().load_state_dict(*a, **k)
+
+    def packed(self, dtype: torch.dtype) -> Dict:
+        """One-time conversion of the fp32 parameters into the 16-bit operands the kernels stream:
+        per block fused [to_k; to_v] and qkv matrices, and ONE adaLN matrix for all blocks + final."""
+        key = (dtype, self.x_embedder.weight.device)
+        if key in self._pack:
+            return self._pack[key]
+        with torch.no_grad():
+            blocks = []
+            for blk in self.blocks:
+                ca, sa, mlp = blk.crossattn, blk.attn, blk.mlp
+                blocks.append({
+                    "w_q": _c16(ca.to_q.weight, dtype), "b_q": _c16(ca.to_q.bias, dtype),
+                    "w_kv": _c16(torch.cat([ca.to_k.weight, ca.to_v.weight], 0), dtype),
+                    "b_kv": _c16(torch.cat([ca.to_k.bias, ca.to_v.bias], 0), dtype),
+                    "w_cproj": _c16(ca.proj.weight, dtype), "b_cproj": _c16(ca.proj.bias, dtype),
+                    "w_qkv": _c16(sa.qkv.weight, dtype), "b_qkv": _c16(sa.qkv.bias, dtype),
+                    "w_proj": _c16(sa.proj.weight, dtype), "b_proj": _c16(sa.proj.bias, dtype),
+                    "w_fc1": _c16(mlp.fc1.weight, dtype), "b_fc1": _c16(mlp.fc1.bias, dtype),
+                    "w_fc2": _c16(mlp.fc2.weight, dtype), "b_fc2": _c16(mlp.fc2.bias, dtype),
+                })
+            ada_w = [b.adaLN_modulation[1].weight for b in self.blocks] + [self.final_layer.adaLN_modulation[1].weight]
+            ada_b = [b.adaLN_modulation[1].bias for b in self.blocks] + [self.final_layer.adaLN_modulation[1].bias]
+            pk = {
+                "blocks": blocks,
+                "w_ada": _c16(torch.cat(ada_w, 0), dtype), "b_ada": _c16(torch.cat(ada_b, 0), dtype),
+                "w_final": _c16(self.final_layer.linear.weight, dtype),
+                "b_final": _c16(self.final_layer.linear.bias, dtype),
+            }
+        self._pack = {key: pk}
+        return pk
+
+    def _heads(self, tag: str, B: int, n: int, kind: int, dtype, device, pad_to: int) -> torch.Tensor:
+        """Persistent zero-padded attention operand buffers (pads are never written, so they stay zero)."""
+        key = (tag, B, n, kind, dtype, str(device), pad_to)
+        buf = self._heads_ws.get(key)
+        if buf is None:
+            buf = ops.alloc_heads(B, self.num_heads, n, self.hidden_size // self.num_heads, kind, dtype, device, pad_to)
+            self._heads_ws[key] = buf
+        return buf
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, t, y, precision_dtype=torch.float32, enable_amp=False):
+        """x: (B, N, C) fp32; t: (B,) int; y: (B, L, Dc) fp32 -> (B, N, out_channels) in ``precision_dtype``."""
+        if self.training:
+            raise NotImplementedError("the accelerated DiT is inference-only: call .eval()")
+        if not enable_amp or precision_dtype not in (torch.float16, torch.bfloat16):
+            raise NotImplementedError(
+                "only the autocast path (enable_amp=True, precision_dtype fp16/bf16) is accelerated; "
+                "the fp32 / TF32 variant is not implemented on gfx950 (see DESIGN.md)")
+        if not x.is_cuda:
+            raise RuntimeError("DiT.forward needs HIP device tensors; there is no CPU path")
+        dt = precision_dtype
+        Be, N, Cin = x.shape
+        L, Dc = y.shape[1], y.shape[2]
+        D, H = self.hidden_size, self.num_heads
+        dh = D // H
+        T = Be * N
+        pk = self.packed(dt)
+        dev = x.device
+
+        # fp32, outside autocast in the reference (dit_crossattn.py:191-192)
+        h = ops.linear_f32(x.reshape(T, Cin).float().contiguous(), self.x_embedder.weight.detach(),
+                           self.x_embedder.bias.detach())
+        t_emb = self.t_embedder(t)
+        # adaLN for every block + final layer: SiLU -> one streaming GEMM (dit_crossattn.py:40-43,54,69-75)
+        mod = ops.linear(ops.silu_cast(t_emb, dt), pk["w_ada"], pk["b_ada"])  # [Be, depth*9D + 2D]
+        y16 = ops.cast16(y.reshape(Be * L, Dc).float().contiguous(), dt)
+
+        nq_pad = ops.round_up(N, ops.BQ)
+        Qc = self._heads("Qc", Be, N, HEADS_ROWS, dt, dev, ops.BQ)
+        Kc = self._heads("Kc", Be, L, HEADS_ROWS, dt, dev, ops.BKV)
+        Vc = self._heads("Vc", Be, L, HEADS_VT, dt, dev, ops.BKV)
+        Qs = self._heads("Qs", Be, N, HEADS_ROWS, dt, dev, ops.BQ)
+        Ks = self._heads("Ks", Be, N, HEADS_ROWS, dt, dev, ops.BQ)
+        Vs = self._heads("Vs", Be, N, HEADS_VT, dt, dev, ops.BQ)
+        xn = torch.empty(T, D, dtype=dt, device=dev)
+        att = torch.empty(Be, N, D, dtype=dt, device=dev)
+        hid = torch.empty(T, pk["blocks"][0]["w_fc1"].shape[0], dtype=dt, device=dev) if self.depth else None
+        scale = dh ** -0.5
+
+        for i, w in enumerate(pk["blocks"]):
+            m = mod[:, i * 9 * D:(i + 1) * 9 * D]
+            ch = [m[:, j * D:(j + 1) * D] for j in range(9)]  # shift/scale/gate x (mca, msa, mlp)
+            # ---- cross-attention to the image tokens (dit_crossattn.py:55, attention.py:96-114)
+            ops.layernorm_modulate(h, ch[0], ch[1], N, xn, self.LN_EPS)
+            ops.linear_heads(xn, w["w_q"], w["b_q"], N, H, dh, [HEADS_ROWS], [Qc], nq_pad, scale0=scale)
+            ops.linear_heads(y16, w["w_kv"], w["b_kv"], L, H, dh, [HEADS_ROWS, HEADS_VT], [Kc, Vc], Kc.shape[2])
+            ops.attention(Qc, Kc, Vc, N, L, dh, scale, out=att)
+            ops.linear_gate_residual(att.view(T, D), w["w_cproj"], w["b_cproj"], ch[2], h, N)
+            # ---- self-attention over the primitive tokens (dit_crossattn.py:56, attention.py:48-59)
+            ops.layernorm_modulate(h, ch[3], ch[4], N, xn, self.LN_EPS)
+            ops.linear_heads(xn, w["w_qkv"], w["b_qkv"], N, H, dh, [HEADS_ROWS, HEADS_ROWS, HEADS_VT], [Qs, Ks, Vs],
+                             nq_pad)
+            ops.attention(Qs, Ks, Vs, N, N, dh, scale, out=att)
+            ops.linear_gate_residual(att.view(T, D), w["w_proj"], w["b_proj"], ch[5], h, N)
+            # ---- MLP (dit_crossattn.py:57, models/utils.py:94-101)
+            ops.layernorm_modulate(h, ch[6], ch[7], N, xn, self.LN_EPS)
+            ops.linear(xn, w["w_fc1"], w["b_fc1"], out=hid, act=ACT_GELU_TANH)
+            ops.linear_gate_residual(hid, w["w_fc2"], w["b_fc2"], ch[8], h, N)
+
+        # ---- final layer (dit_crossattn.py:74-78)
+        base = self.depth * 9 * D
+        ops.layernorm_modulate(h, mod[:, base:base + D], mod[:, base + D:base + 2 * D], N, xn, self.LN_EPS)
+        out = ops.linear(xn, pk["w_final"], pk["b_final"])
+        return out.view(Be, N, self.out_channels)
+
+    def forward_with_cfg(self, x, t, y, cfg_scale=0.0, precision_dtype=torch.float32, enable_amp=False):
+        """Classifier-free guidance: one forward at 2B, combine on all channels, return the B-sized half
+        (dit_crossattn.py:204-213)."""
+        combined = torch.cat([x, x], dim=0)
+        combined_t = torch.cat([t, t], dim=0)
+        y_null = self.null_cond_embedding.detach().to(y.dtype).expand_as(y)
+        combined_y = torch.cat([y, y_null], dim=0)
+        model_out = self.forward(combined, combined_t, combined_y, precision_dtype, enable_amp)
+        return ops.cfg_combine(model_out.contiguous(), float(cfg_scale))

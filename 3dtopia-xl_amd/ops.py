@@ -1,0 +1,295 @@
+"""Tensor-level wrappers over the C ABI: pointer extraction, shape checks, current-stream plumbing.
+
+PyTorch is used for device memory and streams only; every function here ends in exactly one (or a
+short fixed sequence of) ``primx_*`` calls enqueued on ``torch.cuda.current_stream()`` - the
+reference's extensions hard-code stream 0 (mvpraymarch.cpp:121), this does not.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU_TANH, ACT_NONE, BF16, F16, F32, HEADS_ROWS, HEADS_VT, check
+
+_DT = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}
+BQ, BKV = 128, 64  # attention query-tile / key-tile sizes (csrc/attention.hip)
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {dt}") from None
+
+
+def _dev(t: torch.Tensor, name: str, dtype: Optional[torch.dtype] = None) -> int:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a HIP device (got {t.device}); there is no CPU path")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def padded_head_dim(dh: int) -> int:
+    return (dh + 15) // 16 * 16
+
+
+def round_up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------- row kernels
+def layernorm_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, rows_per_batch: int,
+                       out: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """x: [rows, D] fp32; shift/scale: [B, D] 16-bit views (last dim contiguous, row stride arbitrary)."""
+    rows, D = x.shape
+    if shift.stride(-1) != 1 or scale.stride(-1) != 1 or shift.stride(0) != scale.stride(0):
+        raise RuntimeError("shift/scale must be last-dim contiguous with equal row strides")
+    if not (shift.is_cuda and scale.is_cuda and shift.dtype == out.dtype == scale.dtype):
+        raise TypeError("shift/scale/out dtype or device mismatch")
+    check(_lib.load().primx_layernorm_modulate(
+        _dev(x, "x", torch.float32), shift.data_ptr(), scale.data_ptr(), shift.stride(0), _dev(out, "out"),
+        dtype_code(out.dtype), rows, rows_per_batch, D, eps, _stream()), "primx_layernorm_modulate")
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
+    t = t.to(torch.int64).contiguous()
+    out = torch.empty(t.shape[0], dim, dtype=torch.float32, device=t.device)
+    check(_lib.load().primx_timestep_embedding(_dev(t, "t"), out.data_ptr(), t.shape[0], dim, max_period,
+                                               _stream()), "primx_timestep_embedding")
+    return out
+
+
+def silu_cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(_lib.load().primx_silu_cast(_dev(x, "x", torch.float32), out.data_ptr(), dtype_code(dtype), x.numel(),
+                                      _stream()), "primx_silu_cast")
+    return out
+
+
+def cast16(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(_lib.load().primx_cast16(_dev(x, "x", torch.float32), out.data_ptr(), dtype_code(dtype), x.numel(),
+                                   _stream()), "primx_cast16")
+    return out
+
+
+def linear_f32(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], act_out: int = 0) -> torch.Tensor:
+    M, K = x.shape
+    N = W.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    check(_lib.load().primx_linear_f32(_dev(x, "x", torch.float32), _dev(W, "W", torch.float32),
+                                       _dev(b, "b", torch.float32) if b is not None else None, out.data_ptr(),
+                                       M, N, K, act_out, _stream()), "primx_linear_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------- GEMMs
+def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
+           act: int = ACT_NONE, out_scale: float = 1.0) -> torch.Tensor:
+    M, K = A.shape
+    N = W.shape[0]
+    if W.shape[1] != K or W.dtype != A.dtype:
+        raise RuntimeError("linear: operand mismatch")
+    if out is None:
+        out = torch.empty(M, N, dtype=A.dtype, device=A.device)
+    check(_lib.load().primx_linear(_dev(A, "A"), _dev(W, "W"), _dev(bias, "bias", A.dtype) if bias is not None else None,
+                                   _dev(out, "out", A.dtype), M, N, K, dtype_code(A.dtype), act, out_scale, _stream()),
+          "primx_linear")
+    return out
+
+
+def linear_gate_residual(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], gate: torch.Tensor,
+                         x: torch.Tensor, rows_per_batch: int) -> torch.Tensor:
+    """x[M, N] (fp32, in place) += cast16(gate[b] * cast16(A W^T + bias))."""
+    M, K = A.shape
+    N = W.shape[0]
+    if gate.stride(-1) != 1 or gate.dtype != A.dtype or not gate.is_cuda:
+        raise RuntimeError("gate must be a last-dim-contiguous 16-bit device view")
+    check(_lib.load().primx_linear_gate_residual(
+        _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None,
+        gate.data_ptr(), gate.stride(0), _dev(x, "x", torch.float32), M, N, K, rows_per_batch,
+        dtype_code(A.dtype), _stream()), "primx_linear_gate_residual")
+    return x
+
+
+def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], rows_per_batch: int, heads: int,
+                 dh: int, kinds: Sequence[int], dsts: Sequence[torch.Tensor], n_pad: int,
+                 scale0: float = 1.0) -> None:
+    M, K = A.shape
+    N = W.shape[0]
+    n_seg = len(kinds)
+    kind_arr = (C.c_int * n_seg)(*kinds)
+    dst_arr = (C.c_void_p * n_seg)(*[_dev(d, "dst", A.dtype) for d in dsts])
+    check(_lib.load().primx_linear_heads(
+        _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None, M, N, K,
+        rows_per_batch, heads, dh, n_seg, kind_arr, dst_arr, n_pad, scale0, dtype_code(A.dtype), _stream()),
+        "primx_linear_heads")
+
+
+# ----------------------------------------------------------------------------- attention
+def alloc_heads(B: int, H: int, n: int, dh: int, kind: int, dtype: torch.dtype, device, pad_to: int) -> torch.Tensor:
+    """Zero-initialised attention operand buffer (pad rows/cols must stay zero)."""
+    DP = padded_head_dim(dh)
+    n_pad = round_up(n, pad_to)
+    shape = (B, H, n_pad, DP) if kind == HEADS_ROWS else (B, H, DP, n_pad)
+    return torch.zeros(shape, dtype=dtype, device=device)
+
+
+def attention(Qp: torch.Tensor, Kp: torch.Tensor, Vt: torch.Tensor, nq: int, nkv: int, dh: int, scale: float,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    B, H, nq_pad, DP = Qp.shape
+    nkv_pad = Kp.shape[2]
+    if Vt.shape != (B, H, DP, nkv_pad) or Kp.shape != (B, H, nkv_pad, DP):
+        raise RuntimeError("attention: operand layout mismatch")
+    if out is None:
+        out = torch.empty(B, nq, H * dh, dtype=Qp.dtype, device=Qp.device)
+    check(_lib.load().primx_attention(_dev(Qp, "Qp"), _dev(Kp, "Kp", Qp.dtype), _dev(Vt, "Vt", Qp.dtype),
+                                      _dev(out, "out", Qp.dtype), B, H, nq, nq_pad, nkv, nkv_pad, dh, scale,
+                                      dtype_code(Qp.dtype), _stream()), "primx_attention")
+    return out
+
+
+def pack_heads(src: torch.Tensor, kind: int, pad_to: int) -> torch.Tensor:
+    """src: [B, M, H, dh] view with contiguous last dim -> attention operand layout."""
+    B, M, H, dh = src.shape
+    if src.stride(3) != 1 or not src.is_cuda:
+        raise RuntimeError("pack_heads: last dim must be contiguous on a HIP device")
+    dst = alloc_heads(B, H, M, dh, kind, src.dtype, src.device, pad_to)
+    m_pad = dst.shape[2] if kind == HEADS_ROWS else dst.shape[3]
+    check(_lib.load().primx_pack_heads(src.data_ptr(), src.stride(0), src.stride(1), src.stride(2), dst.data_ptr(),
+                                       kind, B, M, H, dh, m_pad, dtype_code(src.dtype), _stream()), "primx_pack_heads")
+    return dst
+
+
+def memory_efficient_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, attn_bias=None,
+                               scale: Optional[float] = None) -> torch.Tensor:
+    """Drop-in for ``xformers.ops.memory_efficient_attention`` on ``[B, M, H, K]`` 16-bit operands
+    (the reference's call sites: models/attention.py:54,109): default scale ``K**-0.5``, no bias, p=0."""
+    if attn_bias is not None:
+        raise NotImplementedError("attn_bias is not used on the 3DTopia-XL path")
+    B, Mq, H, dh = q.shape
+    Mk = k.shape[1]
+    Qp = pack_heads(q, HEADS_ROWS, BQ)
+    Kp = pack_heads(k, HEADS_ROWS, BKV)
+    Vt = pack_heads(v, HEADS_VT, BKV)
+    out = attention(Qp, Kp, Vt, Mq, Mk, dh, dh ** -0.5 if scale is None else scale)
+    return out.view(B, Mq, H, dh)
+
+
+# ----------------------------------------------------------------------------- CFG + sampler update
+def cfg_combine(model_out: torch.Tensor, cfg_scale: float) -> torch.Tensor:
+    """model_out: [2B, ...] (cond half first) -> [B, ...]   (dit_crossattn.py:210-213)."""
+    B2 = model_out.shape[0]
+    out = torch.empty((B2 // 2,) + tuple(model_out.shape[1:]), dtype=model_out.dtype, device=model_out.device)
+    check(_lib.load().primx_cfg_combine(_dev(model_out, "model_out"), out.data_ptr(), dtype_code(model_out.dtype),
+                                        out.numel(), cfg_scale, _stream()), "primx_cfg_combine")
+    return out
+
+
+def diffusion_step(x: torch.Tensor, model_out: torch.Tensor, coef: torch.Tensor, step: int, *, mean_type: int,
+                   var_type: int, ancestral: bool, clip_denoised: bool,
+                   noise: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    B, nt, Cc = x.shape
+    model_out = model_out.contiguous()
+    sample = torch.empty_like(x)
+    x0 = torch.empty_like(x)
+    check(_lib.load().primx_diffusion_step(
+        _dev(x, "x", torch.float32), _dev(model_out, "model_out"), dtype_code(model_out.dtype), B * nt, Cc,
+        model_out.shape[-1], _dev(coef, "coef", torch.float32), step, mean_type, var_type, int(ancestral),
+        int(clip_denoised), _dev(noise, "noise", torch.float32) if noise is not None else None,
+        sample.data_ptr(), x0.data_ptr(), _stream()), "primx_diffusion_step")
+    return sample, x0
+
+
+# ----------------------------------------------------------------------------- VAE decoder
+def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
+                   silu: bool) -> torch.Tensor:
+    """x: [P, V, C] 16-bit channels-last."""
+    P, V, Cc = x.shape
+    out = torch.empty_like(x)
+    check(_lib.load().primx_groupnorm_silu(_dev(x, "x"), _dev(gamma, "gamma", torch.float32),
+                                           _dev(beta, "beta", torch.float32), out.data_ptr(), P, V, Cc, groups, eps,
+                                           int(silu), dtype_code(x.dtype), _stream()), "primx_groupnorm_silu")
+    return out
+
+
+_ZEROS = {}
+
+
+def _zeros16(device) -> torch.Tensor:
+    z = _ZEROS.get(str(device))
+    if z is None:
+        z = _ZEROS[str(device)] = torch.zeros(64, dtype=torch.uint8, device=device)
+    return z
+
+
+def conv3d_k3(x: torch.Tensor, Wk: torch.Tensor, bias: Optional[torch.Tensor], S: int,
+              res: Optional[torch.Tensor] = None, res_scale: float = 1.0) -> torch.Tensor:
+    """x: [P, S^3, Cin]; Wk: [Cout, Kpad] 16-bit (k = tap*Cin + ci); optional fused (conv + res) * res_scale."""
+    P, V, Cin = x.shape
+    Cout, Kpad = Wk.shape
+    out = torch.empty(P, V, Cout, dtype=x.dtype, device=x.device)
+    check(_lib.load().primx_conv3d_k3(_dev(x, "x"), _dev(Wk, "Wk", x.dtype),
+                                      _dev(bias, "bias", x.dtype) if bias is not None else None,
+                                      _dev(res, "res", x.dtype) if res is not None else None, res_scale,
+                                      _zeros16(x.device).data_ptr(), out.data_ptr(), P, S, Cin, Cout, Kpad,
+                                      dtype_code(x.dtype), _stream()),
+          "primx_conv3d_k3")
+    return out
+
+
+def linear_residual(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
+                    res: Optional[torch.Tensor], scale: float) -> torch.Tensor:
+    """out[M, N] = ((A W^T + bias) + res) * scale, 16-bit, no intermediate rounding."""
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty(M, N, dtype=A.dtype, device=A.device)
+    check(_lib.load().primx_linear_residual(_dev(A, "A"), _dev(W, "W", A.dtype),
+                                            _dev(bias, "bias", A.dtype) if bias is not None else None,
+                                            _dev(res, "res", A.dtype) if res is not None else None, scale,
+                                            out.data_ptr(), M, N, K, dtype_code(A.dtype), _stream()),
+          "primx_linear_residual")
+    return out
+
+
+def conv_in(z: torch.Tensor, pq_scale: float, pq_bias: float, W: torch.Tensor, bias: torch.Tensor, S: int,
+            dtype: torch.dtype) -> torch.Tensor:
+    """z: [P, S^3] fp32 latent; W: [Cout, 27] fp32."""
+    P = z.shape[0]
+    Cout = W.shape[0]
+    out = torch.empty(P, S * S * S, Cout, dtype=dtype, device=z.device)
+    check(_lib.load().primx_conv_in(_dev(z, "z", torch.float32), pq_scale, pq_bias, _dev(W, "W", torch.float32),
+                                    _dev(bias, "bias", torch.float32), out.data_ptr(), P, S, Cout,
+                                    dtype_code(dtype), _stream()), "primx_conv_in")
+    return out
+
+
+def convtranspose_k2s2(x: torch.Tensor, Wt: torch.Tensor, bias: torch.Tensor, S: int) -> torch.Tensor:
+    """x: [P, S^3, Cin]; Wt: [8*Cout, Cin] 16-bit (row = tap*Cout + co) -> [P, (2S)^3, Cout]."""
+    P, V, Cin = x.shape
+    Cout = Wt.shape[0] // 8
+    out = torch.empty(P, 8 * V, Cout, dtype=x.dtype, device=x.device)
+    check(_lib.load().primx_convtranspose_k2s2(_dev(x, "x"), _dev(Wt, "Wt", x.dtype), _dev(bias, "bias", x.dtype),
+                                               out.data_ptr(), P, S, Cin, Cout, dtype_code(x.dtype), _stream()),
+          "primx_convtranspose_k2s2")
+    return out
+
+
+def vae_output(x: torch.Tensor, denorm: bool, sdf_div: float = 5.0) -> torch.Tensor:
+    """x: [P, V, C] 16-bit channels-last -> [P, C, V] fp32."""
+    P, V, Cc = x.shape
+    out = torch.empty(P, Cc, V, dtype=torch.float32, device=x.device)
+    check(_lib.load().primx_vae_output(_dev(x, "x"), out.data_ptr(), P, V, Cc, int(denorm), sdf_div,
+                                       dtype_code(x.dtype), _stream()), "primx_vae_output")
+    return out

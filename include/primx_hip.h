@@ -1,0 +1,206 @@
+/*
+ * primx_hip.h - C ABI of libprimx_hip.so: the MI355X (gfx950) hot path of 3DTopia-XL's
+ * DDIM denoising loop (PrimX DiT) and 3D-VAE decode.
+ *
+ * Boundary rules
+ *   - plain C: device pointers, sizes, a HIP stream handle passed as void*; no torch types.
+ *   - every entry point returns 0 on success or a negative PRIMX_E* code; the message of the
+ *     last failure on the calling thread is available from primx_last_error().
+ *   - buffers are owned by the caller (PyTorch's caching allocator in the Python host); kernels
+ *     keep no pointers after return and never allocate.  Work is enqueued on `stream` and is
+ *     asynchronous with respect to the host.
+ *   - `dtype` selects the 16-bit storage/MFMA-input type of activations and weights:
+ *     PRIMX_F16 or PRIMX_BF16.  Accumulation is always fp32.
+ *
+ * Each entry cites the reference code it replaces (paths relative to the 3DTopia-XL repo).
+ * The reference has no native FFI on this path (it is PyTorch + xFormers); its one functional
+ * seam is xformers.ops.memory_efficient_attention (models/attention.py:17,54,109), and the
+ * convention mirrored here is the one of its CUDA extensions (caller-allocated outputs,
+ * dva/mvp/extensions/mvpraymarch/mvpraymarch.py:132-138), except that the current stream is
+ * honoured instead of stream 0 (mvpraymarch.cpp:121).
+ */
+#ifndef PRIMX_HIP_H
+#define PRIMX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRIMX_ABI_VERSION 4
+
+/* dtype codes */
+#define PRIMX_F32 0
+#define PRIMX_F16 1
+#define PRIMX_BF16 2
+
+/* error codes */
+#define PRIMX_OK 0
+#define PRIMX_EINVAL (-1)   /* bad argument (null pointer, unsupported shape/dtype) */
+#define PRIMX_ELAUNCH (-2)  /* hipGetLastError() after a launch was not hipSuccess */
+
+/* activation codes for primx_linear */
+#define PRIMX_ACT_NONE 0
+#define PRIMX_ACT_GELU_TANH 1
+
+/* head-layout kinds for primx_linear_heads / primx_pack_heads */
+#define PRIMX_HEADS_ROWS 0 /* [B, H, n_pad, DP]  token-major rows, head dim zero-padded to DP   */
+#define PRIMX_HEADS_VT 1   /* [B, H, DP, n_pad]  transposed, keys permuted inside 16-groups     */
+
+int primx_abi_version(void);
+const char* primx_last_error(void);
+
+/* Padded head dim used by the attention layouts: smallest multiple of 16 >= dh (72 -> 80). */
+int primx_padded_head_dim(int dh);
+
+/* ----------------------------------------------------------------------------------------------
+ * Row kernels of the DiT block
+ * -------------------------------------------------------------------------------------------- */
+
+/* out[r, :] = cast( LN(x[r, :]) * (1 + scale[b, :]) + shift[b, :] ),  b = r / rows_per_batch.
+ * LN has no affine, fp32 statistics, eps as given.  `shift`/`scale` are 16-bit vectors of
+ * length D taken at element stride `mod_stride` between batch entries (they are chunks of the
+ * adaLN output).  (1 + scale) is rounded to the 16-bit type first, as autocast does.
+ * Replaces nn.LayerNorm(elementwise_affine=False, eps=1e-6) + modulate():
+ * models/dit_crossattn.py:32-36,55-57,67,76 and models/utils.py:19-20.   D % 128 == 0. */
+int primx_layernorm_modulate(const float* x, const void* shift, const void* scale, int64_t mod_stride,
+                             void* out, int dtype, int rows, int rows_per_batch, int D, float eps,
+                             void* stream);
+
+/* emb[b, :] = [cos(t_b * f_k) | sin(t_b * f_k)], f_k = exp(-ln(max_period) * k / (dim/2)).
+ * Replaces TimestepEmbedder.timestep_embedding, models/utils.py:40-59 (dim even). */
+int primx_timestep_embedding(const int64_t* t, float* emb, int B, int dim, float max_period, void* stream);
+
+/* out = cast16( silu(in) ) elementwise.  The SiLU in front of every adaLN Linear
+ * (models/dit_crossattn.py:40-43,69-72) producing the 16-bit GEMM operand. */
+int primx_silu_cast(const float* in, void* out, int dtype, int64_t n, void* stream);
+
+/* out = cast16(in) elementwise: the fp32 -> fp16/bf16 cast autocast applies to a Linear's input
+ * (here: the conditioning tokens y in front of to_k / to_v, attention.py:106-107). */
+int primx_cast16(const float* in, void* out, int dtype, int64_t n, void* stream);
+
+/* Small fp32 linear: out[m, n] = act_out( sum_k in[m, k] * W[n, k] + bias[n] ), W in nn.Linear
+ * (out, in) layout, everything fp32 (these layers run outside autocast in the reference).
+ * act_out: 0 none, 1 SiLU.  Used for x_embedder (models/dit_crossattn.py:141,191) and the
+ * TimestepEmbedder MLP (models/utils.py:33-37). */
+int primx_linear_f32(const float* in, const float* W, const float* bias, float* out, int M, int N, int K,
+                     int act_out, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * MFMA GEMMs with fused epilogues.  A: [M, K] 16-bit row-major activations; W: [N, K] 16-bit,
+ * nn.Linear (out, in) layout; bias: [N] 16-bit or NULL.  K % 64 == 0.  fp32 accumulate.
+ * -------------------------------------------------------------------------------------------- */
+
+/* out[M, N] (16-bit) = out_scale * act(A W^T + bias), each stage rounded to the 16-bit type as
+ * autocast does (Linear output, activation output, scaled output).  out_scale == 1 skips the
+ * last rounding.  Replaces nn.Linear under autocast: Mlp.fc1 + GELU(tanh) (models/utils.py:87-96,
+ * dit_crossattn.py:38), adaLN Linear (dit_crossattn.py:40-43), FinalLayer.linear (:68). */
+int primx_linear(const void* A, const void* W, const void* bias, void* out, int M, int N, int K, int dtype,
+                 int act, float out_scale, void* stream);
+
+/* x[m, :] += cast16( gate[b, :] * cast16(A W^T + bias)[m, :] ),  b = m / rows_per_batch, x fp32.
+ * Replaces the projection Linear + gated residual `x = x + gate.unsqueeze(1) * branch`:
+ * attention.py:56,111 / models/utils.py:98 with dit_crossattn.py:55-57. */
+int primx_linear_gate_residual(const void* A, const void* W, const void* bias, const void* gate,
+                               int64_t gate_stride, float* x, int M, int N, int K, int rows_per_batch,
+                               int dtype, void* stream);
+
+/* Projection whose output columns are `n_seg` groups of (heads * dh) features, each written
+ * straight into an attention operand layout (see PRIMX_HEADS_*): dst[s] with kind[s]; rows of
+ * batch b (= m / rows_per_batch) go to [b, h, m % rows_per_batch, :].  Segment 0 is multiplied
+ * by `scale0` (after rounding) - the cross-attention `self.scale * to_q(q)` (attention.py:105).
+ * Pad rows/cols of the destinations are never written (callers zero them once).
+ * Replaces qkv Linear + reshape + unbind (attention.py:50-52) and to_q/to_k/to_v + reshape
+ * (attention.py:105-107). */
+int primx_linear_heads(const void* A, const void* W, const void* bias, int M, int N, int K, int rows_per_batch,
+                       int heads, int dh, int n_seg, const int* kind, void* const* dst, int n_pad,
+                       float scale0, int dtype, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Attention (flash-style, fp32 online softmax, MFMA 32x32x16)
+ * -------------------------------------------------------------------------------------------- */
+
+/* out[b, q, h*dh + d] = sum_k softmax_k( scale * <Q[b,h,q,:], K[b,h,k,:]> ) V[b,h,k,d]
+ * Qp: [B, H, nq_pad, DP] rows layout (nq_pad % 128 == 0); Kp: [B, H, nkv_pad, DP] rows layout;
+ * Vt: [B, H, DP, nkv_pad] VT layout (nkv_pad % 64 == 0); keys >= nkv are masked; pad entries of
+ * Kp/Vt/Qp must be finite (zero).  out: [B, nq, H*dh] 16-bit.  dh in {32, 64, 72}.
+ * Replaces xformers.ops.memory_efficient_attention(q, k, v) (attention.py:54,109). */
+int primx_attention(const void* Qp, const void* Kp, const void* Vt, void* out, int B, int H, int nq, int nq_pad,
+                    int nkv, int nkv_pad, int dh, float scale, int dtype, void* stream);
+
+/* Gather a [B, M, H, dh] tensor with arbitrary element strides (the xFormers BMHK operand, e.g.
+ * a view into the fused qkv buffer) into an attention operand layout. */
+int primx_pack_heads(const void* src, int64_t sb, int64_t sm, int64_t sh, void* dst, int kind, int B, int M,
+                     int H, int dh, int m_pad, int dtype, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Classifier-free guidance + the diffusion update
+ * -------------------------------------------------------------------------------------------- */
+
+/* out[b] = uncond[b] + s * (cond[b] - uncond[b]) with cond = in[0:B], uncond = in[B:2B], every
+ * operation rounded to the storage type (fp16/bf16 under autocast, fp32 otherwise).
+ * Replaces DiT.forward_with_cfg's combine, models/dit_crossattn.py:210-213.  n = elements per half. */
+int primx_cfg_combine(const void* in, void* out, int dtype, int64_t n, float s, void* stream);
+
+/* One reverse-diffusion update, fully fused.  coef: device table [n_steps, 16] fp32 built by the
+ * host (sampler.py step_coefficients), `step` selects the row.
+ *   mean_type 0 eps / 1 x0 / 2 v;  var_type 0 fixed-small / 1 fixed-large / 2 learned / 3 learned-range
+ *   ancestral 0: DDIM  (gaussian_diffusion.py:531-578);  1: p_sample (gaussian_diffusion.py:394-435)
+ * model_out: [B, n_tok, c_out] with c_out = C or 2C (variance channels second), dtype out_dtype.
+ * noise may be NULL when it would be multiplied by zero.  Writes sample and pred_xstart (fp32).
+ * Replaces p_mean_variance + _predict_xstart_from_z_and_v + _predict_eps_from_xstart + the DDIM
+ * / ancestral formulas: gaussian_diffusion.py:255-356,394-435,531-578,880-892. */
+int primx_diffusion_step(const float* x, const void* model_out, int out_dtype, int64_t n_rows, int C, int c_out,
+                         const float* coef, int step, int mean_type, int var_type, int ancestral, int clip,
+                         const float* noise, float* sample, float* pred_xstart, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * 3D-VAE decoder (models/vae3d_dib.py:330-387,437-440).  Activations are channels-last 16-bit:
+ * [P, V, C] with V = S^3 voxels in (z, y, x) raster order.
+ * -------------------------------------------------------------------------------------------- */
+
+/* GroupNorm(groups, eps, affine) + optional SiLU over one primitive's [V, C] block, fp32
+ * statistics; in/out 16-bit channels-last.  (vae3d_dib.py:109-112,131-139,366,383-384) */
+int primx_groupnorm_silu(const void* in, const float* gamma, const float* beta, void* out, int P, int V, int C,
+                         int groups, float eps, int silu, int dtype, void* stream);
+
+/* 3x3x3 convolution, stride 1, zero padding 1, on an S^3 grid, channels-last, as an implicit GEMM
+ * on MFMA: out[p, v, co] = ((bias[co] + sum_{tap, ci} in[p, v + tap, ci] * Wk[co, tap*Cin + ci]) + res[p, v, co])
+ * * res_scale.  Wk is the 16-bit weight re-laid by the host as [Cout, Kpad] with k = tap*Cin + ci
+ * (tap = (dz*3 + dy)*3 + dx), zero-padded to Kpad (a multiple of 64).  res may be NULL.  `zeros` points
+ * to >= 16 zero bytes on the device (read for out-of-volume taps).  Cin a power of two >= 8.
+ * Replaces nn.Conv3d(k=3, p=1) in ResnetBlock incl. the skip `(x + shortcut(res)) * skip_scale`
+ * (vae3d_dib.py:110,113,137-143) and, with a flipped/transposed weight, the output
+ * ConvTranspose3d(k=3, s=1, p=1) (vae3d_dib.py:367,385). */
+int primx_conv3d_k3(const void* in, const void* Wk, const void* bias, const void* res, float res_scale,
+                    const void* zeros, void* out, int P, int S, int Cin, int Cout, int Kpad, int dtype,
+                    void* stream);
+
+/* out[M, N] (16-bit) = ((A W^T + bias) + res) * scale with no intermediate rounding; res may be NULL.
+ * The 1x1 shortcut conv (vae3d_dib.py:124-125) and VolumeAttention's proj + `(x + res) * skip_scale`
+ * (vae3d_dib.py:43-46) on channels-last activations. */
+int primx_linear_residual(const void* A, const void* W, const void* bias, const void* res, float scale, void* out,
+                          int M, int N, int K, int dtype, void* stream);
+
+/* conv_in: Conv3d(1 -> Cout, k3, p1) on the fp32 latent grid after post_quant_conv's scalar affine
+ * z = a * x + b (vae3d_dib.py:344,373,429,438).  in: [P, S^3] fp32; W: [Cout, 27] fp32; out 16-bit CL. */
+int primx_conv_in(const float* in, float pq_scale, float pq_bias, const float* W, const float* bias, void* out,
+                  int P, int S, int Cout, int dtype, void* stream);
+
+/* ConvTranspose3d(C -> C, k=2, s=2): S^3 -> (2S)^3, no tap overlap; Wt: [8*Cout, Cin] 16-bit, row = tap*Cout + co,
+ * tap = (dz*2 + dy)*2 + dx.
+ * (vae3d_dib.py:251,264-265) */
+int primx_convtranspose_k2s2(const void* in, const void* Wt, const void* bias, void* out, int P, int S, int Cin,
+                             int Cout, int dtype, void* stream);
+
+/* Final layout change + inverse normalisation: channels-last 16-bit [P, V, C] -> fp32 [P, C, V]
+ * with channel 0 divided by sdf_div and the others mapped (x + 1) / 2 when `denorm` != 0
+ * (inference.py:345-346); denorm == 0 gives the raw VAE.decode output. */
+int primx_vae_output(const void* in, float* out, int P, int V, int C, int denorm, float sdf_div, int dtype,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRIMX_HIP_H */

@@ -1,0 +1,138 @@
+"""Generate the golden vectors from the REAL reference (run in the build container only):
+
+    python tests/golden/make_golden.py
+
+Imports the unmodified 3DTopia-XL modules from /root/reference through oracle/ref_import.py (xformers
+stand-in documented there), loads deterministic synthetic weights (oracle/synth.py - the reference's
+own init is all-zero in the adaLN / final layers, which would make parity vacuous), runs them in fp32
+on the CPU and stores inputs' seeds + outputs as small .npz fixtures next to this file.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import ref_import, synth  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# (name, DiT kwargs, heads, N tokens, L cond tokens, batch)
+DIT_CASES = [
+    ("dit_dh64", dict(in_channels=68, condition_channels=96, hidden_size=384, depth=2), 6, 256, 5, 2),
+    ("dit_dh72", dict(in_channels=68, condition_channels=64, hidden_size=288, depth=2), 4, 128, 70, 1),
+]
+VAE_CFG = dict(in_channels=6, latent_channels=1, out_channels=6, down_channels=[32, 256], mid_attention=True,
+               up_channels=[256, 32], layers_per_block=2, gradient_checkpointing=False)
+SEED = 1234
+
+
+def gen_schedule(diffusion_pkg):
+    out = {}
+    gd = sys.modules["models.diffusion.gaussian_diffusion"]
+    for n in (5, 25, 50, 100, 200):
+        d = diffusion_pkg.create_diffusion(timestep_respacing=f"ddim{n}", noise_schedule="squaredcos_cap_v2",
+                                           parameterization="v", diffusion_steps=1000)
+        out[f"ddim{n}_map"] = np.array(d.timestep_map, dtype=np.int64)
+        for attr in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                     "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                     "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1",
+                     "posterior_mean_coef2"):
+            out[f"ddim{n}_{attr}"] = np.asarray(getattr(d, attr), dtype=np.float64)
+    out["cos1000_betas"] = gd.get_named_beta_schedule("squaredcos_cap_v2", 1000)
+    out["lin1000_betas"] = gd.get_named_beta_schedule("linear", 1000)
+    out["lin250_betas"] = gd.get_named_beta_schedule("linear", 250)
+    respace = sys.modules["models.diffusion.respace"]
+    out["sections_300_10_15_20"] = np.array(sorted(respace.space_timesteps(300, [10, 15, 20])), dtype=np.int64)
+    out["sections_1000_str"] = np.array(sorted(respace.space_timesteps(1000, "7,3,11")), dtype=np.int64)
+    full = diffusion_pkg.create_diffusion(timestep_respacing="", noise_schedule="linear", parameterization="eps",
+                                          learn_sigma=False, diffusion_steps=50)
+    out["full50_map"] = np.array(full.timestep_map, dtype=np.int64)
+    out["full50_alphas_cumprod"] = full.alphas_cumprod
+    np.savez_compressed(os.path.join(HERE, "schedule.npz"), **out)
+
+
+def gen_dit(dit_mod, diffusion_pkg):
+    for name, cfg, heads, N, L, B in DIT_CASES:
+        model = dit_mod.DiT(seq_length=N, num_heads=heads, attn_proj_bias=True, cond_drop_prob=0.1, **cfg).eval()
+        sd = synth.dit_state_dict(SEED, **cfg)
+        model.load_state_dict(sd, strict=True)
+        x = synth.tensor(SEED, name + ".x", (B, N, cfg["in_channels"]))
+        y = synth.tensor(SEED, name + ".y", (B, L, cfg["condition_channels"]))
+        t = torch.tensor([960, 40][:B], dtype=torch.int64)
+        out = {}
+        with torch.no_grad():
+            out["t_emb_freq"] = model.t_embedder.timestep_embedding(torch.tensor([0, 1, 40, 500, 960, 999]), 256).numpy()
+            out["forward"] = model(x, t, y).numpy()
+            out["forward_cfg"] = model.forward_with_cfg(x, t, y, cfg_scale=6.0).numpy()
+            blk = model.blocks[0]
+            te = model.t_embedder(t)
+            out["block0"] = blk(model.x_embedder(x), y, te).numpy()
+            d = diffusion_pkg.create_diffusion(timestep_respacing="ddim5", noise_schedule="squaredcos_cap_v2",
+                                               parameterization="v", diffusion_steps=1000)
+            traj = []
+            for s in d.ddim_sample_loop_progressive(model.forward_with_cfg, x.shape, noise=x, clip_denoised=False,
+                                                    model_kwargs=dict(y=y, cfg_scale=6.0), device="cpu"):
+                traj.append(s["sample"].numpy())
+            out["ddim5_samples"] = np.stack(traj)
+            last = s["pred_xstart"].numpy()
+            out["ddim5_last_pred_xstart"] = last
+            # one ancestral step (p_sample) with fixed noise via a seeded generator is RNG-dependent;
+            # store the pieces that are not: mean / log-variance of p_mean_variance at spaced t = 3
+            tt = torch.full((B,), 3, dtype=torch.int64)
+            pmv = d.p_mean_variance(model.forward_with_cfg, x, tt, clip_denoised=False,
+                                    model_kwargs=dict(y=y, cfg_scale=6.0))
+            out["pmv_mean"] = pmv["mean"].numpy()
+            out["pmv_log_variance"] = pmv["log_variance"].numpy()
+        out["seed"] = np.int64(SEED)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+def gen_attention(att_mod):
+    out = {}
+    with torch.no_grad():
+        m = att_mod.MemEffAttention(dim=256, num_heads=8, qkv_bias=False, proj_bias=True).eval()
+        sd = synth.state_dict_like(SEED, m.state_dict())
+        m.load_state_dict(sd)
+        x = synth.tensor(SEED, "att.x", (3, 64, 256))
+        out["self_dh32"] = m(x).numpy()
+        c = att_mod.MemEffCrossAttention(dim=144, dim_q=144, dim_k=40, dim_v=40, num_heads=2, qkv_bias=True,
+                                         proj_bias=True).eval()
+        c.load_state_dict(synth.state_dict_like(SEED, c.state_dict()))
+        q = synth.tensor(SEED, "catt.q", (2, 96, 144))
+        kv = synth.tensor(SEED, "catt.kv", (2, 37, 40))
+        out["cross_dh72"] = c(q, kv, kv).numpy()
+    np.savez_compressed(os.path.join(HERE, "attention.npz"), **out)
+
+
+def gen_vae(vae_mod):
+    vae = vae_mod.VAE(**VAE_CFG).eval()
+    sd = synth.state_dict_like(SEED, vae.state_dict())
+    vae.load_state_dict(sd, strict=True)
+    z = synth.tensor(SEED, "vae.z", (3, 1, 4, 4, 4))
+    with torch.no_grad():
+        dec = vae.decode(z).numpy()
+    np.savez_compressed(os.path.join(HERE, "vae_decode.npz"), decoded=dec, seed=np.int64(SEED),
+                        keys=np.array(sorted(sd.keys())),
+                        shapes=np.array([str(tuple(sd[k].shape)) for k in sorted(sd.keys())]))
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    dit_mod, vae_mod, diffusion_pkg, att_mod = ref_import.load()
+    gen_schedule(diffusion_pkg)
+    gen_dit(dit_mod, diffusion_pkg)
+    gen_attention(att_mod)
+    gen_vae(vae_mod)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,78 @@
+"""Drop-in surface of the modules (no GPU): same state_dict keys/shapes as the reference, strict
+load works, CPU tensors are refused loudly (there is no fallback path)."""
+import subprocess
+import sys
+import os
+
+import pytest
+import torch
+
+from oracle import synth
+from tests.golden.make_golden import SEED, VAE_CFG
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+XL = dict(seq_length=2048, in_channels=68, condition_channels=768, hidden_size=1152, depth=28, num_heads=16,
+          attn_proj_bias=True, cond_drop_prob=0.1, gradient_checkpointing=False)  # configs/inference_dit.yml:52-62
+
+
+def test_dit_state_dict_keys_match_reference_layout(pkg):
+    cfg = dict(in_channels=68, condition_channels=96, hidden_size=384, depth=3)
+    m = pkg.DiT(seq_length=64, num_heads=6, attn_proj_bias=True, cond_drop_prob=0.1, **cfg)
+    want = synth.dit_shapes(**cfg)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == want
+    m.load_state_dict(synth.dit_state_dict(SEED, **cfg), strict=True)
+    # zero-init of adaLN / final layers as in the reference (dit_crossattn.py:173-182)
+    fresh = pkg.DiT(seq_length=64, num_heads=6, attn_proj_bias=True, cond_drop_prob=0.1, **cfg)
+    assert float(fresh.final_layer.linear.weight.detach().abs().max()) == 0.0
+    assert float(fresh.blocks[0].adaLN_modulation[1].weight.detach().abs().max()) == 0.0
+
+
+def test_dit_xl_has_515_tensors_909M_params(pkg):
+    with torch.device("meta"):
+        m = pkg.DiT(**XL)
+    sd = m.state_dict()
+    assert len(sd) == 515
+    assert abs(sum(v.numel() for v in sd.values()) / 1e6 - 909.43) < 0.01
+    assert tuple(sd["blocks.0.attn.qkv.weight"].shape) == (3456, 1152)
+    assert tuple(sd["blocks.27.adaLN_modulation.1.weight"].shape) == (10368, 1152)
+    assert tuple(sd["null_cond_embedding"].shape) == (768,)
+
+
+def test_vae_state_dict_keys_match_reference(pkg, golden):
+    g = golden("vae_decode")
+    want = {str(k): eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    vae = pkg.VAE(**VAE_CFG)
+    got = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
+    assert got == want
+    vae.load_state_dict(synth.state_dict_like(SEED, vae.state_dict()), strict=True)
+
+
+def test_cpu_tensors_are_refused(pkg):
+    cfg = dict(in_channels=68, condition_channels=96, hidden_size=384, depth=1)
+    m = pkg.DiT(seq_length=64, num_heads=6, attn_proj_bias=True, cond_drop_prob=0.1, **cfg).eval()
+    x, t, y = torch.zeros(1, 64, 68), torch.zeros(1, dtype=torch.long), torch.zeros(1, 3, 96)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(x, t, y, torch.float16, True)
+    with pytest.raises(NotImplementedError):
+        m(x, t, y)                                 # fp32 / no-amp variant is not accelerated
+    vae = pkg.VAE(**VAE_CFG)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        vae.decode(torch.zeros(2, 1, 4, 4, 4))
+    with pytest.raises(RuntimeError):
+        pkg.memory_efficient_attention(torch.zeros(1, 4, 2, 32, dtype=torch.float16),
+                                       torch.zeros(1, 4, 2, 32, dtype=torch.float16),
+                                       torch.zeros(1, 4, 2, 32, dtype=torch.float16))
+
+
+def test_compat_shim_resolves_reference_class_names():
+    """compat/ mirrors the reference's import paths (configs/inference_dit.yml:32,53 class_name strings)."""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "import importlib;"
+            "m = importlib.import_module('models.dit_crossattn'); v = importlib.import_module('models.vae3d_dib');"
+            "d = importlib.import_module('models.diffusion');"
+            "import topia_xl_amd as p;"
+            "assert m.DiT is p.DiT and v.VAE is p.VAE and d.create_diffusion is p.create_diffusion; print('ok')"
+            ) % (ROOT, os.path.join(ROOT, "compat"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
