@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libprimx_hip.so")
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH = 0, 1
 HEADS_ROWS, HEADS_VT = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -25,7 +25,7 @@ SIGNATURES = {
     "primx_last_error": [],
     "primx_padded_head_dim": [_i],
     "primx_layernorm_modulate": [_p, _p, _p, _l, _p, _i, _i, _i, _i, _f, _p],
-    "primx_timestep_embedding": [_p, _p, _i, _i, _f, _p],
+    "primx_timestep_embedding": [_p, _p, _p, _i, _i, _p],
     "primx_silu_cast": [_p, _p, _i, _l, _p],
     "primx_cast16": [_p, _p, _i, _l, _p],
     "primx_linear_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
@@ -37,7 +37,7 @@ SIGNATURES = {
     "primx_cfg_combine": [_p, _p, _i, _l, _f, _p],
     "primx_diffusion_step": [_p, _p, _i, _l, _i, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "primx_groupnorm_silu": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p],
-    "primx_conv3d_k3": [_p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "primx_conv3d_k3": [_p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _i, _p],
     "primx_linear_residual": [_p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _p],
     "primx_conv_in": [_p, _f, _f, _p, _p, _p, _i, _i, _i, _i, _p],
     "primx_convtranspose_k2s2": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

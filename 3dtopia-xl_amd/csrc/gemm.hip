@@ -19,6 +19,9 @@
 
 namespace {
 
+// 16 zero bytes: the source of every out-of-range operand chunk (K tail, conv padding taps)
+__device__ const u32x4 g_zero16 = {0u, 0u, 0u, 0u};
+
 constexpr int BK = 64;
 constexpr int LROW = BK + 8;  // padded LDS row (halves)
 
@@ -48,7 +51,6 @@ struct GemmArgs {
     // EPI_RES: out = cast16((acc + bias + res) * out_scale); res may be null
     const S* res;
     // conv gather (GATHER) and EPI_CONVT geometry
-    const S* zeros;       // >= 16 bytes of zeros
     int S3;               // grid edge S (volume S^3)
     int cin_log2;         // log2(Cin)
     int cout;             // EPI_CONVT: N = 8 * cout
@@ -115,6 +117,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs<DT> p) {
     }
     const bool w_active = (NW * 256 <= BN * 8) || (tid < BN * 8);  // Narrow: one chunk per thread, all active
 
+    const S* zeros = reinterpret_cast<const S*>(&g_zero16);
     auto load_a = [&](int kt, V8 (&r)[NA]) {
         if (GATHER) {
             const int kk = kt * BK + kc;
@@ -126,17 +129,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs<DT> p) {
                 const bool ok = tap < 27 && (unsigned)z < (unsigned)p.S3 && (unsigned)y < (unsigned)p.S3 &&
                                 (unsigned)x < (unsigned)p.S3;
                 const S* src = gbase[i] + ((int64_t)((z * p.S3 + y) * p.S3 + x) << p.cin_log2) + ci;
-                r[i] = *reinterpret_cast<const V8*>(ok ? src : p.zeros);
+                r[i] = *reinterpret_cast<const V8*>(ok ? src : zeros);
             }
         } else {
+            const bool k_ok = kt * BK + kc < p.K;  // K tail (K % 64 != 0): zero chunk
 #pragma unroll
-            for (int i = 0; i < NA; ++i) r[i] = *reinterpret_cast<const V8*>(ga[i] + kt * BK);
+            for (int i = 0; i < NA; ++i) r[i] = *reinterpret_cast<const V8*>(k_ok ? ga[i] + kt * BK : zeros);
         }
     };
     auto load_w = [&](int kt, V8 (&r)[NW]) {
+        const bool k_ok = kt * BK + kc < p.K;
 #pragma unroll
         for (int i = 0; i < NW; ++i)
-            if (w_active) r[i] = *reinterpret_cast<const V8*>(gw[i] + kt * BK);
+            if (w_active) r[i] = *reinterpret_cast<const V8*>(k_ok ? gw[i] + kt * BK : zeros);
     };
     auto store_tiles = [&](int buf, V8 (&ra)[NA], V8 (&rw)[NW]) {
         S* base = smem + buf * (TA + TW);
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs<DT> p) {
     store_tiles(0, ra_, rw_);
     __syncthreads();
 
-    const int nk = p.K / BK;
+    const int nk = (p.K + BK - 1) / BK;
     const int a_rd = (wm * MI * 32 + l31) * LROW + hi * 8;
     const int w_rd = (wn * NI * 32 + l31) * LROW + hi * 8;
     for (int kt = 0; kt < nk; ++kt) {
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs<DT> p) {
 template <int DT, int EPI, int GATHER = 0>
 int launch(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
     PRIMX_REQUIRE(a.A && a.W, "%s: null operand", name);
-    PRIMX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % BK == 0, "%s: need M,N>0 and K %% 64 == 0 (M=%d N=%d K=%d)",
+    PRIMX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 8 == 0, "%s: need M,N>0 and K %% 8 == 0 (M=%d N=%d K=%d)",
                   name, a.M, a.N, a.K);
     const int mt = (a.M + 127) / 128;
     if (a.N <= 32) {  // Narrow tile
@@ -391,9 +396,8 @@ extern "C" int primx_linear_heads(const void* A, const void* W, const void* bias
 }
 
 extern "C" int primx_conv3d_k3(const void* in, const void* Wk, const void* bias, const void* res, float res_scale,
-                               const void* zeros, void* out, int P, int S, int Cin, int Cout, int Kpad, int dtype,
-                               void* stream) {
-    PRIMX_REQUIRE(in && Wk && zeros && out, "primx_conv3d_k3: null pointer");
+                               void* out, int P, int S, int Cin, int Cout, int Kpad, int dtype, void* stream) {
+    PRIMX_REQUIRE(in && Wk && out, "primx_conv3d_k3: null pointer");
     const int cl = ilog2_exact(Cin);
     PRIMX_REQUIRE(P > 0 && S > 0 && Cout > 0 && cl >= 3, "primx_conv3d_k3: Cin must be a power of two >= 8 (Cin=%d)", Cin);
     PRIMX_REQUIRE(Kpad >= 27 * Cin && Kpad % BK == 0, "primx_conv3d_k3: Kpad must be a multiple of 64 >= 27*Cin");
@@ -403,7 +407,7 @@ extern "C" int primx_conv3d_k3(const void* in, const void* Wk, const void* bias,
         a.A = (const Sx*)in; a.W = (const Sx*)Wk; a.bias = (const Sx*)bias;
         a.M = P * S * S * S; a.N = Cout; a.K = Kpad;
         a.out = (Sx*)out; a.res = (const Sx*)res; a.out_scale = res_scale;
-        a.zeros = (const Sx*)zeros; a.S3 = S; a.cin_log2 = cl;
+        a.S3 = S; a.cin_log2 = cl;
         return launch<DT, EPI_RES, 1>(a, (hipStream_t)stream, "primx_conv3d_k3");
     });
     return PRIMX_OK;
@@ -412,7 +416,7 @@ extern "C" int primx_conv3d_k3(const void* in, const void* Wk, const void* bias,
 extern "C" int primx_convtranspose_k2s2(const void* in, const void* Wt, const void* bias, void* out, int P, int S,
                                         int Cin, int Cout, int dtype, void* stream) {
     PRIMX_REQUIRE(in && Wt && out, "primx_convtranspose_k2s2: null pointer");
-    PRIMX_REQUIRE(P > 0 && S > 0 && Cout > 0 && Cin % BK == 0, "primx_convtranspose_k2s2: Cin %% 64 != 0");
+    PRIMX_REQUIRE(P > 0 && S > 0 && Cout > 0 && Cin % 8 == 0, "primx_convtranspose_k2s2: Cin %% 8 != 0");
     PRIMX_DISPATCH_16(dtype, "primx_convtranspose_k2s2", {
         using Sx = typename T16<DT>::S;
         GemmArgs<DT> a = {};

@@ -27,10 +27,10 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
                                                          const typename T16<DT>::S* __restrict__ shift,
                                                          const typename T16<DT>::S* __restrict__ scale,
                                                          int64_t mod_stride, typename T16<DT>::S* __restrict__ out,
-                                                         int rows, int rows_per_batch, float eps) {
+                                                         int rows, int rows_per_batch, int D, float eps) {
+    // NCH = ceil(D / 128); lanes whose column falls beyond D in the last chunk are masked
     using S = typename T16<DT>::S;
     using V2 = typename T16<DT>::V2;
-    constexpr int D = NCH * 128;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -39,15 +39,17 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        v[c] = *reinterpret_cast<const f32x2*>(xr + c * 128 + lane * 2);
+        const bool in = c * 128 + lane * 2 < D;
+        v[c] = in ? *reinterpret_cast<const f32x2*>(xr + c * 128 + lane * 2) : f32x2{0.f, 0.f};
         s += v[c].x + v[c].y;
     }
     const float mean = wave_sum(s) * (1.0f / D);
     float q = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
+        const bool in = c * 128 + lane * 2 < D;
         float a = v[c].x - mean, b = v[c].y - mean;
-        q += a * a + b * b;
+        q += in ? a * a + b * b : 0.f;
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
     const int b = row / rows_per_batch;
@@ -57,6 +59,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int col = c * 128 + lane * 2;
+        if (col >= D) continue;
         V2 s2 = *reinterpret_cast<const V2*>(sc + col);
         V2 h2 = *reinterpret_cast<const V2*>(sh + col);
         // (1 + scale) is formed in the 16-bit type (autocast: fp16 tensor + python scalar)
@@ -78,18 +81,11 @@ static int launch_ln_modulate(const float* x, const void* shift, const void* sca
 #define LN_CASE(N)                                                                                              \
     case N:                                                                                                     \
         hipLaunchKernelGGL((ln_modulate_kernel<DT, N>), grid, block, 0, st, x, (const S*)shift, (const S*)scale, \
-                           mod_stride, (S*)out, rows, rows_per_batch, eps);                                     \
+                           mod_stride, (S*)out, rows, rows_per_batch, D, eps);                                     \
         break;
-    switch (D / 128) {
-        LN_CASE(1)
-        LN_CASE(2)
-        LN_CASE(3)
-        LN_CASE(4)
-        LN_CASE(6)
-        LN_CASE(8)
-        LN_CASE(9)
-        LN_CASE(12)
-        LN_CASE(16)
+    switch ((D + 127) / 128) {
+        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
+        LN_CASE(9) LN_CASE(10) LN_CASE(11) LN_CASE(12) LN_CASE(13) LN_CASE(14) LN_CASE(15) LN_CASE(16)
         default:
             primx_set_error("primx_layernorm_modulate: unsupported D=%d", D);
             return PRIMX_EINVAL;
@@ -102,8 +98,8 @@ extern "C" int primx_layernorm_modulate(const float* x, const void* shift, const
                                         void* out, int dtype, int rows, int rows_per_batch, int D, float eps,
                                         void* stream) {
     PRIMX_REQUIRE(x && shift && scale && out, "primx_layernorm_modulate: null pointer");
-    PRIMX_REQUIRE(rows > 0 && rows_per_batch > 0 && D > 0 && D % 128 == 0,
-                  "primx_layernorm_modulate: need rows>0, rows_per_batch>0, D%%128==0 (D=%d)", D);
+    PRIMX_REQUIRE(rows > 0 && rows_per_batch > 0 && D > 0 && D % 2 == 0 && D <= 2048,
+                  "primx_layernorm_modulate: need rows>0, rows_per_batch>0, D even and <= 2048 (D=%d)", D);
     int rc = PRIMX_OK;
     PRIMX_DISPATCH_16(dtype, "primx_layernorm_modulate",
                       rc = launch_ln_modulate<DT>(x, shift, scale, mod_stride, out, rows, rows_per_batch, D, eps,
@@ -114,26 +110,24 @@ extern "C" int primx_layernorm_modulate(const float* x, const void* shift, const
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, float* __restrict__ emb, int B, int dim,
-                                          float neg_log_period) {
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, const float* __restrict__ freqs,
+                                          float* __restrict__ emb, int B, int dim) {
     const int half = dim / 2;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * half) return;
     const int b = idx / half, k = idx % half;
-    // torch: exp(-log(P) * arange(half, fp32) / half) then t.float() * freq, all fp32
-    const float freq = expf(neg_log_period * (float)k / (float)half);
-    const float arg = (float)t[b] * freq;
+    const float arg = (float)t[b] * freqs[k];  // t[:, None].float() * freqs[None]   (models/utils.py:55)
     emb[(int64_t)b * dim + k] = cosf(arg);
     emb[(int64_t)b * dim + half + k] = sinf(arg);
 }
 
-extern "C" int primx_timestep_embedding(const int64_t* t, float* emb, int B, int dim, float max_period,
+extern "C" int primx_timestep_embedding(const int64_t* t, const float* freqs, float* emb, int B, int dim,
                                         void* stream) {
-    PRIMX_REQUIRE(t && emb, "primx_timestep_embedding: null pointer");
+    PRIMX_REQUIRE(t && freqs && emb, "primx_timestep_embedding: null pointer");
     PRIMX_REQUIRE(B > 0 && dim > 0 && dim % 2 == 0, "primx_timestep_embedding: dim must be even");
     const int n = B * (dim / 2);
-    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, emb,
-                       B, dim, (float)(-log((double)max_period)));
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, freqs,
+                       emb, B, dim);
     PRIMX_CHECK_LAUNCH("primx_timestep_embedding");
     return PRIMX_OK;
 }

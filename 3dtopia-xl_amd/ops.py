@@ -39,6 +39,23 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional per-launch timing of the MFMA kernels (bench.py's roofline leg): when PROFILE is a list, every
+# GEMM / attention launch is bracketed by HIP events recorded on the launch stream (torch's current
+# stream) and (kernel family, algorithmic FLOPs, start, end) is appended.  No host synchronisation.
+PROFILE = None
+
+
+def _timed(tag: str, flops: float, fn):
+    if PROFILE is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = fn()
+    e.record()
+    PROFILE.append((tag, flops, s, e))
+    return r
+
+
 def padded_head_dim(dh: int) -> int:
     return (dh + 15) // 16 * 16
 
@@ -62,11 +79,28 @@ def layernorm_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor
     return out
 
 
+_FREQS = {}
+
+
+def _freq_table(dim: int, max_period: float, device) -> torch.Tensor:
+    """exp(-ln(P) * arange(dim/2, fp32) / (dim/2)) evaluated with torch CPU ops, exactly as the reference
+    does before ``.to(device)`` (models/utils.py:51-54); cached per (dim, period, device)."""
+    key = (dim, float(max_period), str(device))
+    tab = _FREQS.get(key)
+    if tab is None:
+        import math
+        half = dim // 2
+        tab = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half).to(device)
+        _FREQS[key] = tab
+    return tab
+
+
 def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
     t = t.to(torch.int64).contiguous()
     out = torch.empty(t.shape[0], dim, dtype=torch.float32, device=t.device)
-    check(_lib.load().primx_timestep_embedding(_dev(t, "t"), out.data_ptr(), t.shape[0], dim, max_period,
-                                               _stream()), "primx_timestep_embedding")
+    check(_lib.load().primx_timestep_embedding(_dev(t, "t"), _freq_table(dim, max_period, t.device).data_ptr(),
+                                               out.data_ptr(), t.shape[0], dim, _stream()),
+          "primx_timestep_embedding")
     return out
 
 
@@ -103,9 +137,9 @@ def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: 
         raise RuntimeError("linear: operand mismatch")
     if out is None:
         out = torch.empty(M, N, dtype=A.dtype, device=A.device)
-    check(_lib.load().primx_linear(_dev(A, "A"), _dev(W, "W"), _dev(bias, "bias", A.dtype) if bias is not None else None,
-                                   _dev(out, "out", A.dtype), M, N, K, dtype_code(A.dtype), act, out_scale, _stream()),
-          "primx_linear")
+    _timed("gemm_kernel<EPI_LINEAR>", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear(
+        _dev(A, "A"), _dev(W, "W"), _dev(bias, "bias", A.dtype) if bias is not None else None,
+        _dev(out, "out", A.dtype), M, N, K, dtype_code(A.dtype), act, out_scale, _stream()), "primx_linear"))
     return out
 
 
@@ -116,10 +150,10 @@ def linear_gate_residual(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.
     N = W.shape[0]
     if gate.stride(-1) != 1 or gate.dtype != A.dtype or not gate.is_cuda:
         raise RuntimeError("gate must be a last-dim-contiguous 16-bit device view")
-    check(_lib.load().primx_linear_gate_residual(
+    _timed("gemm_kernel<EPI_GATE_RESIDUAL>", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_gate_residual(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None,
         gate.data_ptr(), gate.stride(0), _dev(x, "x", torch.float32), M, N, K, rows_per_batch,
-        dtype_code(A.dtype), _stream()), "primx_linear_gate_residual")
+        dtype_code(A.dtype), _stream()), "primx_linear_gate_residual"))
     return x
 
 
@@ -131,10 +165,10 @@ def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     n_seg = len(kinds)
     kind_arr = (C.c_int * n_seg)(*kinds)
     dst_arr = (C.c_void_p * n_seg)(*[_dev(d, "dst", A.dtype) for d in dsts])
-    check(_lib.load().primx_linear_heads(
+    _timed("gemm_kernel<EPI_HEADS>", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_heads(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None, M, N, K,
         rows_per_batch, heads, dh, n_seg, kind_arr, dst_arr, n_pad, scale0, dtype_code(A.dtype), _stream()),
-        "primx_linear_heads")
+        "primx_linear_heads"))
 
 
 # ----------------------------------------------------------------------------- attention
@@ -154,9 +188,10 @@ def attention(Qp: torch.Tensor, Kp: torch.Tensor, Vt: torch.Tensor, nq: int, nkv
         raise RuntimeError("attention: operand layout mismatch")
     if out is None:
         out = torch.empty(B, nq, H * dh, dtype=Qp.dtype, device=Qp.device)
-    check(_lib.load().primx_attention(_dev(Qp, "Qp"), _dev(Kp, "Kp", Qp.dtype), _dev(Vt, "Vt", Qp.dtype),
-                                      _dev(out, "out", Qp.dtype), B, H, nq, nq_pad, nkv, nkv_pad, dh, scale,
-                                      dtype_code(Qp.dtype), _stream()), "primx_attention")
+    # algorithmic FLOPs: QK^T + PV on the unpadded head dim, softmax excluded
+    _timed("attn_kernel", 4.0 * B * H * nq * nkv * dh, lambda: check(_lib.load().primx_attention(
+        _dev(Qp, "Qp"), _dev(Kp, "Kp", Qp.dtype), _dev(Vt, "Vt", Qp.dtype), _dev(out, "out", Qp.dtype), B, H, nq,
+        nq_pad, nkv, nkv_pad, dh, scale, dtype_code(Qp.dtype), _stream()), "primx_attention"))
     return out
 
 
@@ -224,16 +259,6 @@ def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
     return out
 
 
-_ZEROS = {}
-
-
-def _zeros16(device) -> torch.Tensor:
-    z = _ZEROS.get(str(device))
-    if z is None:
-        z = _ZEROS[str(device)] = torch.zeros(64, dtype=torch.uint8, device=device)
-    return z
-
-
 def conv3d_k3(x: torch.Tensor, Wk: torch.Tensor, bias: Optional[torch.Tensor], S: int,
               res: Optional[torch.Tensor] = None, res_scale: float = 1.0) -> torch.Tensor:
     """x: [P, S^3, Cin]; Wk: [Cout, Kpad] 16-bit (k = tap*Cin + ci); optional fused (conv + res) * res_scale."""
@@ -243,7 +268,7 @@ def conv3d_k3(x: torch.Tensor, Wk: torch.Tensor, bias: Optional[torch.Tensor], S
     check(_lib.load().primx_conv3d_k3(_dev(x, "x"), _dev(Wk, "Wk", x.dtype),
                                       _dev(bias, "bias", x.dtype) if bias is not None else None,
                                       _dev(res, "res", x.dtype) if res is not None else None, res_scale,
-                                      _zeros16(x.device).data_ptr(), out.data_ptr(), P, S, Cin, Cout, Kpad,
+                                      out.data_ptr(), P, S, Cin, Cout, Kpad,
                                       dtype_code(x.dtype), _stream()),
           "primx_conv3d_k3")
     return out

@@ -1,0 +1,136 @@
+"""Batch-sharded multi-GPU sampling: one process per GPU, RCCL over xGMI only at the edges.
+
+Samples never interact on this path (attention is within one sample's tokens, CFG pairs a sample
+with its own null-conditioned copy, VAE primitives are independent - SURVEY.md section 8e), so the
+unit of sharding is the user sample and the DDIM loop itself needs NO collective:
+
+    once   : broadcast(weights)   - ONE flat buffer per dtype (the reference has 515 tensors; a single
+             large broadcast is link-efficient on point-to-point xGMI, 515 small ones are latency-bound)
+             scatter(noise), scatter(conditioning)   (rank 0 draws the whole batch's noise from the one
+             seeded CPU generator, preserving the reference's seed semantics - inference.py:251,316)
+    loop   : per-rank ``ddim_sample_loop`` on its slice            (zero collectives)
+    end    : gather(samples) to rank 0
+
+Works unchanged with world_size 1 (no process group needed) and on CPU tensors with the ``gloo``
+backend for the plumbing tests; the sampler itself still requires a HIP device.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items: int, world_size: int) -> List[Tuple[int, int]]:
+    """Contiguous, as-even-as-possible slices: the first ``n_items % world_size`` ranks get one extra."""
+    base, extra = divmod(n_items, world_size)
+    out, lo = [], 0
+    for r in range(world_size):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def _world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def broadcast_module_(module: torch.nn.Module, src: int = 0) -> int:
+    """In-place broadcast of every parameter and buffer as ONE flat tensor per dtype.  Returns bytes sent."""
+    rank, world = _world()
+    if world == 1:
+        return 0
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    total = 0
+    for dt in sorted({t.dtype for t in tensors}, key=str):
+        group = [t for t in tensors if t.dtype == dt]
+        flat = torch.cat([t.reshape(-1) for t in group])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in group:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+        total += flat.numel() * flat.element_size()
+    if hasattr(module, "repack"):
+        module.repack()
+    return total
+
+
+def scatter_batch(full: Optional[torch.Tensor], shape_tail: Sequence[int], n_items: int, dtype: torch.dtype,
+                  device, src: int = 0) -> torch.Tensor:
+    """Rank ``src`` holds ``full`` [n_items, *shape_tail]; every rank receives its contiguous slice."""
+    rank, world = _world()
+    lo, hi = shard_bounds(n_items, world)[rank]
+    if world == 1:
+        return full[lo:hi].to(device=device, dtype=dtype)
+    mine = torch.empty((hi - lo, *shape_tail), dtype=dtype, device=device)
+    # uneven slices: pad every chunk to the largest so a single scatter suffices
+    mx = max(h - l for l, h in shard_bounds(n_items, world))
+    recv = torch.empty((mx, *shape_tail), dtype=dtype, device=device)
+    chunks = None
+    if rank == src:
+        chunks = []
+        for l, h in shard_bounds(n_items, world):
+            c = torch.zeros((mx, *shape_tail), dtype=dtype, device=device)
+            c[:h - l] = full[l:h].to(device=device, dtype=dtype)
+            chunks.append(c)
+    dist.scatter(recv, chunks, src=src)
+    mine.copy_(recv[:hi - lo])
+    return mine
+
+
+def gather_batch(local: torch.Tensor, n_items: int, dst: int = 0) -> Optional[torch.Tensor]:
+    """Inverse of scatter_batch: rank ``dst`` gets [n_items, ...], other ranks None."""
+    rank, world = _world()
+    if world == 1:
+        return local
+    bounds = shard_bounds(n_items, world)
+    mx = max(h - l for l, h in bounds)
+    send = torch.zeros((mx, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    send[:local.shape[0]] = local
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[:h - l] for b, (l, h) in zip(bufs, bounds)], dim=0)
+
+
+class ShardedSampler:
+    """Batch-sharded DDIM sampling over the ranks of the default process group."""
+
+    def __init__(self, model: torch.nn.Module, diffusion, device, sync_weights: bool = True):
+        self.model, self.diffusion, self.device = model, diffusion, torch.device(device)
+        self.rank, self.world = _world()
+        self.weight_bytes = broadcast_module_(model, 0) if sync_weights else 0
+
+    def sample(self, batch: int, n_tokens: int, channels: int, cond: Optional[torch.Tensor], seed: Optional[int],
+               loop: Optional[Callable] = None, **model_kwargs) -> Optional[torch.Tensor]:
+        """cond: [batch, L, Dc] on rank 0 (None elsewhere).  Returns the [batch, n_tokens, channels] samples on
+        rank 0.  ``loop(noise_slice, cond_slice) -> samples`` overrides the DDIM call (used by the CPU tests)."""
+        noise = None
+        if self.rank == 0:
+            gen = torch.Generator().manual_seed(seed) if seed is not None else None
+            noise = torch.randn(batch, n_tokens, channels, generator=gen)        # CPU draw, as inference.py:316
+        cond_tail = None
+        if self.world > 1:
+            meta = [tuple(cond.shape[1:])] if self.rank == 0 else [None]
+            dist.broadcast_object_list(meta, src=0)
+            cond_tail = meta[0]
+        else:
+            cond_tail = tuple(cond.shape[1:])
+        x = scatter_batch(noise, (n_tokens, channels), batch, torch.float32, self.device)
+        y = scatter_batch(cond, cond_tail, batch, torch.float32, self.device)
+        if x.shape[0] == 0:
+            out = x
+        elif loop is not None:
+            out = loop(x, y)
+        else:
+            out = self.diffusion.ddim_sample_loop(self.model.forward_with_cfg, tuple(x.shape), noise=x,
+                                                  clip_denoised=False, model_kwargs=dict(y=y, **model_kwargs),
+                                                  device=self.device)
+        return gather_batch(out, batch)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 4
+#define PRIMX_ABI_VERSION 5
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -63,14 +63,16 @@ int primx_padded_head_dim(int dh);
  * length D taken at element stride `mod_stride` between batch entries (they are chunks of the
  * adaLN output).  (1 + scale) is rounded to the 16-bit type first, as autocast does.
  * Replaces nn.LayerNorm(elementwise_affine=False, eps=1e-6) + modulate():
- * models/dit_crossattn.py:32-36,55-57,67,76 and models/utils.py:19-20.   D % 128 == 0. */
+ * models/dit_crossattn.py:32-36,55-57,67,76 and models/utils.py:19-20.   D even, D <= 2048. */
 int primx_layernorm_modulate(const float* x, const void* shift, const void* scale, int64_t mod_stride,
                              void* out, int dtype, int rows, int rows_per_batch, int D, float eps,
                              void* stream);
 
-/* emb[b, :] = [cos(t_b * f_k) | sin(t_b * f_k)], f_k = exp(-ln(max_period) * k / (dim/2)).
+/* emb[b, :] = [cos(t_b * f_k) | sin(t_b * f_k)], k < dim/2.  `freqs` (dim/2 floats, device) is the
+ * table f_k = exp(-ln(max_period) * k / (dim/2)) that the reference also evaluates on the HOST before
+ * moving it to the device (models/utils.py:51-54); the product and the sin/cos run here in fp32.
  * Replaces TimestepEmbedder.timestep_embedding, models/utils.py:40-59 (dim even). */
-int primx_timestep_embedding(const int64_t* t, float* emb, int B, int dim, float max_period, void* stream);
+int primx_timestep_embedding(const int64_t* t, const float* freqs, float* emb, int B, int dim, void* stream);
 
 /* out = cast16( silu(in) ) elementwise.  The SiLU in front of every adaLN Linear
  * (models/dit_crossattn.py:40-43,69-72) producing the 16-bit GEMM operand. */
@@ -89,7 +91,7 @@ int primx_linear_f32(const float* in, const float* W, const float* bias, float* 
 
 /* ----------------------------------------------------------------------------------------------
  * MFMA GEMMs with fused epilogues.  A: [M, K] 16-bit row-major activations; W: [N, K] 16-bit,
- * nn.Linear (out, in) layout; bias: [N] 16-bit or NULL.  K % 64 == 0.  fp32 accumulate.
+ * nn.Linear (out, in) layout; bias: [N] 16-bit or NULL.  K % 8 == 0.  fp32 accumulate.
  * -------------------------------------------------------------------------------------------- */
 
 /* out[M, N] (16-bit) = out_scale * act(A W^T + bias), each stage rounded to the 16-bit type as
@@ -168,14 +170,13 @@ int primx_groupnorm_silu(const void* in, const float* gamma, const float* beta, 
 /* 3x3x3 convolution, stride 1, zero padding 1, on an S^3 grid, channels-last, as an implicit GEMM
  * on MFMA: out[p, v, co] = ((bias[co] + sum_{tap, ci} in[p, v + tap, ci] * Wk[co, tap*Cin + ci]) + res[p, v, co])
  * * res_scale.  Wk is the 16-bit weight re-laid by the host as [Cout, Kpad] with k = tap*Cin + ci
- * (tap = (dz*3 + dy)*3 + dx), zero-padded to Kpad (a multiple of 64).  res may be NULL.  `zeros` points
- * to >= 16 zero bytes on the device (read for out-of-volume taps).  Cin a power of two >= 8.
+ * (tap = (dz*3 + dy)*3 + dx), zero-padded to Kpad (a multiple of 64).  res may be NULL.
+ * Cin a power of two >= 8.
  * Replaces nn.Conv3d(k=3, p=1) in ResnetBlock incl. the skip `(x + shortcut(res)) * skip_scale`
  * (vae3d_dib.py:110,113,137-143) and, with a flipped/transposed weight, the output
  * ConvTranspose3d(k=3, s=1, p=1) (vae3d_dib.py:367,385). */
 int primx_conv3d_k3(const void* in, const void* Wk, const void* bias, const void* res, float res_scale,
-                    const void* zeros, void* out, int P, int S, int Cin, int Cout, int Kpad, int dtype,
-                    void* stream);
+                    void* out, int P, int S, int Cin, int Cout, int Kpad, int dtype, void* stream);
 
 /* out[M, N] (16-bit) = ((A W^T + bias) + res) * scale with no intermediate rounding; res may be NULL.
  * The 1x1 shortcut conv (vae3d_dib.py:124-125) and VolumeAttention's proj + `(x + res) * skip_scale`

@@ -42,10 +42,13 @@ def timestep_embedding(t: Tensor, dim: int = 256, max_period: float = 10000.0) -
     return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
 
 
+ATTN_DTYPE = torch.float64  # bench.py's cpu_baseline leg sets fp32 (the reference's own CPU precision)
+
+
 def attention_core(q: Tensor, k: Tensor, v: Tensor, scale: float) -> Tensor:
     """xformers.ops.memory_efficient_attention semantics on [B, M, H, K] (attention.py:54,109):
     softmax(q k^T * scale) v, no mask, fp32 softmax.  Evaluated in float64 for a clean reference."""
-    qd, kd, vd = (z.double().permute(0, 2, 1, 3) for z in (q, k, v))
+    qd, kd, vd = (z.to(ATTN_DTYPE).permute(0, 2, 1, 3) for z in (q, k, v))
     logits = qd @ kd.transpose(-1, -2) * scale
     p = torch.softmax(logits, dim=-1)
     return (p @ vd).permute(0, 2, 1, 3).float()

@@ -57,8 +57,8 @@ def test_argument_validation_without_gpu(lib):
     h = lib.load()
     assert h.primx_attention(None, None, None, None, 1, 1, 1, 128, 1, 64, 72, 1.0, 1, None) == -1
     assert b"null" in h.primx_last_error()
-    assert h.primx_layernorm_modulate(1, 1, 1, 0, 1, 1, 4, 4, 100, 1e-6, None) == -1   # D % 128 != 0
-    assert h.primx_linear(1, 1, None, 1, 4, 4, 70, 1, 0, 1.0, None) == -1               # K % 64 != 0
+    assert h.primx_layernorm_modulate(1, 1, 1, 0, 1, 1, 4, 4, 101, 1e-6, None) == -1   # D odd
+    assert h.primx_linear(1, 1, None, 1, 4, 4, 70, 1, 0, 1.0, None) == -1               # K % 8 != 0
     assert h.primx_linear(1, 1, None, 1, 4, 4, 64, 7, 0, 1.0, None) == -1               # bad dtype
     with pytest.raises(lib.PrimxError):
         lib.check(-1, "primx_linear")

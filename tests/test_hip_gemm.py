@@ -1,0 +1,109 @@
+"""GPU parity of the MFMA GEMM and every fused epilogue (through the C ABI) against float64 matmuls
+with the reference's autocast rounding points."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import synth
+from tests.util import max_abs, rel_l2, unpack_rows, unpack_vt
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = {torch.float16: 1.5e-3, torch.bfloat16: 1.2e-2}   # rel-L2: one 16-bit rounding of an fp32-accumulated sum
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import __graft_entry__
+    __graft_entry__.build()
+    from topia_xl_amd import ops
+    return ops
+
+
+def _mk(seed, M, N, K, dtype):
+    A = synth.tensor(seed, "A", (M, K)).to(dtype)
+    W = synth.tensor(seed, "W", (N, K), K ** -0.5).to(dtype)
+    b = synth.tensor(seed, "b", (N,), 0.3).to(dtype)
+    ref = F.linear(A.double(), W.double(), b.double())
+    return A, W, b, ref
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (4096, 1152, 1152), (2, 2304, 384), (300, 136, 1152),
+                                   (1370, 200, 768), (129, 129, 4608)])
+def test_linear_plain(ops, dtype, M, N, K):
+    A, W, b, ref = _mk(11, M, N, K, dtype)
+    got = ops.linear(A.to(DEV), W.to(DEV), b.to(DEV))
+    assert got.shape == (M, N) and rel_l2(got, ref) < TOL[dtype], rel_l2(got, ref)
+    got = ops.linear(A.to(DEV), W.to(DEV), None)
+    assert rel_l2(got, ref - b.double()) < TOL[dtype]
+
+
+def test_linear_detects_transposition(ops):
+    """A = I with an asymmetric W: catches row/col swaps in the MFMA fragment maps."""
+    K = 128
+    A = torch.eye(K, dtype=torch.float16)
+    W = (torch.arange(192 * K, dtype=torch.float32).reshape(192, K) % 251 / 64).to(torch.float16)
+    got = ops.linear(A.to(DEV), W.to(DEV), None).cpu()
+    assert torch.equal(got, W.t().contiguous())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_linear_gelu_and_scale(ops, dtype):
+    A, W, b, ref = _mk(12, 512, 4608, 1152, dtype)
+    r = lambda t: t.to(dtype).double()
+    want = r(F.gelu(r(ref).float(), approximate="tanh"))
+    got = ops.linear(A.to(DEV), W.to(DEV), b.to(DEV), act=1)
+    assert rel_l2(got, want) < 2 * TOL[dtype]
+    got = ops.linear(A.to(DEV), W.to(DEV), b.to(DEV), out_scale=72 ** -0.5)
+    assert rel_l2(got, r(72 ** -0.5 * r(ref))) < 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_linear_gate_residual(ops, dtype):
+    B, Ntok, D, K = 2, 256, 1152, 4608
+    A, W, b, ref = _mk(13, B * Ntok, D, K, dtype)
+    mod = synth.tensor(13, "gate", (B, 3 * D), 0.5).to(dtype)
+    gate = mod[:, D:2 * D]
+    x = synth.tensor(13, "x", (B * Ntok, D))
+    r = lambda t: t.to(dtype).double()
+    want = x.double() + r(gate.double().repeat_interleave(Ntok, 0) * r(ref))
+    xd = x.to(DEV)
+    ops.linear_gate_residual(A.to(DEV), W.to(DEV), b.to(DEV), mod.to(DEV)[:, D:2 * D], xd, Ntok)
+    assert rel_l2(xd - x.to(DEV), want - x.double()) < 2 * TOL[dtype]
+    assert max_abs(xd, want) < 5e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,n,H,dh,K", [(2, 256, 16, 72, 1152), (3, 70, 4, 72, 64), (1, 1370, 16, 72, 768),
+                                       (2, 64, 8, 32, 256), (1, 1, 6, 64, 128)])
+def test_linear_heads_layouts(ops, dtype, B, n, H, dh, K):
+    """qkv projection written straight into the attention layouts == Linear + reshape + unbind."""
+    from topia_xl_amd._lib import HEADS_ROWS, HEADS_VT
+    D = H * dh
+    A, W, b, ref = _mk(14, B * n, 3 * D, K, dtype)
+    scale0 = dh ** -0.5
+    r = lambda t: t.to(dtype)
+    qkv = r(ref).view(B, n, 3, H, dh)
+    Q = ops.alloc_heads(B, H, n, dh, HEADS_ROWS, dtype, DEV, 128)
+    Kb = ops.alloc_heads(B, H, n, dh, HEADS_ROWS, dtype, DEV, 128)
+    Vt = ops.alloc_heads(B, H, n, dh, HEADS_VT, dtype, DEV, 128)
+    ops.linear_heads(A.to(DEV), W.to(DEV), b.to(DEV), n, H, dh, [HEADS_ROWS, HEADS_ROWS, HEADS_VT], [Q, Kb, Vt],
+                     Q.shape[2], scale0=scale0)
+    tol = 2 * TOL[dtype]
+    assert rel_l2(unpack_rows(Q, n, dh), r(scale0 * qkv[:, :, 0].float())) < tol
+    assert rel_l2(unpack_rows(Kb, n, dh), qkv[:, :, 1]) < tol
+    assert rel_l2(unpack_vt(Vt, n, dh), qkv[:, :, 2]) < tol
+    # pads are untouched (zero): total mass equals the mass of the valid region
+    for buf, ref_part in ((Kb, qkv[:, :, 1]), (Vt, qkv[:, :, 2])):
+        assert abs(float(buf.float().abs().sum()) - float(ref_part.float().abs().sum())) < 1e-2 * float(ref_part.float().abs().sum())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_linear_residual(ops, dtype):
+    A, W, b, ref = _mk(15, 700, 32, 256, dtype)
+    res = synth.tensor(15, "res", (700, 32)).to(dtype)
+    got = ops.linear_residual(A.to(DEV), W.to(DEV), b.to(DEV), res.to(DEV), 0.5 ** 0.5)
+    assert rel_l2(got, (ref + res.double()) * 0.5 ** 0.5) < TOL[dtype]
+    got = ops.linear_residual(A.to(DEV), W.to(DEV), b.to(DEV), None, 1.0)
+    assert rel_l2(got, ref) < TOL[dtype]

@@ -1,0 +1,120 @@
+"""GPU parity of the VAE decoder kernels and of VAE.decode against the oracle and the REAL
+reference's output (tests/golden/vae_decode.npz, fp32)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import synth, vae_ref
+from tests.golden.make_golden import SEED, VAE_CFG
+from tests.util import max_abs, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__
+    __graft_entry__.build()
+    import topia_xl_amd
+    return topia_xl_amd
+
+
+def _cl(x):   # [P, C, S, S, S] -> channels-last [P, V, C]
+    P, C = x.shape[:2]
+    return x.reshape(P, C, -1).permute(0, 2, 1).contiguous()
+
+
+def _cf(x, S):  # [P, V, C] -> [P, C, S, S, S]
+    P, V, C = x.shape
+    return x.permute(0, 2, 1).reshape(P, C, S, S, S)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("C,S,groups,silu", [(256, 4, 32, True), (32, 8, 32, True), (256, 8, 32, False)])
+def test_groupnorm_silu(pkg, dtype, C, S, groups, silu):
+    from topia_xl_amd import ops
+    x = synth.tensor(31, "gn.x", (5, C, S, S, S), 1.3, 0.2).to(dtype)
+    g, b = synth.tensor(31, "gn.g", (C,), 0.2, 1.0), synth.tensor(31, "gn.b", (C,), 0.2)
+    ref = F.group_norm(x.float(), groups, g, b, 1e-5)
+    ref = F.silu(ref) if silu else ref
+    got = ops.groupnorm_silu(_cl(x).to(DEV), g.to(DEV), b.to(DEV), groups, 1e-5, silu)
+    assert rel_l2(_cf(got, S), ref) < (1e-3 if dtype == torch.float16 else 6e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Cin,Cout,S,P", [(256, 256, 4, 5), (256, 32, 8, 2), (32, 32, 8, 3), (32, 6, 8, 3)])
+def test_conv3d_k3_and_residual(pkg, dtype, Cin, Cout, S, P):
+    from topia_xl_amd import ops
+    from topia_xl_amd.vae import _conv_weight_as_gemm
+    x = synth.tensor(32, "cv.x", (P, Cin, S, S, S)).to(dtype)
+    w = synth.tensor(32, "cv.w", (Cout, Cin, 3, 3, 3), (27 * Cin) ** -0.5).to(dtype)
+    b = synth.tensor(32, "cv.b", (Cout,), 0.2).to(dtype)
+    res = synth.tensor(32, "cv.r", (P, Cout, S, S, S)).to(dtype)
+    ref = F.conv3d(x.double(), w.double(), b.double(), padding=1)
+    wk = _conv_weight_as_gemm(w, dtype).to(DEV)
+    tol = 1.5e-3 if dtype == torch.float16 else 1.2e-2
+    got = ops.conv3d_k3(_cl(x).to(DEV), wk, b.to(DEV), S)
+    assert rel_l2(_cf(got, S), ref) < tol, rel_l2(_cf(got, S), ref)
+    got = ops.conv3d_k3(_cl(x).to(DEV), wk, b.to(DEV), S, res=_cl(res).to(DEV), res_scale=0.5 ** 0.5)
+    assert rel_l2(_cf(got, S), (ref + res.double()) * 0.5 ** 0.5) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_conv_in_convtranspose_and_output(pkg, dtype):
+    from topia_xl_amd import ops
+    P, S = 4, 4
+    z = synth.tensor(33, "z", (P, 1, S, S, S))
+    w = synth.tensor(33, "w", (256, 1, 3, 3, 3), 0.2)
+    b = synth.tensor(33, "b", (256,), 0.2)
+    a_, b_ = 1.7, -0.3
+    ref = F.conv3d(a_ * z + b_, w, b, padding=1)          # zero padding AFTER the affine (vae3d_dib.py:438,373)
+    got = ops.conv_in(z.reshape(P, -1).to(DEV), a_, b_, w.reshape(256, 27).to(DEV), b.to(DEV), S, dtype)
+    assert rel_l2(_cf(got, S), ref) < (1e-3 if dtype == torch.float16 else 6e-3)
+    # ConvTranspose3d(k2, s2)
+    x = synth.tensor(33, "x", (P, 256, S, S, S)).to(dtype)
+    wt = synth.tensor(33, "wt", (256, 256, 2, 2, 2), 256 ** -0.5).to(dtype)
+    bt = synth.tensor(33, "bt", (256,), 0.2).to(dtype)
+    ref = F.conv_transpose3d(x.double(), wt.double(), bt.double(), stride=2)
+    wg = wt.permute(2, 3, 4, 1, 0).reshape(8 * 256, 256).contiguous()
+    got = ops.convtranspose_k2s2(_cl(x).to(DEV), wg.to(DEV), bt.to(DEV), S)
+    assert rel_l2(_cf(got, 2 * S), ref) < (1.5e-3 if dtype == torch.float16 else 1.2e-2)
+    # output layout change + inverse normalisation (inference.py:345-346)
+    y = synth.tensor(33, "y", (P, 6, 8, 8, 8)).to(dtype)
+    got = ops.vae_output(_cl(y).to(DEV), True).view(P, 6, 8, 8, 8)
+    assert torch.equal(got.cpu(), vae_ref.denormalise_decoded(y.float()))
+    assert torch.equal(ops.vae_output(_cl(y).to(DEV), False).view(P, 6, 8, 8, 8).cpu(), y.float())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_vae_decode_against_reference(pkg, golden, dtype):
+    """Stated tolerance: max-abs <= 2e-2 (fp16) / 1.5e-1 (bf16, 8-bit mantissa through ~20 layers) on outputs of
+    O(1) vs the fp32 reference; fp16 is the decoder's default compute type."""
+    g = golden("vae_decode")
+    vae = pkg.VAE(**VAE_CFG).eval()
+    sd = synth.state_dict_like(SEED, vae.state_dict())
+    vae.load_state_dict(sd, strict=True)
+    vae.to(DEV)
+    vae.compute_dtype = dtype
+    z = synth.tensor(SEED, "vae.z", (3, 1, 4, 4, 4))
+    out = vae.decode(z.to(DEV))
+    assert out.shape == (3, 6, 8, 8, 8) and out.dtype == torch.float32
+    ref = torch.as_tensor(g["decoded"])
+    assert max_abs(out, ref) < (2e-2 if dtype == torch.float16 else 1.5e-1), max_abs(out, ref)
+    assert rel_l2(out, ref) < (5e-3 if dtype == torch.float16 else 3e-2), rel_l2(out, ref)
+    emu = vae_ref.vae_decode(sd, z, VAE_CFG["up_channels"], VAE_CFG["layers_per_block"], emulate=dtype)
+    assert rel_l2(out, emu) < (3e-3 if dtype == torch.float16 else 2e-2)
+    den = vae.decode(z.to(DEV), denormalize=True)
+    assert rel_l2(den, vae_ref.denormalise_decoded(ref)) < (5e-3 if dtype == torch.float16 else 3e-2)
+
+
+def test_vae_decode_many_primitives_are_independent(pkg):
+    """2048-primitive batch (one sample): primitives never interact, so decode(batch)[i] == decode(batch[i:i+1])."""
+    vae = pkg.VAE(**VAE_CFG).eval()
+    vae.load_state_dict(synth.state_dict_like(SEED, vae.state_dict()))
+    vae.to(DEV)
+    z = synth.tensor(9, "z", (2048, 1, 4, 4, 4)).to(DEV)
+    full = vae.decode(z)
+    assert torch.isfinite(full).all()
+    for i in (0, 1, 777, 2047):
+        assert torch.equal(vae.decode(z[i:i + 1].contiguous()), full[i:i + 1])
