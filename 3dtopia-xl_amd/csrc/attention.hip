@@ -15,9 +15,11 @@
 // makes the 8 keys a lane owns in one 16-key MFMA step a contiguous 16-byte LDS read - P never
 // leaves registers and needs no permute.
 //
-// KV tiles of 64 keys are double-buffered in LDS through registers (global loads of tile j+1 in
-// flight during the 22 MFMAs of tile j, one barrier per tile).  LDS rows are padded so that the
-// 16-byte-slot stride is odd (K rows DP+8 halves, V^T rows 72 halves) -> ds_read_b128 conflict-free.
+// KV tiles of 64 keys go global -> registers -> LDS with prefetch distance 2: two register sets, two LDS
+// buffers, a branch-free loop body (tile indices past the end are clamped; only the LDS stores are
+// predicated) so that hipcc keeps counted vmcnt waits - the v1 loop (one set, conditional loads) was
+// compiled to s_waitcnt vmcnt(0) at the loop head.  One barrier per tile.  LDS rows are padded so
+// that the 16-byte-slot stride is odd (K rows DP+8 halves, V^T rows 72 halves): ds_read_b128 conflict-free.
 // Head dim 72 is zero-padded to DP = 80 for QK^T (5 k-steps) and to 96 output rows for PV (3 tiles):
 // 22 MFMAs per 64 keys x 32 queries = 0.72 MFLOP issued for 0.59 MFLOP algorithmic (81.8 %).
 #include "common.h"
@@ -27,6 +29,12 @@ namespace {
 constexpr int BQ = 128;   // query rows per workgroup
 constexpr int BKV = 64;   // keys per tile
 constexpr int VROW = BKV + 8;
+
+template <typename V8>
+__device__ __forceinline__ V8 ldg16(const void* ptr) {
+    typedef __attribute__((address_space(1))) const V8 GV8;
+    return *reinterpret_cast<GV8*>(reinterpret_cast<uintptr_t>(ptr));
+}
 
 template <int DT, int KSTEPS, int DTILES>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S* __restrict__ Qp,
@@ -67,8 +75,47 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
     {
         const S* qrow = Qp + ((int64_t)bh * nq_pad + q0 + wave * 32 + l31) * DP + hi * 8;
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) qf[s] = *reinterpret_cast<const V8*>(qrow + s * 16);
+        for (int s = 0; s < KSTEPS; ++s) qf[s] = ldg16<V8>(qrow + s * 16);
     }
+
+    // ---- loader geometry (chunk ids past the tile are clamped for the load and skipped for the store)
+    int k_goff[KIT], k_loff[KIT], v_loff[VIT];
+    int64_t v_goff[VIT];
+    bool k_on[KIT], v_on[VIT];
+#pragma unroll
+    for (int i = 0; i < KIT; ++i) {
+        const int ch = tid + 256 * i;
+        k_on[i] = ch < KCH;
+        const int cc = k_on[i] ? ch : KCH - 1;
+        k_goff[i] = cc * 8;                                      // the K tile is one contiguous block
+        k_loff[i] = (cc / (DP / 8)) * KROW + (cc % (DP / 8)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < VIT; ++i) {
+        const int ch = tid + 256 * i;
+        v_on[i] = ch < VCH;
+        const int cc = v_on[i] ? ch : VCH - 1;
+        v_goff[i] = (int64_t)(cc >> 3) * nkv_pad + (cc & 7) * 8;
+        v_loff[i] = (cc >> 3) * VROW + (cc & 7) * 8;
+    }
+    auto load_tile = [&](int j, V8 (&kr)[KIT], V8 (&vr)[VIT]) {
+        const S* kt = Kbase + (int64_t)j * BKV * DP;
+        const S* vt = Vbase + j * BKV;
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) kr[i] = ldg16<V8>(kt + k_goff[i]);
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) vr[i] = ldg16<V8>(vt + v_goff[i]);
+    };
+    auto store_tile = [&](int buf, V8 (&kr)[KIT], V8 (&vr)[VIT]) {
+        S* kb = smem + buf * BUF;
+        S* vb = kb + KT;
+#pragma unroll
+        for (int i = 0; i < KIT; ++i)
+            if (k_on[i]) *reinterpret_cast<V8*>(kb + k_loff[i]) = kr[i];
+#pragma unroll
+        for (int i = 0; i < VIT; ++i)
+            if (v_on[i]) *reinterpret_cast<V8*>(vb + v_loff[i]) = vr[i];
+    };
 
     f32x16 o[DTILES];
 #pragma unroll
@@ -77,57 +124,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
 
-    const int ntiles = (nkv + BKV - 1) / BKV;
-
-    V8 kreg[KIT], vreg[VIT];
-    auto load_tile = [&](int j) {
-        const int key0 = j * BKV;
-#pragma unroll
-        for (int i = 0; i < KIT; ++i) {
-            const int ch = tid + 256 * i;
-            if (ch < KCH) kreg[i] = *reinterpret_cast<const V8*>(Kbase + (int64_t)key0 * DP + ch * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < VIT; ++i) {
-            const int ch = tid + 256 * i;
-            if (ch < VCH) {
-                const int d = ch >> 3, col = (ch & 7) * 8;
-                vreg[i] = *reinterpret_cast<const V8*>(Vbase + (int64_t)d * nkv_pad + key0 + col);
-            }
-        }
-    };
-    auto store_tile = [&](int buf) {
-        S* kb = smem + buf * BUF;
-        S* vb = kb + KT;
-#pragma unroll
-        for (int i = 0; i < KIT; ++i) {
-            const int ch = tid + 256 * i;
-            if (ch < KCH) {
-                const int row = ch / (DP / 8), col = (ch % (DP / 8)) * 8;
-                *reinterpret_cast<V8*>(kb + row * KROW + col) = kreg[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < VIT; ++i) {
-            const int ch = tid + 256 * i;
-            if (ch < VCH) {
-                const int d = ch >> 3, col = (ch & 7) * 8;
-                *reinterpret_cast<V8*>(vb + d * VROW + col) = vreg[i];
-            }
-        }
-    };
-
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
-    for (int j = 0; j < ntiles; ++j) {
-        const bool more = j + 1 < ntiles;
-        if (more) load_tile(j + 1);
-        const S* kb = smem + (j & 1) * BUF;
+    // ---- one KV tile: S^T = K Q^T, online softmax, O^T += V^T P^T
+    auto process = [&](int buf, int j) {
+        const S* kb = smem + buf * BUF;
         const S* vb = kb + KT;
-
-        // ---- S^T = K Q^T  (two 32-key sub-tiles)
         f32x16 sc[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -140,9 +140,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
                 sc[kt] = T16<DT>::mfma32(a, qf[s], sc[kt]);
             }
         }
-
-        // ---- mask the tail keys of the last tile
-        if ((j + 1) * BKV > nkv) {
+        if ((j + 1) * BKV > nkv) {  // mask the tail keys of the last tile
             const int kbase = j * BKV + 4 * hi;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -152,18 +150,24 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
                     if (key >= nkv) sc[kt][r] = -1e30f;
                 }
         }
-
-        // ---- online softmax (per-lane scalars; one cross-half exchange of the max)
+        // online softmax: per-lane scalars; one cross-half exchange of the max
         float mx = sc[0][0];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        const float mc = m_new * c;
-        m_run = m_new;
+        if (!__all(mx <= m_run)) {  // exact: when no row's max moves, alpha == 1 and the rescale is the identity
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int t = 0; t < DTILES; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
+        const float mc = m_run * c;
         float psum = 0.f;
         V8 pb[4];
 #pragma unroll
@@ -175,13 +179,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
                 pb[ks][e] = (S)pv;
             }
         }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int t = 0; t < DTILES; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-
-        // ---- O^T += V^T P^T
+        l_run += psum;
 #pragma unroll
         for (int t = 0; t < DTILES; ++t) {
             const S* vrow = vb + (t * 32 + l31) * VROW + hi * 8;
@@ -191,10 +189,27 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
                 o[t] = T16<DT>::mfma32(a, pb[ks], o[t]);
             }
         }
+    };
 
-        if (more) store_tile((j + 1) & 1);
+    // ---- main loop: prefetch distance 2 (set A / set B), branch-free body
+    const int ntiles = (nkv + BKV - 1) / BKV;
+    V8 kA[KIT], vA[VIT], kB[KIT], vB[VIT];
+    load_tile(0, kA, vA);
+    load_tile(min(1, ntiles - 1), kB, vB);
+    store_tile(0, kA, vA);
+    __syncthreads();
+    int j = 0;
+    for (; j + 1 < ntiles; j += 2) {
+        load_tile(min(j + 2, ntiles - 1), kA, vA);
+        process(0, j);
+        store_tile(1, kB, vB);
+        __syncthreads();
+        load_tile(min(j + 3, ntiles - 1), kB, vB);
+        process(1, j + 1);
+        store_tile(0, kA, vA);
         __syncthreads();
     }
+    if (j < ntiles) process(0, j);
 
     // ---- epilogue: normalise and store out[b, q, h*dh + d]
     const float l_tot = l_run + __shfl_xor(l_run, 32);

@@ -1,29 +1,50 @@
 // 16-bit MFMA GEMM  C[M,N] = A[M,K] * W[N,K]^T  (both operands K-contiguous: activations row-major,
 // weights in nn.Linear (out,in) layout) with the DiT block's and the VAE decoder's epilogues fused.
 //
-// 256 threads = 4 waves of v_mfma_f32_32x32x16_{f16,bf16}; two tile shapes:
-//   Wide  : 128 x 128 x 64, waves 2x2, each wave 64x64 (2x2 MFMA tiles)   - every DiT Linear, 256-ch convs
-//   Narrow: 128 x  32 x 64, waves 4x1, each wave 32x32 (1 MFMA tile)      - Cout <= 32 convs of the VAE
+// 256 threads = 4 waves; BK = 64; three tile shapes:
+//   T144  : 128 x 144, waves 4x1, each wave 32 x 144 = 2 x 9 tiles of v_mfma_f32_16x16x32   (N % 144 == 0)
+//           1152 = 8*144, 3456 = 24*144, 4608 = 32*144: with M = 4096 tokens (N_prim 2048 x CFG pair) the
+//           DiT's GEMMs become exactly 256 / 768 / 1024 workgroups = 1 / 3 / 4 full waves of the 256 CUs.
+//   Wide  : 128 x 128, waves 2x2, each wave 64 x 64 = 2 x 2 tiles of v_mfma_f32_32x32x16   (any N)
+//   Narrow: 128 x  32, waves 4x1, each wave 32 x 32 = one 32x32x16 tile                   (N <= 32: VAE convs)
 // Operand orientation: MFMA-A = activation rows (m), MFMA-B = weight rows (n), so the accumulator's
-// lane index (lane & 31) runs along n - the contiguous dimension of every destination - and its
-// registers run along m.  LDS rows are padded 64 -> 72 halves (144 B): 144/16 = 9 is odd, so the 16
-// lanes of a ds_read_b128 group (distinct rows mod 16) hit 16 distinct 16-byte slots - conflict-free
-// (MI355X_MICROARCH.md, LDS).  Register-staged double buffering: the global loads of k-tile t+1 are in
-// flight while the MFMAs of k-tile t run; one barrier per k-tile.  Workgroup ids are remapped so that
-// each XCD (private 4 MiB L2) owns a contiguous run of tiles that share A row-panels.
+// lane index runs along n - the contiguous dimension of every destination - and each lane holds quads
+// of 4 consecutive rows m.
 //
-// GATHER = 1 turns the A loader into the implicit-GEMM gather of a 3x3x3 / stride 1 / pad 1
-// convolution over channels-last [P, S^3, Cin] activations: k = tap * Cin + ci, row m = (p, voxel);
-// out-of-volume taps (and the zero-padded tail of K) read a 16-byte zero block instead of branching.
+// LDS: unpadded 128-byte rows (64 halves) with the 16-byte chunk index XOR-swizzled by ((row >> 1) & 7):
+// conflict-free for the ds_read_b128 lane groups of BOTH MFMA shapes (checked exhaustively against the
+// lane-group table of MI355X_MICROARCH.md) and for the 8-lane ds_write_b128 groups of the loader.
+//
+// Pipeline: register-staged, prefetch distance 2 - while k-tile t is multiplied out of LDS buffer t&1,
+// the global loads of tiles t+1 AND t+2 are in flight in two register sets; tile t+1 is written to the
+// other LDS buffer after the MFMAs (the compiler's counted vmcnt leaves tile t+2 in flight), one
+// barrier per k-tile.  (v1 issued loads one tile ahead and measured ~1 us per k-tile - HBM/L2 latency
+// bound at 300-450 TFLOP/s; see profiles/r1_kernel_trace_summary.txt.)
+// Workgroup ids are remapped so each XCD (private 4 MiB L2) owns a contiguous run of tiles sharing A panels.
+//
+// GATHER = 1 turns the A loader into the implicit-GEMM gather of a 3x3x3 / stride 1 / pad 1 convolution
+// over channels-last [P, S^3, Cin] activations: k = tap * Cin + ci, row m = (p, voxel); out-of-volume taps
+// and any K tail read a 16-byte zero block instead of branching.
 #include "common.h"
 
 namespace {
 
-// 16 zero bytes: the source of every out-of-range operand chunk (K tail, conv padding taps)
-__device__ const u32x4 g_zero16 = {0u, 0u, 0u, 0u};
+// Global-address-space load of one 16-byte operand chunk.  Out-of-range chunks (K tail, conv padding
+// taps) are handled by loading a VALID address and zeroing the VALUE: selecting between pointers of
+// different provenance made hipcc emit flat_load (counted on vmcnt AND lgkmcnt, not partially waitable),
+// which serialised every LDS wait behind the global prefetches (profiles/r1_gemm_pmc.txt).
+template <typename V8, typename S>
+__device__ __forceinline__ V8 ldg16(const S* ptr, bool keep) {
+    typedef __attribute__((address_space(1))) const V8 GV8;
+    V8 v = *reinterpret_cast<GV8*>(reinterpret_cast<uintptr_t>(ptr));
+    if (!keep) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (S)0.f;
+    }
+    return v;
+}
 
 constexpr int BK = 64;
-constexpr int LROW = BK + 8;  // padded LDS row (halves)
 
 enum { EPI_LINEAR = 0, EPI_GATE_RESIDUAL = 1, EPI_HEADS = 2, EPI_RES = 3, EPI_CONVT = 4 };
 
@@ -51,9 +72,9 @@ struct GemmArgs {
     // EPI_RES: out = cast16((acc + bias + res) * out_scale); res may be null
     const S* res;
     // conv gather (GATHER) and EPI_CONVT geometry
-    int S3;               // grid edge S (volume S^3)
-    int cin_log2;         // log2(Cin)
-    int cout;             // EPI_CONVT: N = 8 * cout
+    int S3;        // grid edge S (volume S^3)
+    int cin_log2;  // log2(Cin)
+    int cout;      // EPI_CONVT: N = 8 * cout
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -64,21 +85,151 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + local;
 }
 
-// WM x WN waves, each MI x NI tiles of 32x32
-template <int DT, int EPI, int WM, int WN, int MI, int NI, int GATHER>
+// byte-free LDS addressing in halves: row-major 64-half rows, 16-byte chunks XOR-swizzled
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+
+template <int MF>
+struct AccT;
+template <>
+struct AccT<32> {
+    using T = f32x16;
+};
+template <>
+struct AccT<16> {
+    using T = f32x4;
+};
+
+// Per-column constants of the epilogue (computed once per lane per n-tile).
+struct ColInfo {
+    int n;
+    bool ok;
+    float bias;
+    int seg, hh, dd;
+};
+
+template <int DT, int EPI>
+__device__ __forceinline__ ColInfo make_col(const GemmArgs<DT>& p, int n) {
+    ColInfo c;
+    c.n = n;
+    c.ok = n < p.N;
+    c.seg = c.hh = c.dd = 0;
+    if (EPI == EPI_HEADS && c.ok) {
+        const int per = p.heads * p.dh;
+        c.seg = n / per;
+        const int w = n - c.seg * per;
+        c.hh = w / p.dh;
+        c.dd = w - c.hh * p.dh;
+    }
+    if (EPI == EPI_CONVT && c.ok) {
+        c.seg = n / p.cout;
+        c.dd = n - c.seg * p.cout;
+    }
+    c.bias = (p.bias && c.ok) ? (float)p.bias[EPI == EPI_CONVT ? c.dd : n] : 0.f;
+    return c;
+}
+
+// One accumulator quad: rows mq .. mq+3 (consecutive m), column c.n.
+template <int DT, int EPI>
+__device__ __forceinline__ void epilogue_quad(const GemmArgs<DT>& p, const ColInfo& c, int mq, const float (&a)[4]) {
+    using S = typename T16<DT>::S;
+    using V4 = typename T16<DT>::V4;
+    if (!c.ok) return;
+    const int n = c.n;
+    if (EPI == EPI_LINEAR) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mq + j;
+            if (m >= p.M) continue;
+            float y = rnd16<DT>(a[j] + c.bias);
+            if (p.act == PRIMX_ACT_GELU_TANH) y = rnd16<DT>(gelu_tanh_f(y));
+            if (p.out_scale != 1.0f) y = rnd16<DT>(p.out_scale * y);
+            p.out[(int64_t)m * p.N + n] = (S)y;
+        }
+    } else if (EPI == EPI_RES) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mq + j;
+            if (m >= p.M) continue;
+            float y = a[j] + c.bias;
+            if (p.res) y += (float)p.res[(int64_t)m * p.N + n];
+            p.out[(int64_t)m * p.N + n] = (S)(y * p.out_scale);
+        }
+    } else if (EPI == EPI_CONVT) {
+        // row m = (prim, z, y, x) on the S^3 grid; column = (tap dz,dy,dx ; co) -> voxel (2z+dz, ..)
+        const int Sg = p.S3, V = Sg * Sg * Sg, S2 = 2 * Sg;
+        const int dz = c.seg >> 2, dy = (c.seg >> 1) & 1, dx = c.seg & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mq + j;
+            if (m >= p.M) continue;
+            const int pp = m / V, v = m - pp * V;
+            const int z = v / (Sg * Sg), y = (v / Sg) % Sg, x = v % Sg;
+            const int64_t ov = ((int64_t)(2 * z + dz) * S2 + (2 * y + dy)) * S2 + (2 * x + dx);
+            p.out[((int64_t)pp * 8 * V + ov) * p.cout + c.dd] = (S)(a[j] + c.bias);
+        }
+    } else if (EPI == EPI_GATE_RESIDUAL) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mq + j;
+            if (m >= p.M) continue;
+            const int b = m / p.rows_per_batch;
+            const float gt = (float)p.gate[(int64_t)b * p.gate_stride + n];
+            const float v = rnd16<DT>(a[j] + c.bias);
+            float* xp = p.x + (int64_t)m * p.N + n;
+            *xp = *xp + rnd16<DT>(gt * v);
+        }
+    } else {  // EPI_HEADS
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = rnd16<DT>(a[j] + c.bias);
+        S* dst = p.dst[0];
+        int kind = p.kind[0];
+        if (c.seg == 1) { dst = p.dst[1]; kind = p.kind[1]; }
+        if (c.seg == 2) { dst = p.dst[2]; kind = p.kind[2]; }
+        if (c.seg == 0 && p.scale0 != 1.0f) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = rnd16<DT>(p.scale0 * v[j]);
+        }
+        const bool quad_ok = (p.rows_per_batch % 4 == 0) && (mq + 3 < p.M);
+        if (kind == PRIMX_HEADS_VT && quad_ok) {
+            // 4 consecutive tokens of one batch entry = one contiguous quad of the VT layout
+            const int b = mq / p.rows_per_batch, tok = mq - b * p.rows_per_batch;
+            const int64_t head = (int64_t)b * p.heads + c.hh;
+            V4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (S)v[j];
+            *reinterpret_cast<V4*>(dst + (head * p.DP + c.dd) * p.n_pad + vt_key_pos(tok)) = o;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = mq + j;
+                if (m >= p.M) continue;
+                const int b = m / p.rows_per_batch, tok = m - b * p.rows_per_batch;
+                const int64_t head = (int64_t)b * p.heads + c.hh;
+                if (kind == PRIMX_HEADS_ROWS) dst[(head * p.n_pad + tok) * p.DP + c.dd] = (S)v[j];
+                else dst[(head * p.DP + c.dd) * p.n_pad + vt_key_pos(tok)] = (S)v[j];
+            }
+        }
+    }
+}
+
+// MF: MFMA edge (32 -> 32x32x16, 16 -> 16x16x32); WM x WN waves, each MI x NI MFMA tiles
+template <int DT, int EPI, int MF, int WM, int WN, int MI, int NI, int GATHER, int KTAIL>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs<DT> p) {
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
-    using V4 = typename T16<DT>::V4;
+    using Acc = typename AccT<MF>::T;
     static_assert(WM * WN == 4, "4 waves");
-    constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
-    constexpr int TA = BM * LROW, TW = BN * LROW;   // halves per operand tile
-    constexpr int NA = BM * 8 / 256, NW = (BN * 8 + 255) / 256;  // 16-byte chunks per thread
+    constexpr int BM = WM * MI * MF, BN = WN * NI * MF;
+    constexpr int TA = BM * 64, TW = BN * 64;                   // halves per operand tile
+    constexpr int NA = (BM * 8 + 255) / 256, NW = (BN * 8 + 255) / 256;  // 16-byte chunks per thread
+    constexpr int KS = (MF == 32) ? 4 : 2;                      // MFMA k-steps per BK
+    constexpr int CPS = 8 / KS;                                 // 16-byte chunks per k-step
     __shared__ __attribute__((aligned(16))) S smem[2 * (TA + TW)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, hi = lane >> 5;
+    const int lr = lane & (MF - 1), lg = lane / MF;             // fragment row / k-group of this lane
 
     const int nt = (p.N + BN - 1) / BN, mt = (p.M + BM - 1) / BM;
     const int id = xcd_remap(blockIdx.x, nt * mt);
@@ -89,13 +240,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs<DT> p) {
     const S* ga[NA];
     const S* gw[NW];
     int offa[NA], offw[NW];
-    int gz[NA], gy[NA], gx[NA];       // GATHER: voxel coordinates of the row
-    const S* gbase[NA];               // GATHER: &in[p, 0, 0]
+    int gz[NA], gy[NA], gx[NA];  // GATHER: voxel coordinates of the row
+    const S* gbase[NA];          // GATHER: &in[p, 0, 0]
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int row = (tid + 256 * i) >> 3;
         const int ra = min(m0 + row, p.M - 1);  // clamp: rows >= M are computed but never stored
-        offa[i] = row * LROW + kc;
+        offa[i] = lds_off(row, tid & 7);
         if (GATHER) {
             const int V = p.S3 * p.S3 * p.S3;
             const int pp = ra / V, v = ra - pp * V;
@@ -110,15 +261,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs<DT> p) {
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-        const int row = (tid + 256 * i) >> 3;
+        const int row = min((tid + 256 * i) >> 3, BN - 1);
         const int rw = min(n0 + row, p.N - 1);
         gw[i] = p.W + (int64_t)rw * p.K + kc;
-        offw[i] = row * LROW + kc;
+        offw[i] = lds_off(row, tid & 7);
     }
-    const bool w_active = (NW * 256 <= BN * 8) || (tid < BN * 8);  // Narrow: one chunk per thread, all active
+    // the last loader iteration may be partial (T144: 1152 W chunks = 4.5 per thread; wave-uniform predicate)
+    constexpr bool A_FULL = (BM * 8) % 256 == 0, W_FULL = (BN * 8) % 256 == 0;
+    const bool a_last = A_FULL || (tid + 256 * (NA - 1) < BM * 8);
+    const bool w_last = W_FULL || (tid + 256 * (NW - 1) < BN * 8);
 
-    const S* zeros = reinterpret_cast<const S*>(&g_zero16);
-    auto load_a = [&](int kt, V8 (&r)[NA]) {
+    auto load_tile = [&](int kt, V8 (&ra)[NA], V8 (&rw)[NW]) {
         if (GATHER) {
             const int kk = kt * BK + kc;
             const int tap = kk >> p.cin_log2, ci = kk & ((1 << p.cin_log2) - 1);
@@ -128,174 +281,231 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs<DT> p) {
                 const int z = gz[i] + dz, y = gy[i] + dy, x = gx[i] + dx;
                 const bool ok = tap < 27 && (unsigned)z < (unsigned)p.S3 && (unsigned)y < (unsigned)p.S3 &&
                                 (unsigned)x < (unsigned)p.S3;
-                const S* src = gbase[i] + ((int64_t)((z * p.S3 + y) * p.S3 + x) << p.cin_log2) + ci;
-                r[i] = *reinterpret_cast<const V8*>(ok ? src : zeros);
+                const int64_t off = ok ? (((int64_t)((z * p.S3 + y) * p.S3 + x) << p.cin_log2) + ci) : 0;
+                ra[i] = ldg16<V8, S>(gbase[i] + off, ok);
             }
         } else {
-            const bool k_ok = kt * BK + kc < p.K;  // K tail (K % 64 != 0): zero chunk
+            const bool k_ok = !KTAIL || kt * BK + kc < p.K;  // K tail (K % 64 != 0): zero chunk
 #pragma unroll
-            for (int i = 0; i < NA; ++i) r[i] = *reinterpret_cast<const V8*>(k_ok ? ga[i] + kt * BK : zeros);
+            for (int i = 0; i < NA; ++i) ra[i] = ldg16<V8, S>(ga[i] + (k_ok ? kt * BK : 0), k_ok);
         }
-    };
-    auto load_w = [&](int kt, V8 (&r)[NW]) {
-        const bool k_ok = kt * BK + kc < p.K;
+        const bool k_ok = !KTAIL || kt * BK + kc < p.K;
 #pragma unroll
-        for (int i = 0; i < NW; ++i)
-            if (w_active) r[i] = *reinterpret_cast<const V8*>(k_ok ? gw[i] + kt * BK : zeros);
+        for (int i = 0; i < NW; ++i) rw[i] = ldg16<V8, S>(gw[i] + (k_ok ? kt * BK : 0), k_ok);
     };
-    auto store_tiles = [&](int buf, V8 (&ra)[NA], V8 (&rw)[NW]) {
+    auto store_tile = [&](int buf, V8 (&ra)[NA], V8 (&rw)[NW]) {
         S* base = smem + buf * (TA + TW);
 #pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<V8*>(base + offa[i]) = ra[i];
+        for (int i = 0; i < NA; ++i)
+            if (i < NA - 1 || a_last) *reinterpret_cast<V8*>(base + offa[i]) = ra[i];
 #pragma unroll
         for (int i = 0; i < NW; ++i)
-            if (w_active) *reinterpret_cast<V8*>(base + TA + offw[i]) = rw[i];
+            if (i < NW - 1 || w_last) *reinterpret_cast<V8*>(base + TA + offw[i]) = rw[i];
     };
 
-    f32x16 acc[MI][NI];
+    Acc acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < (MF == 32 ? 16 : 4); ++r) acc[i][j][r] = 0.f;
 
-    V8 ra_[NA], rw_[NW];
-    load_a(0, ra_);
-    load_w(0, rw_);
-    store_tiles(0, ra_, rw_);
-    __syncthreads();
-
-    const int nk = (p.K + BK - 1) / BK;
-    const int a_rd = (wm * MI * 32 + l31) * LROW + hi * 8;
-    const int w_rd = (wn * NI * 32 + l31) * LROW + hi * 8;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) {
-            load_a(kt + 1, ra_);
-            load_w(kt + 1, rw_);
-        }
-        const S* As = smem + (kt & 1) * (TA + TW);
+    const int a_row = wm * MI * MF + lr, w_row = wn * NI * MF + lr;
+    auto compute = [&](int buf) {
+        const S* As = smem + buf * (TA + TW);
         const S* Ws = As + TA;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < KS; ++s) {
+            const int chunk = s * CPS + lg;
             V8 a[MI], b[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const V8*>(As + a_rd + i * 32 * LROW + s * 16);
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const V8*>(As + lds_off(a_row + i * MF, chunk));
 #pragma unroll
-            for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(Ws + w_rd + j * 32 * LROW + s * 16);
+            for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(Ws + lds_off(w_row + j * MF, chunk));
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma32(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < NI; ++j) {
+                    if constexpr (MF == 32) acc[i][j] = T16<DT>::mfma32(a[i], b[j], acc[i][j]);
+                    else acc[i][j] = T16<DT>::mfma16(a[i], b[j], acc[i][j]);
+                }
         }
-        if (more) store_tiles((kt + 1) & 1, ra_, rw_);
+    };
+
+    // ---- main loop: prefetch distance 2, two register sets, two LDS buffers.  The body is BRANCH-FREE
+    // (tile indices past the end are clamped and re-load the last tile): with conditional loads hipcc's
+    // wait-count pass falls back to s_waitcnt vmcnt(0) and the prefetch distance collapses to zero.
+    const int nk = (p.K + BK - 1) / BK;
+    V8 ra0[NA], rw0[NW], ra1[NA], rw1[NW];
+    load_tile(0, ra0, rw0);
+    load_tile(min(1, nk - 1), ra1, rw1);
+    store_tile(0, ra0, rw0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        load_tile(min(kt + 2, nk - 1), ra0, rw0);  // set 0 is free; set 1 carries tile kt+1 in flight
+        compute(0);                                // tile kt
+        store_tile(1, ra1, rw1);
+        __syncthreads();
+        load_tile(min(kt + 3, nk - 1), ra1, rw1);  // set 1 is free; set 0 carries tile kt+2
+        compute(1);                                // tile kt+1
+        store_tile(0, ra0, rw0);
         __syncthreads();
     }
+    if (kt < nk) compute(0);                       // odd tile count: the last tile sits in buffer 0
 
-    // ------------------------------------------------------------------ epilogue
-    // acc[mi][ni][r] = C[m0 + (wm*MI + mi)*32 + (r&3) + 8*(r>>2) + 4*hi][n0 + (wn*NI + ni)*32 + l31]
+    // ---- epilogue
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-        const int n = n0 + (wn * NI + ni) * 32 + l31;
-        const bool n_ok = n < p.N;
-        int seg = 0, hh = 0, dd = 0;  // EPI_HEADS: column -> (segment, head, d);  EPI_CONVT: seg = tap, dd = co
-        if (EPI == EPI_HEADS && n_ok) {
-            const int per = p.heads * p.dh;
-            seg = n / per;
-            const int w = n - seg * per;
-            hh = w / p.dh;
-            dd = w - hh * p.dh;
-        }
-        if (EPI == EPI_CONVT && n_ok) {
-            seg = n / p.cout;
-            dd = n - seg * p.cout;
-        }
-        const float bv = (p.bias && n_ok) ? (float)p.bias[EPI == EPI_CONVT ? dd : n] : 0.f;
+        const ColInfo c = make_col<DT, EPI>(p, n0 + (wn * NI + ni) * MF + lr);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const int mbase = m0 + (wm * MI + mi) * 32 + 4 * hi;
+            if constexpr (MF == 32) {
+                // acc[r] = C[tile_m + (r&3) + 8*(r>>2) + 4*lg][tile_n + lr]
+                const int mbase = m0 + (wm * MI + mi) * 32 + 4 * lg;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {  // register quad g: rows mbase + 8g + {0,1,2,3}
-                const int mq = mbase + 8 * g;
-                if (!n_ok) continue;
-                if (EPI == EPI_LINEAR) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int m = mq + j;
-                        if (m >= p.M) continue;
-                        float y = rnd16<DT>(acc[mi][ni][4 * g + j] + bv);
-                        if (p.act == PRIMX_ACT_GELU_TANH) y = rnd16<DT>(gelu_tanh_f(y));
-                        if (p.out_scale != 1.0f) y = rnd16<DT>(p.out_scale * y);
-                        p.out[(int64_t)m * p.N + n] = (S)y;
-                    }
-                } else if (EPI == EPI_RES) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int m = mq + j;
-                        if (m >= p.M) continue;
-                        float y = acc[mi][ni][4 * g + j] + bv;
-                        if (p.res) y += (float)p.res[(int64_t)m * p.N + n];
-                        p.out[(int64_t)m * p.N + n] = (S)(y * p.out_scale);
-                    }
-                } else if (EPI == EPI_CONVT) {
-                    // row m = (prim, z, y, x) on the S^3 grid; column = (tap dz,dy,dx ; co) -> voxel (2z+dz, ..)
-                    const int Sg = p.S3, V = Sg * Sg * Sg, S2 = 2 * Sg;
-                    const int dz = seg >> 2, dy = (seg >> 1) & 1, dx = seg & 1;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int m = mq + j;
-                        if (m >= p.M) continue;
-                        const int pp = m / V, v = m - pp * V;
-                        const int z = v / (Sg * Sg), y = (v / Sg) % Sg, x = v % Sg;
-                        const int64_t ov = ((int64_t)(2 * z + dz) * S2 + (2 * y + dy)) * S2 + (2 * x + dx);
-                        p.out[((int64_t)pp * 8 * V + ov) * p.cout + dd] = (S)(acc[mi][ni][4 * g + j] + bv);
-                    }
-                } else if (EPI == EPI_GATE_RESIDUAL) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int m = mq + j;
-                        if (m >= p.M) continue;
-                        const int b = m / p.rows_per_batch;
-                        const float gt = (float)p.gate[(int64_t)b * p.gate_stride + n];
-                        const float v = rnd16<DT>(acc[mi][ni][4 * g + j] + bv);
-                        float* xp = p.x + (int64_t)m * p.N + n;
-                        *xp = *xp + rnd16<DT>(gt * v);
-                    }
-                } else {  // EPI_HEADS
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = rnd16<DT>(acc[mi][ni][4 * g + j] + bv);
-                    S* dst = p.dst[0];
-                    int kind = p.kind[0];
-                    if (seg == 1) { dst = p.dst[1]; kind = p.kind[1]; }
-                    if (seg == 2) { dst = p.dst[2]; kind = p.kind[2]; }
-                    if (seg == 0 && p.scale0 != 1.0f) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = rnd16<DT>(p.scale0 * v[j]);
-                    }
-                    const bool quad_ok = (p.rows_per_batch % 4 == 0) && (mq + 3 < p.M);
-                    if (kind == PRIMX_HEADS_VT && quad_ok) {
-                        // 4 consecutive tokens of one batch entry = one contiguous quad of the VT layout
-                        const int b = mq / p.rows_per_batch, tok = mq - b * p.rows_per_batch;
-                        const int64_t head = (int64_t)b * p.heads + hh;
-                        V4 o;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = (S)v[j];
-                        *reinterpret_cast<V4*>(dst + (head * p.DP + dd) * p.n_pad + vt_key_pos(tok)) = o;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int m = mq + j;
-                            if (m >= p.M) continue;
-                            const int b = m / p.rows_per_batch, tok = m - b * p.rows_per_batch;
-                            const int64_t head = (int64_t)b * p.heads + hh;
-                            if (kind == PRIMX_HEADS_ROWS) dst[(head * p.n_pad + tok) * p.DP + dd] = (S)v[j];
-                            else dst[(head * p.DP + dd) * p.n_pad + vt_key_pos(tok)] = (S)v[j];
-                        }
-                    }
+                for (int g = 0; g < 4; ++g) {
+                    const float q[4] = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2],
+                                        acc[mi][ni][4 * g + 3]};
+                    epilogue_quad<DT, EPI>(p, c, mbase + 8 * g, q);
                 }
+            } else {
+                // acc[r] = C[tile_m + 4*lg + r][tile_n + lr]
+                const float q[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+                epilogue_quad<DT, EPI>(p, c, m0 + (wm * MI + mi) * 16 + 4 * lg, q);
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// T144: 128 x 144 tile, 8 waves = 4 (M) x 2 (K halves).  Wave (kg, wm) multiplies rows wm*32..+31 by all
+// 144 columns over k-half kg (32 of the 64 k's of every k-tile) with 2 x 9 tiles of 16x16x32 - two waves
+// per SIMD hide each other's LDS/barrier latency at ~190 VGPRs, and each wave stages only 1/8 of a tile.
+// The two K halves are summed through LDS at the end; ownership of the 9 column tiles is split 5 / 4
+// between the halves so both run the epilogue.
+template <int DT, int EPI, int KTAIL>
+__global__ __launch_bounds__(512, 2) void gemm144_kernel(const GemmArgs<DT> p) {
+    using S = typename T16<DT>::S;
+    using V8 = typename T16<DT>::V8;
+    constexpr int BM = 128, BN = 144, MI = 2, NI = 9;
+    constexpr int TA = BM * 64, TW = BN * 64;
+    constexpr int NA = 2, NW = 3;                       // 16-byte chunks per thread (512 threads)
+    constexpr int RED_HALVES = BM * BN * 2;             // fp32 reduction scratch, in halves (73,728 B)
+    constexpr int LDS_HALVES = (2 * (TA + TW) > RED_HALVES) ? 2 * (TA + TW) : RED_HALVES;
+    __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kg = wave >> 2, wm = wave & 3;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    const int nt = p.N / BN, mt = (p.M + BM - 1) / BM;
+    const int id = xcd_remap(blockIdx.x, nt * mt);
+    const int m0 = (id / nt) * BM, n0 = (id % nt) * BN;
+
+    const int kc = (tid & 7) * 8;
+    const S* ga[NA];
+    const S* gw[NW];
+    int offa[NA], offw[NW];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = (tid + 512 * i) >> 3;
+        ga[i] = p.A + (int64_t)min(m0 + row, p.M - 1) * p.K + kc;
+        offa[i] = lds_off(row, tid & 7);
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int row = min((tid + 512 * i) >> 3, BN - 1);
+        gw[i] = p.W + (int64_t)(n0 + row) * p.K + kc;
+        offw[i] = lds_off(row, tid & 7);
+    }
+    const bool w_last = tid + 512 * (NW - 1) < BN * 8;  // 1152 W chunks = 2.25 per thread (waves 0,1 take the rest)
+
+    auto load_tile = [&](int kt, V8 (&ra)[NA], V8 (&rw)[NW]) {
+        const bool k_ok = !KTAIL || kt * BK + kc < p.K;
+        const int koff = k_ok ? kt * BK : 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = ldg16<V8, S>(ga[i] + koff, k_ok);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) rw[i] = ldg16<V8, S>(gw[i] + koff, k_ok);
+    };
+    auto store_tile = [&](int buf, V8 (&ra)[NA], V8 (&rw)[NW]) {
+        S* base = smem + buf * (TA + TW);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<V8*>(base + offa[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+            if (i < NW - 1 || w_last) *reinterpret_cast<V8*>(base + TA + offw[i]) = rw[i];
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int a_row = wm * 32 + lr;
+    const int chunk = kg * 4 + lg;  // this wave's k-half: k = kg*32 + lg*8 .. +7
+    auto compute = [&](int buf) {
+        const S* As = smem + buf * (TA + TW);
+        const S* Ws = As + TA;
+        V8 a[MI], b[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const V8*>(As + lds_off(a_row + i * 16, chunk));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(Ws + lds_off(lr + j * 16, chunk));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(a[i], b[j], acc[i][j]);
+    };
+
+    const int nk = (p.K + BK - 1) / BK;
+    V8 ra0[NA], rw0[NW], ra1[NA], rw1[NW];
+    load_tile(0, ra0, rw0);
+    load_tile(min(1, nk - 1), ra1, rw1);
+    store_tile(0, ra0, rw0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {  // branch-free body (see gemm_kernel): keeps the counted vmcnt waits
+        load_tile(min(kt + 2, nk - 1), ra0, rw0);
+        compute(0);
+        store_tile(1, ra1, rw1);
+        __syncthreads();
+        load_tile(min(kt + 3, nk - 1), ra1, rw1);
+        compute(1);
+        store_tile(0, ra0, rw0);
+        __syncthreads();
+    }
+    if (kt < nk) compute(0);
+    __syncthreads();
+
+    // ---- sum the two K halves through LDS: K-half 0 owns column tiles 0..4, K-half 1 owns 5..8
+    float* red = reinterpret_cast<float*>(smem);  // [wm][mi][ni][r][lane]: lane-contiguous, conflict-free
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const bool mine = (ni < 5) == (kg == 0);
+            if (!mine) {
+                float* dst = red + (((wm * MI + mi) * NI + ni) * 4) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[r * 64] = acc[mi][ni][r];
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const bool mine = (ni < 5) == (kg == 0);
+        if (!mine) continue;
+        const ColInfo c = make_col<DT, EPI>(p, n0 + ni * 16 + lr);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const float* src = red + (((wm * MI + mi) * NI + ni) * 4) * 64 + lane;
+            const float q[4] = {acc[mi][ni][0] + src[0], acc[mi][ni][1] + src[64], acc[mi][ni][2] + src[128],
+                                acc[mi][ni][3] + src[192]};
+            epilogue_quad<DT, EPI>(p, c, m0 + wm * 32 + mi * 16 + 4 * lg, q);
         }
     }
 }
@@ -306,12 +516,22 @@ int launch(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
     PRIMX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 8 == 0, "%s: need M,N>0 and K %% 8 == 0 (M=%d N=%d K=%d)",
                   name, a.M, a.N, a.K);
     const int mt = (a.M + 127) / 128;
-    if (a.N <= 32) {  // Narrow tile
-        hipLaunchKernelGGL((gemm_kernel<DT, EPI, 4, 1, 1, 1, GATHER>), dim3(mt * ((a.N + 31) / 32)), dim3(256), 0, st, a);
-    } else {
-        hipLaunchKernelGGL((gemm_kernel<DT, EPI, 2, 2, 2, 2, GATHER>), dim3(mt * ((a.N + 127) / 128)), dim3(256), 0, st,
-                           a);
-    }
+    const bool tail = (a.K % BK) != 0;
+#define PRIMX_GEMM_LAUNCH(KT)                                                                                         \
+    do {                                                                                                              \
+        if (a.N <= 32) {                                                                                              \
+            hipLaunchKernelGGL((gemm_kernel<DT, EPI, 32, 4, 1, 1, 1, GATHER, KT>), dim3(mt * ((a.N + 31) / 32)),      \
+                               dim3(256), 0, st, a);                                                                  \
+        } else if (a.N % 144 == 0 && !GATHER) {                                                                       \
+            hipLaunchKernelGGL((gemm144_kernel<DT, EPI, KT>), dim3(mt * (a.N / 144)), dim3(512), 0, st, a);           \
+        } else {                                                                                                      \
+            hipLaunchKernelGGL((gemm_kernel<DT, EPI, 32, 2, 2, 2, 2, GATHER, KT>), dim3(mt * ((a.N + 127) / 128)),    \
+                               dim3(256), 0, st, a);                                                                  \
+        }                                                                                                             \
+    } while (0)
+    if (tail) PRIMX_GEMM_LAUNCH(1);
+    else PRIMX_GEMM_LAUNCH(0);
+#undef PRIMX_GEMM_LAUNCH
     PRIMX_CHECK_LAUNCH(name);
     return PRIMX_OK;
 }

@@ -67,7 +67,7 @@ def step_stream(diffusion, model, x, kw):
             yield out
 
 
-def cpu_baseline(n_prim: int, budget_blocks: int = 14):
+def cpu_baseline(n_prim: int, budget_blocks: int = 14, threads: int = 32):
     """The CPU oracle (oracle/dit_ref.py, fp32 - the port of the reference algorithm) on a bounded
     sample: one CFG step (effective batch 2) at the full width with `budget_blocks` of the 28 blocks,
     extrapolated linearly in depth (blocks are identical in cost; embedders/final layer are < 0.1 %)."""
@@ -78,7 +78,7 @@ def cpu_baseline(n_prim: int, budget_blocks: int = 14):
     x = synth.tensor(0, "x", (1, n_prim, 68))
     y = synth.tensor(0, "y", (1, L_COND, 768))
     t = torch.tensor([960])
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(threads, os.cpu_count() or 1))   # 32 is the measured optimum on the 256-core GPU-box host
     with torch.no_grad():
         t0 = time.perf_counter()
         dit_ref.dit_forward_with_cfg(sd, x, t, y, 16, 6.0)
