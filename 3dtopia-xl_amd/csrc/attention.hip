@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
         const S* kb = smem + buf * BUF;
         const S* vb = kb + KT;
         f32x16 sc[2];
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
                 sc[kt] = T16<DT>::mfma32(a, qf[s], sc[kt]);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         if ((j + 1) * BKV > nkv) {  // mask the tail keys of the last tile
             const int kbase = j * BKV + 4 * hi;
 #pragma unroll
@@ -169,26 +171,27 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
         }
         const float mc = m_run * c;
         float psum = 0.f;
-        V8 pb[4];
+        // key-step outer: the PV MFMAs of key-step ks issue as soon as ITS 8 probabilities are ready and run
+        // while the VALU is still exponentiating key-steps ks+1.. (MFMA and VALU are separate pipes)
+        const S* vrow = vb + l31 * VROW + hi * 8;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            V8 pb;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float pv = __builtin_amdgcn_exp2f(sc[ks >> 1][8 * (ks & 1) + e] * c - mc);
                 psum += pv;
-                pb[ks][e] = (S)pv;
+                pb[e] = (S)pv;
             }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int t = 0; t < DTILES; ++t) {
+                V8 a = *reinterpret_cast<const V8*>(vrow + t * 32 * VROW + ks * 16);
+                o[t] = T16<DT>::mfma32(a, pb, o[t]);
+            }
+            __builtin_amdgcn_s_setprio(0);
         }
         l_run += psum;
-#pragma unroll
-        for (int t = 0; t < DTILES; ++t) {
-            const S* vrow = vb + (t * 32 + l31) * VROW + hi * 8;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                V8 a = *reinterpret_cast<const V8*>(vrow + ks * 16);
-                o[t] = T16<DT>::mfma32(a, pb[ks], o[t]);
-            }
-        }
     };
 
     // ---- main loop: prefetch distance 2 (set A / set B), branch-free body

@@ -69,6 +69,7 @@ struct GemmArgs {
     int kind[3];
     S* dst[3];
     float scale0;
+    int64_t rep_stride;  // the n_seg column groups repeat; repetition r writes at dst[s] + r * rep_stride
     // EPI_RES: out = cast16((acc + bias + res) * out_scale); res may be null
     const S* res;
     // conv gather (GATHER) and EPI_CONVT geometry
@@ -104,7 +105,7 @@ struct ColInfo {
     int n;
     bool ok;
     float bias;
-    int seg, hh, dd;
+    int seg, hh, dd, rep;
 };
 
 template <int DT, int EPI>
@@ -112,11 +113,13 @@ __device__ __forceinline__ ColInfo make_col(const GemmArgs<DT>& p, int n) {
     ColInfo c;
     c.n = n;
     c.ok = n < p.N;
-    c.seg = c.hh = c.dd = 0;
+    c.seg = c.hh = c.dd = c.rep = 0;
     if (EPI == EPI_HEADS && c.ok) {
         const int per = p.heads * p.dh;
-        c.seg = n / per;
-        const int w = n - c.seg * per;
+        const int seg_all = n / per;
+        c.rep = seg_all / p.n_seg;
+        c.seg = seg_all - c.rep * p.n_seg;
+        const int w = n - seg_all * per;
         c.hh = w / p.dh;
         c.dd = w - c.hh * p.dh;
     }
@@ -186,6 +189,7 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs<DT>& p, const ColIn
         int kind = p.kind[0];
         if (c.seg == 1) { dst = p.dst[1]; kind = p.kind[1]; }
         if (c.seg == 2) { dst = p.dst[2]; kind = p.kind[2]; }
+        dst += c.rep * p.rep_stride;
         if (c.seg == 0 && p.scale0 != 1.0f) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = rnd16<DT>(p.scale0 * v[j]);
@@ -510,6 +514,149 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const GemmArgs<DT> p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// T144 with LDS-DMA staging (K % 64 == 0): same tile / wave roles / reduction as gemm144_kernel, but the
+// operand tiles go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a
+// 3-stage ring: no staging VGPRs, no ds_write pass (272 of the 640 LDS-array cycles per k-tile measured on
+// the register-staged kernel, profiles/r1_gemm_pmc.txt), two tiles in flight across every barrier.
+// A stage is one 272-row x 128-byte image (rows 0..127 = A, 128..271 = W); wave-instruction t covers rows
+// 8t..8t+7, and because LDS-DMA writes lane-linearly (base + lane*16) the XOR swizzle is applied to the
+// per-lane SOURCE address: lane (r = lane>>3, c' = lane&7) fetches global chunk c' ^ ((row>>1)&7) of its row
+// (cdna_hip_programming.md rule 21).  Sync per k-tile: s_waitcnt vmcnt(4) (this wave's DMAs of tile kt have
+// landed, tile kt+1's stay in flight) + raw s_barrier; __syncthreads() would drain the ring.
+template <int DT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> p) {
+    using S = typename T16<DT>::S;
+    using V8 = typename T16<DT>::V8;
+    typedef __attribute__((address_space(1))) const void GV;
+    typedef __attribute__((address_space(3))) void LV;
+    constexpr int BM = 128, BN = 144, MI = 2, NI = 9;
+    constexpr int ROWS = BM + BN;                        // 272 rows per stage
+    constexpr int STAGE = ROWS * 64;                     // halves per stage (34,816 B)
+    constexpr int NINST = ROWS / 8;                      // 34 wave-instructions per stage
+    constexpr int NSLOT = (NINST + 7) / 8;               // 5 slots per wave (waves 0,1 use all 5, others 4)
+    constexpr int RED_HALVES = BM * BN * 2;
+    constexpr int LDS_HALVES = (3 * STAGE > RED_HALVES) ? 3 * STAGE : RED_HALVES;
+    __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave >> 2, wm = wave & 3;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    const int nt = p.N / BN, mt = (p.M + BM - 1) / BM;
+    const int id = xcd_remap(blockIdx.x, nt * mt);
+    const int m0 = (id / nt) * BM, n0 = (id % nt) * BN;
+
+    // per-slot source pointers (k-tile 0) for this lane
+    const S* gp[NSLOT];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+        const int t = min(wave + 8 * i, NINST - 1);
+        const int row = 8 * t + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        gp[i] = (row < BM) ? p.A + (int64_t)min(m0 + row, p.M - 1) * p.K + c * 8
+                           : p.W + (int64_t)(n0 + row - BM) * p.K + c * 8;
+    }
+    const bool last_slot = wave + 8 * (NSLOT - 1) < NINST;  // wave-uniform
+    auto issue = [&](int kt, int stage) {
+        S* base = smem + stage * STAGE + wave * 512;        // instruction t lands at stage + t * 1 KiB
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            if (i < NSLOT - 1 || last_slot)
+                __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + kt * BK), (LV*)(base + i * 8 * 512), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int a_row = wm * 32 + lr;
+    const int chunk = kg * 4 + lg;
+    // Fragment double buffering: tile kt+1's fragments are read from LDS (non-blocking ds_read_b128) BEFORE the
+    // 18 MFMAs of tile kt issue, so the LDS-read phase of one tile overlaps the MFMA phase of the previous one
+    // inside every wave (the lock-step "read all, then multiply" form left the MFMA pipe 58 % idle).
+    auto read_frags = [&](int stage, V8 (&a)[MI], V8 (&b)[NI]) {
+        const S* As = smem + stage * STAGE;
+        const S* Ws = As + BM * 64;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const V8*>(As + lds_off(a_row + i * 16, chunk));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(Ws + lds_off(lr + j * 16, chunk));
+    };
+    auto multiply = [&](const V8 (&a)[MI], const V8 (&b)[NI]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(a[i], b[j], acc[i][j]);
+    };
+
+    // Ring: tile j lives in stage j % 3.  Step kt: [tile kt+1 landed, everyone done reading tile kt] ->
+    // DMA tile kt+3 into tile kt's stage -> read fragments of tile kt+1 -> MFMAs of tile kt.
+    const int nk = p.K / BK;
+    issue(0, 0);
+    issue(min(1, nk - 1), 1);
+    issue(min(2, nk - 1), 2);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // tile 0 landed (4..5 DMAs per tile per wave)
+    V8 a0[MI], b0[NI], a1[MI], b1[NI];
+    read_frags(0, a0, b0);
+    int st_cur = 0, st_next = 1;  // stage of tile kt / tile kt+1
+    auto step = [&](int kt, const V8 (&ac)[MI], const V8 (&bc)[NI], V8 (&an)[MI], V8 (&bn)[NI]) {
+        // vmcnt(4): tile kt+1 landed for this wave (tile kt+2 may stay in flight); lgkmcnt(0): this wave's reads of
+        // tile kt's stage have completed, so after the barrier that stage can be overwritten by the DMA below
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        issue(min(kt + 3, nk - 1), st_cur);
+        read_frags(st_next, an, bn);
+        multiply(ac, bc);
+        st_cur = st_next;
+        st_next = (st_next == 2) ? 0 : st_next + 1;
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        step(kt, a0, b0, a1, b1);
+        step(kt + 1, a1, b1, a0, b0);
+    }
+    if (kt < nk) step(kt, a0, b0, a1, b1);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // drain the (redundant) tail DMAs before LDS reuse
+
+    // ---- sum the two K halves through LDS: K-half 0 owns column tiles 0..4, K-half 1 owns 5..8
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const bool mine = (ni < 5) == (kg == 0);
+            if (!mine) {
+                float* dst = red + (((wm * MI + mi) * NI + ni) * 4) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[r * 64] = acc[mi][ni][r];
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const bool mine = (ni < 5) == (kg == 0);
+        if (!mine) continue;
+        const ColInfo c = make_col<DT, EPI>(p, n0 + ni * 16 + lr);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const float* src = red + (((wm * MI + mi) * NI + ni) * 4) * 64 + lane;
+            const float q[4] = {acc[mi][ni][0] + src[0], acc[mi][ni][1] + src[64], acc[mi][ni][2] + src[128],
+                                acc[mi][ni][3] + src[192]};
+            epilogue_quad<DT, EPI>(p, c, m0 + wm * 32 + mi * 16 + 4 * lg, q);
+        }
+    }
+}
+
+// PRIMX_GEMM_REGSTAGE=1 selects the register-staged T144 kernel instead of the LDS-DMA one (A/B measurements)
+static const bool g_force_regstage = [] {
+    const char* e = getenv("PRIMX_GEMM_REGSTAGE");
+    return e && e[0] == '1';
+}();
+
 template <int DT, int EPI, int GATHER = 0>
 int launch(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
     PRIMX_REQUIRE(a.A && a.W, "%s: null operand", name);
@@ -523,7 +670,10 @@ int launch(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
             hipLaunchKernelGGL((gemm_kernel<DT, EPI, 32, 4, 1, 1, 1, GATHER, KT>), dim3(mt * ((a.N + 31) / 32)),      \
                                dim3(256), 0, st, a);                                                                  \
         } else if (a.N % 144 == 0 && !GATHER) {                                                                       \
-            hipLaunchKernelGGL((gemm144_kernel<DT, EPI, KT>), dim3(mt * (a.N / 144)), dim3(512), 0, st, a);           \
+            if (KT == 0 && !g_force_regstage)                                                                        \
+                hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI>), dim3(mt * (a.N / 144)), dim3(512), 0, st, a);       \
+            else                                                                                                      \
+                hipLaunchKernelGGL((gemm144_kernel<DT, EPI, KT>), dim3(mt * (a.N / 144)), dim3(512), 0, st, a);       \
         } else {                                                                                                      \
             hipLaunchKernelGGL((gemm_kernel<DT, EPI, 32, 2, 2, 2, 2, GATHER, KT>), dim3(mt * ((a.N + 127) / 128)),    \
                                dim3(256), 0, st, a);                                                                  \
@@ -590,9 +740,10 @@ extern "C" int primx_linear_gate_residual(const void* A, const void* W, const vo
 
 extern "C" int primx_linear_heads(const void* A, const void* W, const void* bias, int M, int N, int K,
                                   int rows_per_batch, int heads, int dh, int n_seg, const int* kind, void* const* dst,
-                                  int n_pad, float scale0, int dtype, void* stream) {
-    PRIMX_REQUIRE(kind && dst && n_seg >= 1 && n_seg <= 3, "primx_linear_heads: n_seg must be 1..3");
-    PRIMX_REQUIRE(heads > 0 && dh > 0 && N == n_seg * heads * dh, "primx_linear_heads: N must equal n_seg*heads*dh");
+                                  int n_rep, int64_t rep_stride, int n_pad, float scale0, int dtype, void* stream) {
+    PRIMX_REQUIRE(kind && dst && n_seg >= 1 && n_seg <= 3 && n_rep >= 1, "primx_linear_heads: n_seg must be 1..3, n_rep >= 1");
+    PRIMX_REQUIRE(heads > 0 && dh > 0 && N == n_rep * n_seg * heads * dh,
+                  "primx_linear_heads: N must equal n_rep*n_seg*heads*dh");
     PRIMX_REQUIRE(rows_per_batch > 0 && M % rows_per_batch == 0 && n_pad >= rows_per_batch && n_pad % 16 == 0,
                   "primx_linear_heads: need M %% rows_per_batch == 0, n_pad >= rows_per_batch, n_pad %% 16 == 0");
     for (int s = 0; s < n_seg; ++s) {
@@ -605,7 +756,7 @@ extern "C" int primx_linear_heads(const void* A, const void* W, const void* bias
         a.A = (const S*)A; a.W = (const S*)W; a.bias = (const S*)bias;
         a.M = M; a.N = N; a.K = K;
         a.rows_per_batch = rows_per_batch; a.heads = heads; a.dh = dh; a.DP = primx_padded_head_dim(dh);
-        a.n_pad = n_pad; a.n_seg = n_seg; a.scale0 = scale0;
+        a.n_pad = n_pad; a.n_seg = n_seg; a.scale0 = scale0; a.rep_stride = rep_stride;
         for (int s = 0; s < 3; ++s) {
             a.kind[s] = s < n_seg ? kind[s] : 0;
             a.dst[s] = s < n_seg ? (S*)dst[s] : nullptr;

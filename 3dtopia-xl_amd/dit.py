@@ -10,7 +10,9 @@ Same constructor kwargs, same ``state_dict`` keys (515 tensors for the shipped c
 * q/k/v projections write the attention operand layouts (padded head-major Q/K, transposed
   quad-permuted V) straight from the GEMM epilogue - there is no reshape/unbind/permute pass;
 * the adaLN Linear of all blocks + final layer is ONE weight-streaming GEMM per forward
-  ([B, D] x [D, depth*9D + 2D]) instead of depth+1 GEMV-shaped launches;
+  ([B, D] x [D, depth*9D + 2D]) instead of depth+1 GEMV-shaped launches, and the cross-attention
+  to_k / to_v projections of all blocks (same conditioning tokens) are ONE GEMM with N = depth*2D
+  writing a [depth, ...] K / V^T cache - fixed per-launch cost dominates these small-K GEMMs;
 * rounding points follow the reference's fp16/bf16 autocast topology (fp32 residual stream and
   LayerNorm, 16-bit Linear/attention outputs, 16-bit modulation vectors, 16-bit CFG combine), see
   DESIGN.md "Numerics".
@@ -185,8 +187,13 @@ class DiT(nn.Module):
                 })
             ada_w = [b.adaLN_modulation[1].weight for b in self.blocks] + [self.final_layer.adaLN_modulation[1].weight]
             ada_b = [b.adaLN_modulation[1].bias for b in self.blocks] + [self.final_layer.adaLN_modulation[1].bias]
+            kv_w = [torch.cat([b.crossattn.to_k.weight, b.crossattn.to_v.weight], 0) for b in self.blocks]
+            kv_b = [torch.cat([b.crossattn.to_k.bias, b.crossattn.to_v.bias], 0) for b in self.blocks]
             pk = {
                 "blocks": blocks,
+                # to_k / to_v of ALL blocks read the same conditioning tokens: one [depth*2D, Dc] matrix
+                "w_kv_all": _c16(torch.cat(kv_w, 0), dtype) if kv_w else None,
+                "b_kv_all": _c16(torch.cat(kv_b, 0), dtype) if kv_b else None,
                 "w_ada": _c16(torch.cat(ada_w, 0), dtype), "b_ada": _c16(torch.cat(ada_b, 0), dtype),
                 "w_final": _c16(self.final_layer.linear.weight, dtype),
                 "b_final": _c16(self.final_layer.linear.bias, dtype),
@@ -233,8 +240,14 @@ class DiT(nn.Module):
 
         nq_pad = ops.round_up(N, ops.BQ)
         Qc = self._heads("Qc", Be, N, HEADS_ROWS, dt, dev, ops.BQ)
-        Kc = self._heads("Kc", Be, L, HEADS_ROWS, dt, dev, ops.BKV)
-        Vc = self._heads("Vc", Be, L, HEADS_VT, dt, dev, ops.BKV)
+        # cross-attention K / V of every block in ONE projection GEMM (N = depth * 2D): [depth*Be, H, L_pad, DP]
+        Kc = self._heads("Kc", self.depth * Be, L, HEADS_ROWS, dt, dev, ops.BKV)
+        Vc = self._heads("Vc", self.depth * Be, L, HEADS_VT, dt, dev, ops.BKV)
+        Kc_blk = Kc.view(self.depth, Be, *Kc.shape[1:])
+        Vc_blk = Vc.view(self.depth, Be, *Vc.shape[1:])
+        if self.depth:
+            ops.linear_heads(y16, pk["w_kv_all"], pk["b_kv_all"], L, H, dh, [HEADS_ROWS, HEADS_VT], [Kc, Vc],
+                             Kc.shape[2], n_rep=self.depth, rep_stride=Kc_blk[0].numel())
         Qs = self._heads("Qs", Be, N, HEADS_ROWS, dt, dev, ops.BQ)
         Ks = self._heads("Ks", Be, N, HEADS_ROWS, dt, dev, ops.BQ)
         Vs = self._heads("Vs", Be, N, HEADS_VT, dt, dev, ops.BQ)
@@ -249,8 +262,7 @@ class DiT(nn.Module):
             # ---- cross-attention to the image tokens (dit_crossattn.py:55, attention.py:96-114)
             ops.layernorm_modulate(h, ch[0], ch[1], N, xn, self.LN_EPS)
             ops.linear_heads(xn, w["w_q"], w["b_q"], N, H, dh, [HEADS_ROWS], [Qc], nq_pad, scale0=scale)
-            ops.linear_heads(y16, w["w_kv"], w["b_kv"], L, H, dh, [HEADS_ROWS, HEADS_VT], [Kc, Vc], Kc.shape[2])
-            ops.attention(Qc, Kc, Vc, N, L, dh, scale, out=att)
+            ops.attention(Qc, Kc_blk[i], Vc_blk[i], N, L, dh, scale, out=att)
             ops.linear_gate_residual(att.view(T, D), w["w_cproj"], w["b_cproj"], ch[2], h, N)
             # ---- self-attention over the primitive tokens (dit_crossattn.py:56, attention.py:48-59)
             ops.layernorm_modulate(h, ch[3], ch[4], N, xn, self.LN_EPS)

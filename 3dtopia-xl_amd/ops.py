@@ -159,7 +159,8 @@ def linear_gate_residual(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.
 
 def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], rows_per_batch: int, heads: int,
                  dh: int, kinds: Sequence[int], dsts: Sequence[torch.Tensor], n_pad: int,
-                 scale0: float = 1.0) -> None:
+                 scale0: float = 1.0, n_rep: int = 1, rep_stride: int = 0) -> None:
+    """n_rep > 1: the column groups repeat; repetition r is written at dsts[s] + r * rep_stride elements."""
     M, K = A.shape
     N = W.shape[0]
     n_seg = len(kinds)
@@ -167,7 +168,8 @@ def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     dst_arr = (C.c_void_p * n_seg)(*[_dev(d, "dst", A.dtype) for d in dsts])
     _timed("gemm_kernel<EPI_HEADS>", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_heads(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None, M, N, K,
-        rows_per_batch, heads, dh, n_seg, kind_arr, dst_arr, n_pad, scale0, dtype_code(A.dtype), _stream()),
+        rows_per_batch, heads, dh, n_seg, kind_arr, dst_arr, n_rep, rep_stride, n_pad, scale0, dtype_code(A.dtype),
+        _stream()),
         "primx_linear_heads"))
 
 

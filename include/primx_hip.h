@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 5
+#define PRIMX_ABI_VERSION 6
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -108,16 +108,18 @@ int primx_linear_gate_residual(const void* A, const void* W, const void* bias, c
                                int64_t gate_stride, float* x, int M, int N, int K, int rows_per_batch,
                                int dtype, void* stream);
 
-/* Projection whose output columns are `n_seg` groups of (heads * dh) features, each written
- * straight into an attention operand layout (see PRIMX_HEADS_*): dst[s] with kind[s]; rows of
- * batch b (= m / rows_per_batch) go to [b, h, m % rows_per_batch, :].  Segment 0 is multiplied
- * by `scale0` (after rounding) - the cross-attention `self.scale * to_q(q)` (attention.py:105).
- * Pad rows/cols of the destinations are never written (callers zero them once).
+/* Projection whose output columns are `n_rep` repetitions of `n_seg` groups of (heads * dh) features
+ * (N = n_rep * n_seg * heads * dh), each group written straight into an attention operand layout (see
+ * PRIMX_HEADS_*): group s of repetition r goes to dst[s] + r * rep_stride (elements) with kind[s]; rows of
+ * batch b (= m / rows_per_batch) go to [b, h, m % rows_per_batch, :].  Group 0 is multiplied by `scale0`
+ * (after rounding) - the cross-attention `self.scale * to_q(q)` (attention.py:105).  Pad rows/cols of the
+ * destinations are never written (callers zero them once).  n_rep > 1 batches the SAME projection of several
+ * DiT blocks over one input: the to_k/to_v projections of all 28 blocks read the same conditioning tokens.
  * Replaces qkv Linear + reshape + unbind (attention.py:50-52) and to_q/to_k/to_v + reshape
  * (attention.py:105-107). */
 int primx_linear_heads(const void* A, const void* W, const void* bias, int M, int N, int K, int rows_per_batch,
-                       int heads, int dh, int n_seg, const int* kind, void* const* dst, int n_pad,
-                       float scale0, int dtype, void* stream);
+                       int heads, int dh, int n_seg, const int* kind, void* const* dst, int n_rep,
+                       int64_t rep_stride, int n_pad, float scale0, int dtype, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Attention (flash-style, fp32 online softmax, MFMA 32x32x16)

@@ -1,0 +1,28 @@
+"""Micro-benchmark of primx_attention at the DiT-XL shapes (HIP-event timing)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__
+__graft_entry__.build()
+from topia_xl_amd import ops
+from topia_xl_amd._lib import HEADS_ROWS, HEADS_VT
+
+dev, dt, reps = "cuda:0", torch.float16, int(os.environ.get("REPS", "20"))
+for name, B, H, nq, nkv, dh in [("self_b1", 2, 16, 2048, 2048, 72), ("cross_b1", 2, 16, 2048, 1370, 72),
+                                ("self_b8", 16, 16, 2048, 2048, 72), ("self_n4096", 2, 16, 4096, 4096, 72)]:
+    q = torch.randn(B, nq, H, dh, device=dev).to(dt)
+    k = torch.randn(B, nkv, H, dh, device=dev).to(dt)
+    v = torch.randn(B, nkv, H, dh, device=dev).to(dt)
+    Q, K, Vt = ops.pack_heads(q, HEADS_ROWS, 128), ops.pack_heads(k, HEADS_ROWS, 64), ops.pack_heads(v, HEADS_VT, 64)
+    out = torch.empty(B, nq, H * dh, device=dev, dtype=dt)
+    for _ in range(3):
+        ops.attention(Q, K, Vt, nq, nkv, dh, dh ** -0.5, out=out)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        ops.attention(Q, K, Vt, nq, nkv, dh, dh ** -0.5, out=out)
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / reps
+    print(f"{name:11s} B={B:3d} nq={nq} nkv={nkv}  {us:8.1f} us  {4.0*B*H*nq*nkv*dh/us/1e6:7.1f} TFLOP/s (algorithmic, dh=72)", flush=True)
