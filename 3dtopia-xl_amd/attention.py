@@ -75,8 +75,8 @@ class MemEffAttention(_PackedMixin, nn.Module):
         w = self._packed(dt)
         n_pad = ops.round_up(N, ops.BQ)
         H, dh = self.num_heads, self.head_dim
-        Q = ops.alloc_heads(B, H, N, dh, HEADS_ROWS, dt, x.device, ops.BQ)
-        K = ops.alloc_heads(B, H, N, dh, HEADS_ROWS, dt, x.device, ops.BQ)
+        Q = ops.alloc_heads(B, H, N, dh, HEADS_ROWS, dt, x.device, ops.BQ, "q")
+        K = ops.alloc_heads(B, H, N, dh, HEADS_ROWS, dt, x.device, ops.BQ, "k")
         Vt = ops.alloc_heads(B, H, N, dh, HEADS_VT, dt, x.device, ops.BQ)
         ops.linear_heads(a, w["w_qkv"], w["b_qkv"], N, H, dh, [HEADS_ROWS, HEADS_ROWS, HEADS_VT], [Q, K, Vt], n_pad)
         att = ops.attention(Q, K, Vt, N, N, dh, self.scale)
@@ -129,8 +129,8 @@ class MemEffCrossAttention(_PackedMixin, nn.Module):
         c = to16(k.reshape(B * M, -1))
         w = self._packed(dt)
         H, dh = self.num_heads, self.head_dim
-        Q = ops.alloc_heads(B, H, N, dh, HEADS_ROWS, dt, q.device, ops.BQ)
-        K = ops.alloc_heads(B, H, M, dh, HEADS_ROWS, dt, q.device, ops.BKV)
+        Q = ops.alloc_heads(B, H, N, dh, HEADS_ROWS, dt, q.device, ops.BQ, "q")
+        K = ops.alloc_heads(B, H, M, dh, HEADS_ROWS, dt, q.device, ops.BKV, "k")
         Vt = ops.alloc_heads(B, H, M, dh, HEADS_VT, dt, q.device, ops.BKV)
         ops.linear_heads(a, w["w_q"], w["b_q"], N, H, dh, [HEADS_ROWS], [Q], Q.shape[2], scale0=self.scale)
         ops.linear_heads(c, w["w_kv"], w["b_kv"], M, H, dh, [HEADS_ROWS, HEADS_VT], [K, Vt], K.shape[2])

@@ -206,7 +206,8 @@ class DiT(nn.Module):
         key = (tag, B, n, kind, dtype, str(device), pad_to)
         buf = self._heads_ws.get(key)
         if buf is None:
-            buf = ops.alloc_heads(B, self.num_heads, n, self.hidden_size // self.num_heads, kind, dtype, device, pad_to)
+            buf = ops.alloc_heads(B, self.num_heads, n, self.hidden_size // self.num_heads, kind, dtype, device, pad_to,
+                                  role=tag[0].lower())  # "q" / "k": operand-level key-padding mask (ops.alloc_heads)
             self._heads_ws[key] = buf
         return buf
 

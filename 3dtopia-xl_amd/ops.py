@@ -174,12 +174,33 @@ def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
 
 
 # ----------------------------------------------------------------------------- attention
-def alloc_heads(B: int, H: int, n: int, dh: int, kind: int, dtype: torch.dtype, device, pad_to: int) -> torch.Tensor:
-    """Zero-initialised attention operand buffer (pad rows/cols must stay zero)."""
+KEY_MASK_VALUE = -30000.0  # finite in fp16 and bf16; times scale*log2(e) it underflows exp2 to exactly 0
+
+
+def alloc_heads(B: int, H: int, n: int, dh: int, kind: int, dtype: torch.dtype, device, pad_to: int,
+                role: Optional[str] = None) -> torch.Tensor:
+    """Zero-initialised attention operand buffer; pads are never written by the kernels, so they keep what is put
+    here.  When the head dim has a spare padded column (dh < DP, e.g. 72 -> 80) the key-padding mask lives in
+    the operands: role "q" sets column dh to 1 for every query row, role "k" sets it to KEY_MASK_VALUE for the
+    pad rows >= n, so q.k of a padded key is -30000 and its probability is exactly 0; a V^T buffer gets an
+    all-ones row dh (valid keys only) that makes the PV MFMA produce the softmax row sum (include/primx_hip.h)."""
     DP = padded_head_dim(dh)
     n_pad = round_up(n, pad_to)
     shape = (B, H, n_pad, DP) if kind == HEADS_ROWS else (B, H, DP, n_pad)
-    return torch.zeros(shape, dtype=dtype, device=device)
+    buf = torch.zeros(shape, dtype=dtype, device=device)
+    if kind == HEADS_ROWS and DP > dh:
+        if role == "q":
+            buf[:, :, :, dh] = 1.0
+        elif role == "k" and n_pad > n:
+            buf[:, :, n:, dh] = KEY_MASK_VALUE
+    if kind == HEADS_VT and DP > dh:
+        # row dh of V^T = 1 for every valid key (at its quad-permuted position): the PV MFMA then accumulates
+        # sum_k P[k, q] - the softmax denominator - in output row dh for free
+        k = torch.arange(n, device=device)
+        quad = (k >> 2) & 3
+        pos = (k & ~15) | ((((quad & 1) << 1) | (quad >> 1)) << 2) | (k & 3)
+        buf[:, :, dh, pos] = 1.0
+    return buf
 
 
 def attention(Qp: torch.Tensor, Kp: torch.Tensor, Vt: torch.Tensor, nq: int, nkv: int, dh: int, scale: float,
@@ -197,12 +218,12 @@ def attention(Qp: torch.Tensor, Kp: torch.Tensor, Vt: torch.Tensor, nq: int, nkv
     return out
 
 
-def pack_heads(src: torch.Tensor, kind: int, pad_to: int) -> torch.Tensor:
-    """src: [B, M, H, dh] view with contiguous last dim -> attention operand layout."""
+def pack_heads(src: torch.Tensor, kind: int, pad_to: int, role: Optional[str] = None) -> torch.Tensor:
+    """src: [B, M, H, dh] view with contiguous last dim -> attention operand layout (role: see alloc_heads)."""
     B, M, H, dh = src.shape
     if src.stride(3) != 1 or not src.is_cuda:
         raise RuntimeError("pack_heads: last dim must be contiguous on a HIP device")
-    dst = alloc_heads(B, H, M, dh, kind, src.dtype, src.device, pad_to)
+    dst = alloc_heads(B, H, M, dh, kind, src.dtype, src.device, pad_to, role)
     m_pad = dst.shape[2] if kind == HEADS_ROWS else dst.shape[3]
     check(_lib.load().primx_pack_heads(src.data_ptr(), src.stride(0), src.stride(1), src.stride(2), dst.data_ptr(),
                                        kind, B, M, H, dh, m_pad, dtype_code(src.dtype), _stream()), "primx_pack_heads")
@@ -217,8 +238,8 @@ def memory_efficient_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor
         raise NotImplementedError("attn_bias is not used on the 3DTopia-XL path")
     B, Mq, H, dh = q.shape
     Mk = k.shape[1]
-    Qp = pack_heads(q, HEADS_ROWS, BQ)
-    Kp = pack_heads(k, HEADS_ROWS, BKV)
+    Qp = pack_heads(q, HEADS_ROWS, BQ, "q")
+    Kp = pack_heads(k, HEADS_ROWS, BKV, "k")
     Vt = pack_heads(v, HEADS_VT, BKV)
     out = attention(Qp, Kp, Vt, Mq, Mk, dh, dh ** -0.5 if scale is None else scale)
     return out.view(B, Mq, H, dh)

@@ -246,8 +246,8 @@ class VAE(nn.Module):
         H = w["heads"]
         dh = Cc // H
         t = ops.groupnorm_silu(h, w["g"], w["b"], w["groups"], w["eps"], False)
-        Q = ops.alloc_heads(P, H, V, dh, HEADS_ROWS, h.dtype, h.device, ops.BQ)
-        K = ops.alloc_heads(P, H, V, dh, HEADS_ROWS, h.dtype, h.device, ops.BQ)
+        Q = ops.alloc_heads(P, H, V, dh, HEADS_ROWS, h.dtype, h.device, ops.BQ, "q")
+        K = ops.alloc_heads(P, H, V, dh, HEADS_ROWS, h.dtype, h.device, ops.BQ, "k")
         Vt = ops.alloc_heads(P, H, V, dh, HEADS_VT, h.dtype, h.device, ops.BQ)
         ops.linear_heads(t.view(P * V, Cc), w["w_qkv"], w["b_qkv"], V, H, dh, [HEADS_ROWS, HEADS_ROWS, HEADS_VT],
                          [Q, K, Vt], Q.shape[2])

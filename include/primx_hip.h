@@ -127,8 +127,14 @@ int primx_linear_heads(const void* A, const void* W, const void* bias, int M, in
 
 /* out[b, q, h*dh + d] = sum_k softmax_k( scale * <Q[b,h,q,:], K[b,h,k,:]> ) V[b,h,k,d]
  * Qp: [B, H, nq_pad, DP] rows layout (nq_pad % 128 == 0); Kp: [B, H, nkv_pad, DP] rows layout;
- * Vt: [B, H, DP, nkv_pad] VT layout (nkv_pad % 64 == 0); keys >= nkv are masked; pad entries of
- * Kp/Vt/Qp must be finite (zero).  out: [B, nq, H*dh] 16-bit.  dh in {32, 64, 72}.
+ * Vt: [B, H, DP, nkv_pad] VT layout (nkv_pad % 64 == 0).  out: [B, nq, H*dh] 16-bit.  dh in {32, 64, 72}.
+ * Keys >= nkv are masked.  For dh == DP (32, 64) the kernel overwrites their scores; for dh < DP (72 -> 80)
+ * the mask is carried BY THE OPERANDS, which the caller prepares once (the pads are never written by any
+ * kernel): Qp[.., q, dh] = 1 for every row, Kp[.., key, dh] = -30000 for key in [nkv, nkv_pad) and 0 for valid
+ * keys, Vt[.., dh, pos(key)] = 1 for valid keys (the all-ones row: the PV MFMA accumulates the softmax
+ * denominator in output row dh), every other pad entry of Qp/Kp/Vt zero - a padded key then scores -30000
+ * through the MFMA itself and its probability underflows to exactly 0, with no mask or row-sum code in the
+ * softmax (ops.alloc_heads does this).
  * Replaces xformers.ops.memory_efficient_attention(q, k, v) (attention.py:54,109). */
 int primx_attention(const void* Qp, const void* Kp, const void* Vt, void* out, int B, int H, int nq, int nq_pad,
                     int nkv, int nkv_pad, int dh, float scale, int dtype, void* stream);

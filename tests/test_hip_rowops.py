@@ -126,4 +126,7 @@ def test_pack_heads_layouts(ops, dtype):
         buf = ops.pack_heads(src, kind, 64)
         back = unpack_rows(buf, M, dh) if kind == HEADS_ROWS else unpack_vt(buf, M, dh)
         assert torch.equal(back, src)
-        assert float(buf.float().abs().sum()) == pytest.approx(float(src.float().abs().sum()), rel=1e-3)  # pads stay 0
+        data = buf[:, :, :, :dh] if kind == HEADS_ROWS else buf[:, :, :dh, :]
+        assert float(data.float().abs().sum()) == pytest.approx(float(src.float().abs().sum()), rel=1e-3)  # pads stay 0
+        if kind == HEADS_VT:   # spare rows: row dh = ones at the valid keys (softmax denominator row), the rest zero
+            assert float(buf[:, :, dh].float().sum()) == B * H * M and float(buf[:, :, dh + 1:].float().abs().sum()) == 0.0
