@@ -217,6 +217,67 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs<DT>& p, const ColIn
     }
 }
 
+// Row-major epilogue unit: ONE row m, FOUR consecutive columns n..n+3 (n % 4 == 0, all inside one head / one
+// segment).  Every access is 8 bytes (16-bit destinations) or 16 bytes (the fp32 residual stream), and the 36 lanes
+// covering a 144-column tile row touch 288 / 576 contiguous bytes - the quad-per-lane form touches 32 / 64.
+template <int DT, int EPI>
+__device__ __forceinline__ void epilogue_row4(const GemmArgs<DT>& p, int m, int n, const f32x4 a) {
+    using S = typename T16<DT>::S;
+    using V4 = typename T16<DT>::V4;
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        const V4 bv = *reinterpret_cast<const V4*>(p.bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = (float)bv[j];
+    }
+    if (EPI == EPI_LINEAR) {
+        V4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float y = rnd16<DT>(a[j] + b[j]);
+            if (p.act == PRIMX_ACT_GELU_TANH) y = rnd16<DT>(gelu_tanh_f(y));
+            if (p.out_scale != 1.0f) y = rnd16<DT>(p.out_scale * y);
+            o[j] = (S)y;
+        }
+        *reinterpret_cast<V4*>(p.out + (int64_t)m * p.N + n) = o;
+    } else if (EPI == EPI_RES) {
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.res) {
+            const V4 rv = *reinterpret_cast<const V4*>(p.res + (int64_t)m * p.N + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = (float)rv[j];
+        }
+        V4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (S)((a[j] + b[j] + r[j]) * p.out_scale);
+        *reinterpret_cast<V4*>(p.out + (int64_t)m * p.N + n) = o;
+    } else if (EPI == EPI_GATE_RESIDUAL) {
+        const int bb = m / p.rows_per_batch;
+        const V4 gv = *reinterpret_cast<const V4*>(p.gate + (int64_t)bb * p.gate_stride + n);
+        f32x4* xp = reinterpret_cast<f32x4*>(p.x + (int64_t)m * p.N + n);
+        f32x4 xv = *xp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = xv[j] + rnd16<DT>((float)gv[j] * rnd16<DT>(a[j] + b[j]));
+        *xp = xv;
+    } else if (EPI == EPI_HEADS) {  // PRIMX_HEADS_ROWS segments only (VT segments keep the quad form)
+        const int per = p.heads * p.dh;
+        const int seg_all = n / per;
+        const int rep = seg_all / p.n_seg, seg = seg_all - rep * p.n_seg;
+        const int w = n - seg_all * per;
+        const int hh = w / p.dh, dd = w - hh * p.dh;
+        S* dst = (seg == 0 ? p.dst[0] : seg == 1 ? p.dst[1] : p.dst[2]) + rep * p.rep_stride;
+        const int bb = m / p.rows_per_batch, tok = m - bb * p.rows_per_batch;
+        V4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float y = rnd16<DT>(a[j] + b[j]);
+            if (seg == 0 && p.scale0 != 1.0f) y = rnd16<DT>(p.scale0 * y);
+            o[j] = (S)y;
+        }
+        *reinterpret_cast<V4*>(dst + (((int64_t)bb * p.heads + hh) * p.n_pad + tok) * p.DP + dd) = o;
+    }
+}
+
 // MF: MFMA edge (32 -> 32x32x16, 16 -> 16x16x32); WM x WN waves, each MI x NI MFMA tiles
 template <int DT, int EPI, int MF, int WM, int WN, int MI, int NI, int GATHER, int KTAIL>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs<DT> p) {
@@ -536,7 +597,10 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     constexpr int NINST = ROWS / 8;                      // 34 wave-instructions per stage
     constexpr int NSLOT = (NINST + 7) / 8;               // 5 slots per wave (waves 0,1 use all 5, others 4)
     constexpr int RED_HALVES = BM * BN * 2;
-    constexpr int LDS_HALVES = (3 * STAGE > RED_HALVES) ? 3 * STAGE : RED_HALVES;
+    constexpr int RS = BN + 4;                           // fp32 row stride of the row-major epilogue staging
+    constexpr int ROWMAJOR_HALVES = 2 * BM * RS * 2;     // both K halves, fp32 (151,552 B)
+    constexpr int LDS_HALVES = (3 * STAGE > ROWMAJOR_HALVES) ? 3 * STAGE : ROWMAJOR_HALVES;
+    static_assert(LDS_HALVES * 2 <= 160 * 1024 && RED_HALVES <= LDS_HALVES, "LDS budget");
     __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -622,8 +686,37 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     if (kt < nk) step(kt, a0, b0, a1, b1);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // drain the (redundant) tail DMAs before LDS reuse
 
-    // ---- sum the two K halves through LDS: K-half 0 owns column tiles 0..4, K-half 1 owns 5..8
+    // ---- epilogue.  Default: both K halves park their accumulators in LDS as fp32 [half][128][148]; after one
+    // barrier all 512 threads walk the tile ROW-MAJOR, 4 consecutive columns each (sum of the two halves ->
+    // epilogue_row4): coalesced 8 / 16-byte accesses instead of 2 / 4-byte ones (the fp32 residual read-modify-write
+    // alone cost +12 us per launch in quad form, tools/gemm_ksweep.py).  Column tiles that belong to a
+    // PRIMX_HEADS_VT segment keep the quad form (4 consecutive TOKENS per lane is what that layout wants).
+    bool quad_form = false;
+    if (EPI == EPI_HEADS) {
+        const int per = p.heads * p.dh;                 // row-major only when no 144-column tile straddles a segment
+        quad_form = (per % BN != 0) || p.kind[(n0 / per) % p.n_seg] == PRIMX_HEADS_VT;
+    }
     float* red = reinterpret_cast<float*>(smem);
+    if (!quad_form) {
+        float* mine = red + kg * (BM * RS);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[(wm * 32 + mi * 16 + 4 * lg + r) * RS + ni * 16 + lr] = acc[mi][ni][r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < (BM * (BN / 4)) / 512; ++i) {   // 4608 row-chunks / 512 threads = 9
+            const int cid = tid + 512 * i;
+            const int row = cid / (BN / 4), c4 = cid - row * (BN / 4);
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(red + row * RS + 4 * c4);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(red + BM * RS + row * RS + 4 * c4);
+            if (m0 + row < p.M) epilogue_row4<DT, EPI>(p, m0 + row, n0 + 4 * c4, v0 + v1);
+        }
+        return;
+    }
+    // ---- quad form: K-half 0 owns column tiles 0..4, K-half 1 owns 5..8
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll

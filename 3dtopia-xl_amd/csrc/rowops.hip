@@ -73,10 +73,83 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
     }
 }
 
+// Fast path for D % 128 == 0 (DiT-XL: 1152): one row per HALF-wave, float4 (16-byte) loads, 8-byte stores,
+// 5-step xor reductions inside the 32-lane half.  8 rows per 256-thread block.
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <int DT, int NCH4>
+__global__ __launch_bounds__(256) void ln_modulate_row32_kernel(const float* __restrict__ x,
+                                                               const typename T16<DT>::S* __restrict__ shift,
+                                                               const typename T16<DT>::S* __restrict__ scale,
+                                                               int64_t mod_stride,
+                                                               typename T16<DT>::S* __restrict__ out, int rows,
+                                                               int rows_per_batch, float eps) {
+    using S = typename T16<DT>::S;
+    using V4 = typename T16<DT>::V4;
+    constexpr int D = NCH4 * 128;
+    const int l32 = threadIdx.x & 31;
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * D + l32 * 4;
+    f32x4 v[NCH4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH4; ++c) {
+        v[c] = *reinterpret_cast<const f32x4*>(xr + c * 128);
+        s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+    }
+    const float mean = half_wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH4; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = v[c][j] - mean;
+            q += a * a;
+        }
+    const float rstd = 1.0f / sqrtf(half_wave_sum(q) * (1.0f / D) + eps);
+    const int b = row / rows_per_batch;
+    const S* sh = shift + (int64_t)b * mod_stride + l32 * 4;
+    const S* sc = scale + (int64_t)b * mod_stride + l32 * 4;
+    S* orow = out + (int64_t)row * D + l32 * 4;
+#pragma unroll
+    for (int c = 0; c < NCH4; ++c) {
+        const V4 s4 = *reinterpret_cast<const V4*>(sc + c * 128);
+        const V4 h4 = *reinterpret_cast<const V4*>(sh + c * 128);
+        V4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float m1 = rnd16<DT>(1.0f + (float)s4[j]);  // (1 + scale) is formed in the 16-bit type
+            o[j] = (S)((v[c][j] - mean) * rstd * m1 + (float)h4[j]);
+        }
+        *reinterpret_cast<V4*>(orow + c * 128) = o;
+    }
+}
+
 template <int DT>
 static int launch_ln_modulate(const float* x, const void* shift, const void* scale, int64_t mod_stride, void* out,
                               int rows, int rows_per_batch, int D, float eps, hipStream_t st) {
     using S = typename T16<DT>::S;
+    // 8-byte alignment of the modulation vectors is required by the fast path (chunks of the adaLN row: D*2 bytes apart)
+    const bool aligned = (((uintptr_t)shift | (uintptr_t)scale) & 7) == 0 && (mod_stride % 4) == 0;
+    if (D % 128 == 0 && aligned && D / 128 <= 16) {
+        dim3 g8((rows + 7) / 8), b256(256);
+#define LN32_CASE(N)                                                                                                   \
+    case N:                                                                                                            \
+        hipLaunchKernelGGL((ln_modulate_row32_kernel<DT, N>), g8, b256, 0, st, x, (const S*)shift, (const S*)scale,    \
+                           mod_stride, (S*)out, rows, rows_per_batch, eps);                                            \
+        return PRIMX_OK;
+        switch (D / 128) {
+            LN32_CASE(1) LN32_CASE(2) LN32_CASE(3) LN32_CASE(4) LN32_CASE(6) LN32_CASE(8) LN32_CASE(9) LN32_CASE(12)
+            LN32_CASE(16)
+            default: break;
+        }
+#undef LN32_CASE
+    }
     dim3 grid((rows + 3) / 4), block(256);
 #define LN_CASE(N)                                                                                              \
     case N:                                                                                                     \
