@@ -660,6 +660,20 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
 
     // Ring: tile j lives in stage j % 3.  Step kt: [tile kt+1 landed, everyone done reading tile kt] ->
     // DMA tile kt+3 into tile kt's stage -> read fragments of tile kt+1 -> MFMAs of tile kt.
+    // EPI_GATE_RESIDUAL: the fp32 residual rows this thread will update in the row-major epilogue are fetched NOW
+    // (9 x 16 bytes per thread); they land during the main loop, so the epilogue only has to add and write.
+    constexpr int NROWCH = (BM * (BN / 4)) / 512;
+    f32x4 xpre[NROWCH];
+    if (EPI == EPI_GATE_RESIDUAL) {
+#pragma unroll
+        for (int i = 0; i < NROWCH; ++i) {
+            const int cid = tid + 512 * i;
+            const int row = cid / (BN / 4), c4 = cid - row * (BN / 4);
+            const int m = min(m0 + row, p.M - 1);
+            xpre[i] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.N + n0 + 4 * c4);
+        }
+    }
+
     const int nk = p.K / BK;
     issue(0, 0);
     issue(min(1, nk - 1), 1);
@@ -712,7 +726,21 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
             const int row = cid / (BN / 4), c4 = cid - row * (BN / 4);
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(red + row * RS + 4 * c4);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(red + BM * RS + row * RS + 4 * c4);
-            if (m0 + row < p.M) epilogue_row4<DT, EPI>(p, m0 + row, n0 + 4 * c4, v0 + v1);
+            if (m0 + row >= p.M) continue;
+            if (EPI == EPI_GATE_RESIDUAL) {
+                using V4 = typename T16<DT>::V4;
+                const int m = m0 + row, n = n0 + 4 * c4;
+                const V4 gv = *reinterpret_cast<const V4*>(p.gate + (int64_t)(m / p.rows_per_batch) * p.gate_stride + n);
+                V4 bv = {};
+                if (p.bias) bv = *reinterpret_cast<const V4*>(p.bias + n);
+                f32x4 xv = xpre[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    xv[j] = xv[j] + rnd16<DT>((float)gv[j] * rnd16<DT>(v0[j] + v1[j] + (p.bias ? (float)bv[j] : 0.f)));
+                *reinterpret_cast<f32x4*>(p.x + (int64_t)m * p.N + n) = xv;
+            } else {
+                epilogue_row4<DT, EPI>(p, m0 + row, n0 + 4 * c4, v0 + v1);
+            }
         }
         return;
     }

@@ -45,6 +45,17 @@ def _stream() -> int:
 PROFILE = None
 
 
+def _gemm_tag(epi: int, M: int, N: int, K: int, dtype) -> str:
+    """Name of the kernel instantiation the C side selects (csrc/gemm.hip launch()), spelled as rocprofv3 prints
+    it, so bench.py's per-kernel numbers can be matched against profiles/*kernel_trace_summary.txt."""
+    dt = dtype_code(dtype)
+    if N <= 32:
+        return f"gemm_kernel<{dt}, {epi}, 32, 4, 1, 1, 1, 0, {int(K % 64 != 0)}>"
+    if N % 144 == 0:
+        return f"gemm144_dma_kernel<{dt}, {epi}>" if K % 64 == 0 else f"gemm144_kernel<{dt}, {epi}, 1>"
+    return f"gemm_kernel<{dt}, {epi}, 32, 2, 2, 2, 2, 0, {int(K % 64 != 0)}>"
+
+
 def _timed(tag: str, flops: float, fn):
     if PROFILE is None:
         return fn()
@@ -137,7 +148,7 @@ def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: 
         raise RuntimeError("linear: operand mismatch")
     if out is None:
         out = torch.empty(M, N, dtype=A.dtype, device=A.device)
-    _timed("gemm_kernel<EPI_LINEAR>", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear(
+    _timed(_gemm_tag(0, M, N, K, A.dtype), 2.0 * M * N * K, lambda: check(_lib.load().primx_linear(
         _dev(A, "A"), _dev(W, "W"), _dev(bias, "bias", A.dtype) if bias is not None else None,
         _dev(out, "out", A.dtype), M, N, K, dtype_code(A.dtype), act, out_scale, _stream()), "primx_linear"))
     return out
@@ -150,7 +161,7 @@ def linear_gate_residual(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.
     N = W.shape[0]
     if gate.stride(-1) != 1 or gate.dtype != A.dtype or not gate.is_cuda:
         raise RuntimeError("gate must be a last-dim-contiguous 16-bit device view")
-    _timed("gemm_kernel<EPI_GATE_RESIDUAL>", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_gate_residual(
+    _timed(_gemm_tag(1, M, N, K, A.dtype), 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_gate_residual(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None,
         gate.data_ptr(), gate.stride(0), _dev(x, "x", torch.float32), M, N, K, rows_per_batch,
         dtype_code(A.dtype), _stream()), "primx_linear_gate_residual"))
@@ -166,7 +177,7 @@ def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     n_seg = len(kinds)
     kind_arr = (C.c_int * n_seg)(*kinds)
     dst_arr = (C.c_void_p * n_seg)(*[_dev(d, "dst", A.dtype) for d in dsts])
-    _timed("gemm_kernel<EPI_HEADS>", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_heads(
+    _timed(_gemm_tag(2, M, N, K, A.dtype), 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_heads(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None, M, N, K,
         rows_per_batch, heads, dh, n_seg, kind_arr, dst_arr, n_rep, rep_stride, n_pad, scale0, dtype_code(A.dtype),
         _stream()),
@@ -212,7 +223,8 @@ def attention(Qp: torch.Tensor, Kp: torch.Tensor, Vt: torch.Tensor, nq: int, nkv
     if out is None:
         out = torch.empty(B, nq, H * dh, dtype=Qp.dtype, device=Qp.device)
     # algorithmic FLOPs: QK^T + PV on the unpadded head dim, softmax excluded
-    _timed("attn_kernel", 4.0 * B * H * nq * nkv * dh, lambda: check(_lib.load().primx_attention(
+    _timed(f"attn_kernel<{dtype_code(Qp.dtype)}, {padded_head_dim(dh) // 16}, {(dh + 31) // 32}, {int(padded_head_dim(dh) == dh)}, 0>",
+           4.0 * B * H * nq * nkv * dh, lambda: check(_lib.load().primx_attention(
         _dev(Qp, "Qp"), _dev(Kp, "Kp", Qp.dtype), _dev(Vt, "Vt", Qp.dtype), _dev(out, "out", Qp.dtype), B, H, nq,
         nq_pad, nkv, nkv_pad, dh, scale, dtype_code(Qp.dtype), _stream()), "primx_attention"))
     return out
