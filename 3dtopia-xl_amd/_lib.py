@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libprimx_hip.so")
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH = 0, 1
 HEADS_ROWS, HEADS_VT = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -42,6 +42,7 @@ SIGNATURES = {
     "primx_conv_in": [_p, _f, _f, _p, _p, _p, _i, _i, _i, _i, _p],
     "primx_convtranspose_k2s2": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "primx_vae_output": [_p, _p, _i, _i, _i, _i, _f, _i, _p],
+    "primx_latent_denorm": [_p, _p, _p, _f, _p, _p, _l, _i, _i, _p],
 }
 _RESTYPES = {"primx_last_error": C.c_char_p}
 

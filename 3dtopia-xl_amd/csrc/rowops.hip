@@ -536,3 +536,35 @@ extern "C" int primx_vae_output(const void* in, float* out, int P, int V, int C,
     PRIMX_CHECK_LAUNCH("primx_vae_output");
     return PRIMX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Latent de-normalisation + split (inference.py:328-332; app.py:119-123):  v = x / nf * std + mean per channel;
+// channels [0, n_srt) -> srt[row, :] (scale + xyz), channels [n_srt, C) -> z[row, :] (the 4^3 VAE latent).
+__global__ void latent_denorm_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                     const float* __restrict__ stdv, float nf, float* __restrict__ srt,
+                                     float* __restrict__ z, int64_t rows, int C, int n_srt) {
+#pragma clang fp contract(off)
+    const int64_t total = rows * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / C;
+        const int c = (int)(i - r * C);
+        const float q = x[i] / nf;
+        const float m = q * stdv[c];
+        const float v = m + mean[c];
+        if (c < n_srt) srt[r * n_srt + c] = v;
+        else z[r * (C - n_srt) + (c - n_srt)] = v;
+    }
+}
+
+extern "C" int primx_latent_denorm(const float* x, const float* mean, const float* stdv, float nf, float* srt,
+                                   float* z, int64_t rows, int C, int n_srt, void* stream) {
+    PRIMX_REQUIRE(x && mean && stdv && srt && z, "primx_latent_denorm: null pointer");
+    PRIMX_REQUIRE(rows > 0 && C > n_srt && n_srt > 0 && nf != 0.f, "primx_latent_denorm: bad shape");
+    const int64_t total = rows * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(latent_denorm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, mean, stdv, nf, srt, z,
+                       rows, C, n_srt);
+    PRIMX_CHECK_LAUNCH("primx_latent_denorm");
+    return PRIMX_OK;
+}

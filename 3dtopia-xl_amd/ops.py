@@ -353,3 +353,15 @@ def vae_output(x: torch.Tensor, denorm: bool, sdf_div: float = 5.0) -> torch.Ten
     check(_lib.load().primx_vae_output(_dev(x, "x"), out.data_ptr(), P, V, Cc, int(denorm), sdf_div,
                                        dtype_code(x.dtype), _stream()), "primx_vae_output")
     return out
+
+
+def latent_denorm(x: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, nf: float, n_srt: int = 4):
+    """x: [..., C] fp32 samples -> (srt [..., n_srt], z [..., C - n_srt]) de-normalised (inference.py:328-332)."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    srt = torch.empty(*x.shape[:-1], n_srt, dtype=torch.float32, device=x.device)
+    z = torch.empty(*x.shape[:-1], C - n_srt, dtype=torch.float32, device=x.device)
+    check(_lib.load().primx_latent_denorm(_dev(x, "x", torch.float32), _dev(mean, "mean", torch.float32),
+                                          _dev(std, "std", torch.float32), float(nf), srt.data_ptr(), z.data_ptr(),
+                                          rows, C, n_srt, _stream()), "primx_latent_denorm")
+    return srt, z

@@ -1,0 +1,48 @@
+"""Post-sampling driver of the hot path: denoised latents -> per-primitive PBR voxel payload.
+
+Mirrors what the reference's CLI / app do between the sampler and the ray-marcher / mesh export
+(inference.py:326-348, app.py:117-139):  de-normalise with the per-channel latent statistics, split
+(scale + xyz | 4^3 VAE latent), decode every sample's primitives, apply the decoder's inverse normalisation
+(SDF / 5, colour+material (v + 1) / 2) and concatenate to ``[B, N_prim, 4 + 6 * 8^3]`` - the ``recon_param``
+tensor the renderer and ``PrimSDF`` consume (``srt_param`` = [:, :, :4], ``feat_param`` = [:, :, 4:]).
+
+MI355X-first differences: the reference decodes one sample at a time "to avoid oom" (inference.py:334-340) and
+runs four full-tensor elementwise passes afterwards; here all B * N_prim primitives go through ONE decoder call
+(288 GB of HBM: 8 samples x 2048 primitives peak at ~9 GB of 16-bit activations), the inverse normalisation is
+fused into the decoder's output kernel and the latent de-normalisation + split is one kernel.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from . import ops
+
+
+def latents_to_primitives(samples: torch.Tensor, vae, latent_mean: Optional[Sequence[float]] = None,
+                          latent_std: Optional[Sequence[float]] = None, latent_nf: float = 1.0,
+                          max_prims_per_call: int = 8 * 2048) -> torch.Tensor:
+    """samples: (B, N_prim, 68) fp32 sampler output -> recon_param (B, N_prim, 4 + C_out * (2S)^3) fp32."""
+    if not samples.is_cuda:
+        raise RuntimeError("latents_to_primitives needs HIP device tensors; there is no CPU path")
+    B, N, C = samples.shape
+    dev = samples.device
+    if latent_mean is None:
+        # the reference's non-per-channel branch (inference.py:336-344) is dead for the shipped config (yml:64-65)
+        raise NotImplementedError("per-channel latent_mean / latent_std are required (configs/inference_dit.yml:64-65)")
+    mean = torch.as_tensor(latent_mean, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+    std = torch.as_tensor(latent_std, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+    if mean.numel() != C or std.numel() != C:
+        raise AssertionError("latent_mean / latent_std must have one entry per latent channel")
+    srt, z = ops.latent_denorm(samples.float().contiguous(), mean, std, latent_nf, 4)
+    S = round((C - 4) ** (1.0 / 3.0))
+    if S ** 3 != C - 4:
+        raise AssertionError("latent channels minus 4 must be a cube")
+    z = z.reshape(B * N, 1, S, S, S)
+    outs = []
+    for lo in range(0, B * N, max_prims_per_call):
+        outs.append(vae.decode(z[lo:lo + max_prims_per_call].contiguous(), denormalize=True))
+    dec = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+    feat = dec.reshape(B, N, -1)
+    return torch.cat([srt, feat], dim=-1)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 6
+#define PRIMX_ABI_VERSION 7
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -208,6 +208,12 @@ int primx_convtranspose_k2s2(const void* in, const void* Wt, const void* bias, v
  * (inference.py:345-346); denorm == 0 gives the raw VAE.decode output. */
 int primx_vae_output(const void* in, float* out, int P, int V, int C, int denorm, float sdf_div, int dtype,
                      void* stream);
+
+/* Latent de-normalisation + split after sampling: v = x / nf * std[c] + mean[c] (each op rounded to fp32, as
+ * torch does); channels [0, n_srt) -> srt [rows, n_srt], the rest -> z [rows, C - n_srt] (the VAE latent).
+ * Replaces inference.py:328-332 / app.py:119-123. */
+int primx_latent_denorm(const float* x, const float* mean, const float* stdv, float nf, float* srt, float* z,
+                        int64_t rows, int C, int n_srt, void* stream);
 
 #ifdef __cplusplus
 }
