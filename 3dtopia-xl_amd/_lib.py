@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libprimx_hip.so")
+LIB_PATH = os.environ.get("PRIMX_LIB") or os.path.join(_HERE, "csrc", "libprimx_hip.so")  # PRIMX_LIB: A/B builds
 
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH = 0, 1

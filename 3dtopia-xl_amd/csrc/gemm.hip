@@ -772,9 +772,142 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Big tile: 256 x 288, 8 waves = 4 (M) x 2 (N), each wave 64 x 144 = 4 x 9 tiles of 16x16x32, LDS-DMA staging into a
+// 2-stage ring (2 x 69,632 B).  Made for the GEMMs that the 128x144 kernel runs as several sequential rounds per CU
+// (fc1: N = 4608 = 16 x 288 -> exactly 256 workgroups at M = 4096; qkv: 192; the batched to_k/to_v: 2464): every
+// round pays ~5 us of un-overlapped prologue + epilogue (tools/gemm_ksweep.py), while here one barrier interval
+// carries 72 MFMAs per wave (4x), 13 LDS fragment reads per 36 MFMAs (vs 11 per 18) and half the staged bytes
+// per FLOP.  Two barriers per k-tile (landed / consumed); the DMA of tile kt+2 flies during the MFMAs of tile kt+1.
+// Epilogue: four 64-row slabs are staged through LDS as fp32 and walked row-major (or column-quad-wise for
+// PRIMX_HEADS_VT segments) with the same per-unit functions as the 128x144 kernel.
+template <int DT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm288_dma_kernel(const GemmArgs<DT> p) {
+    using S = typename T16<DT>::S;
+    using V8 = typename T16<DT>::V8;
+    typedef __attribute__((address_space(1))) const void GV;
+    typedef __attribute__((address_space(3))) void LV;
+    constexpr int BM = 256, BN = 288, MI = 4, NI = 9;
+    constexpr int ROWS = BM + BN;            // 544 rows of 128 bytes per stage
+    constexpr int STAGE = ROWS * 64;         // halves
+    constexpr int NINST = ROWS / 8;          // 68 wave-instructions per stage
+    constexpr int NSLOT = (NINST + 7) / 8;   // 9 (waves 0..3), 8 for waves 4..7
+    constexpr int RS = BN + 4;               // fp32 row stride of the epilogue slab
+    static_assert(64 * RS * 4 <= 2 * STAGE * 2, "slab fits in the ring");
+    __shared__ __attribute__((aligned(16))) S smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    const int nt = p.N / BN, mt = (p.M + BM - 1) / BM;
+    const int id = xcd_remap(blockIdx.x, nt * mt);
+    const int m0 = (id / nt) * BM, n0 = (id % nt) * BN;
+
+    const S* gp[NSLOT];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+        const int t = min(wave + 8 * i, NINST - 1);
+        const int row = 8 * t + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        gp[i] = (row < BM) ? p.A + (int64_t)min(m0 + row, p.M - 1) * p.K + c * 8
+                           : p.W + (int64_t)(n0 + row - BM) * p.K + c * 8;
+    }
+    const bool last_slot = wave + 8 * (NSLOT - 1) < NINST;  // wave-uniform (waves 0..3)
+    auto issue = [&](int kt, int stage) {
+        S* base = smem + stage * STAGE + wave * 512;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            if (i < NSLOT - 1 || last_slot)
+                __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + kt * BK), (LV*)(base + i * 8 * 512), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int a_row = wm * 64 + lr, w_row = wn * 144 + lr;
+    auto compute = [&](int stage) {
+        const S* As = smem + stage * STAGE;
+        const S* Ws = As + BM * 64;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int chunk = s * 4 + lg;
+            V8 a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const V8*>(As + lds_off(a_row + i * 16, chunk));
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(Ws + lds_off(w_row + j * 16, chunk));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(a[i], b[j], acc[i][j]);
+        }
+    };
+
+    const int nk = p.K / BK;
+    issue(0, 0);
+    issue(min(1, nk - 1), 1);
+    for (int kt = 0; kt < nk; ++kt) {
+        // 8..9 DMAs per tile per wave: <= 8 outstanding means tile kt has landed (tile kt+1 may still fly)
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        compute(kt & 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone is done reading this stage
+        issue(min(kt + 2, nk - 1), kt & 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // ---- epilogue: 4 slabs of 64 rows through LDS (fp32 [64][292])
+    float* stg = reinterpret_cast<float*>(smem);
+    bool col_walk = false;
+    if (EPI == EPI_HEADS) col_walk = p.kind[(n0 / (p.heads * p.dh)) % p.n_seg] == PRIMX_HEADS_VT;
+#pragma unroll 1
+    for (int slab = 0; slab < 4; ++slab) {
+        if (wm == slab) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stg[(i * 16 + 4 * lg + r) * RS + wn * 144 + j * 16 + lr] = acc[i][j][r];
+        }
+        __syncthreads();
+        const int mb = m0 + slab * 64;
+        if (!col_walk) {
+#pragma unroll
+            for (int it = 0; it < (64 * (BN / 4)) / 512; ++it) {      // 4608 row-chunks / 512 threads = 9
+                const int cid = tid + 512 * it;
+                const int row = cid / (BN / 4), c4 = cid - row * (BN / 4);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * RS + 4 * c4);
+                if (mb + row < p.M) epilogue_row4<DT, EPI>(p, mb + row, n0 + 4 * c4, v);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < (16 * BN) / 512; ++it) {            // 16 row-quads x 288 columns / 512 threads = 9
+                const int uid = tid + 512 * it;
+                const int rq = uid / BN, col = uid - rq * BN;
+                const float q[4] = {stg[(4 * rq) * RS + col], stg[(4 * rq + 1) * RS + col], stg[(4 * rq + 2) * RS + col],
+                                    stg[(4 * rq + 3) * RS + col]};
+                const ColInfo c = make_col<DT, EPI>(p, n0 + col);
+                epilogue_quad<DT, EPI>(p, c, mb + 4 * rq, q);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // PRIMX_GEMM_REGSTAGE=1 selects the register-staged T144 kernel instead of the LDS-DMA one (A/B measurements)
 static const bool g_force_regstage = [] {
     const char* e = getenv("PRIMX_GEMM_REGSTAGE");
+    return e && e[0] == '1';
+}();
+
+static const bool g_no_big = [] {   // PRIMX_GEMM_NOBIG=1 disables the 256x288 tile (A/B measurements)
+    const char* e = getenv("PRIMX_GEMM_NOBIG");
     return e && e[0] == '1';
 }();
 
@@ -785,11 +918,19 @@ int launch(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
                   name, a.M, a.N, a.K);
     const int mt = (a.M + 127) / 128;
     const bool tail = (a.K % BK) != 0;
+    // 256x288 tile: only where same-box A/B showed a win - the dense-output epilogues with enough workgroups to fill
+    // the chip (fc1 at T = 4096: exactly 256; every large-batch GEMM).  The heads epilogue stays on the 128x144 kernel
+    // (qkv would be 192 workgroups = 75 % of the CUs, and the scatter epilogue spilled at this tile's register budget).
+    const bool use_big = !g_no_big && a.N % 288 == 0 && ((a.M + 255) / 256) * (a.N / 288) >= 224 &&
+                         (EPI == EPI_LINEAR || EPI == EPI_RES || EPI == EPI_GATE_RESIDUAL);
 #define PRIMX_GEMM_LAUNCH(KT)                                                                                         \
     do {                                                                                                              \
         if (a.N <= 32) {                                                                                              \
             hipLaunchKernelGGL((gemm_kernel<DT, EPI, 32, 4, 1, 1, 1, GATHER, KT>), dim3(mt * ((a.N + 31) / 32)),      \
                                dim3(256), 0, st, a);                                                                  \
+        } else if (use_big && KT == 0 && !GATHER) {                                                                   \
+            hipLaunchKernelGGL((gemm288_dma_kernel<DT, EPI>), dim3(((a.M + 255) / 256) * (a.N / 288)), dim3(512), 0,  \
+                               st, a);                                                                                \
         } else if (a.N % 144 == 0 && !GATHER) {                                                                       \
             if (KT == 0 && !g_force_regstage)                                                                        \
                 hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI>), dim3(mt * (a.N / 144)), dim3(512), 0, st, a);       \

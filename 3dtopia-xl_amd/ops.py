@@ -51,6 +51,8 @@ def _gemm_tag(epi: int, M: int, N: int, K: int, dtype) -> str:
     dt = dtype_code(dtype)
     if N <= 32:
         return f"gemm_kernel<{dt}, {epi}, 32, 4, 1, 1, 1, 0, {int(K % 64 != 0)}>"
+    if epi != 2 and N % 288 == 0 and K % 64 == 0 and ((M + 255) // 256) * (N // 288) >= 224:
+        return f"gemm288_dma_kernel<{dt}, {epi}>"
     if N % 144 == 0:
         return f"gemm144_dma_kernel<{dt}, {epi}>" if K % 64 == 0 else f"gemm144_kernel<{dt}, {epi}, 1>"
     return f"gemm_kernel<{dt}, {epi}, 32, 2, 2, 2, 2, 0, {int(K % 64 != 0)}>"
