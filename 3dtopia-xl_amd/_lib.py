@@ -14,8 +14,8 @@ LIB_PATH = os.environ.get("PRIMX_LIB") or os.path.join(_HERE, "csrc", "libprimx_
 
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH = 0, 1
-HEADS_ROWS, HEADS_VT = 0, 1
-ABI_VERSION = 7
+HEADS_ROWS, HEADS_VT, HEADS_KROWS = 0, 1, 2
+ABI_VERSION = 8
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -31,7 +31,7 @@ SIGNATURES = {
     "primx_linear_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "primx_linear": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "primx_linear_gate_residual": [_p, _p, _p, _p, _l, _p, _i, _i, _i, _i, _i, _p],
-    "primx_linear_heads": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _l, _i, _f, _i, _p],
+    "primx_linear_heads": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _i, _i, _f, _i, _p],
     "primx_attention": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "primx_pack_heads": [_p, _l, _l, _l, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "primx_cfg_combine": [_p, _p, _i, _l, _f, _p],

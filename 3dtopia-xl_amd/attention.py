@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._lib import HEADS_ROWS, HEADS_VT
+from ._lib import HEADS_KROWS, HEADS_ROWS, HEADS_VT
 
 
 class _PackedMixin:
@@ -76,9 +76,9 @@ class MemEffAttention(_PackedMixin, nn.Module):
         n_pad = ops.round_up(N, ops.BQ)
         H, dh = self.num_heads, self.head_dim
         Q = ops.alloc_heads(B, H, N, dh, HEADS_ROWS, dt, x.device, ops.BQ, "q")
-        K = ops.alloc_heads(B, H, N, dh, HEADS_ROWS, dt, x.device, ops.BQ, "k")
+        K = ops.alloc_heads(B, H, N, dh, HEADS_KROWS, dt, x.device, ops.BQ, "k")
         Vt = ops.alloc_heads(B, H, N, dh, HEADS_VT, dt, x.device, ops.BQ)
-        ops.linear_heads(a, w["w_qkv"], w["b_qkv"], N, H, dh, [HEADS_ROWS, HEADS_ROWS, HEADS_VT], [Q, K, Vt], n_pad)
+        ops.linear_heads(a, w["w_qkv"], w["b_qkv"], N, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT], [Q, K, Vt], n_pad)
         att = ops.attention(Q, K, Vt, N, N, dh, self.scale)
         out = ops.linear(att.view(B * N, Cc), w["w_proj"], w["b_proj"])
         return out.view(B, N, Cc)
@@ -130,10 +130,10 @@ class MemEffCrossAttention(_PackedMixin, nn.Module):
         w = self._packed(dt)
         H, dh = self.num_heads, self.head_dim
         Q = ops.alloc_heads(B, H, N, dh, HEADS_ROWS, dt, q.device, ops.BQ, "q")
-        K = ops.alloc_heads(B, H, M, dh, HEADS_ROWS, dt, q.device, ops.BKV, "k")
+        K = ops.alloc_heads(B, H, M, dh, HEADS_KROWS, dt, q.device, ops.BKV, "k")
         Vt = ops.alloc_heads(B, H, M, dh, HEADS_VT, dt, q.device, ops.BKV)
         ops.linear_heads(a, w["w_q"], w["b_q"], N, H, dh, [HEADS_ROWS], [Q], Q.shape[2], scale0=self.scale)
-        ops.linear_heads(c, w["w_kv"], w["b_kv"], M, H, dh, [HEADS_ROWS, HEADS_VT], [K, Vt], K.shape[2])
+        ops.linear_heads(c, w["w_kv"], w["b_kv"], M, H, dh, [HEADS_KROWS, HEADS_VT], [K, Vt], K.shape[2])
         att = ops.attention(Q, K, Vt, N, M, dh, self.scale)
         out = ops.linear(att.view(B * N, self.dim), w["w_proj"], w["b_proj"])
         return out.view(B, N, self.dim)

@@ -15,10 +15,13 @@
 // makes the 8 keys a lane owns in one 16-key MFMA step a contiguous 16-byte LDS read - P never
 // leaves registers and needs no permute.
 //
-// KV tiles of 64 keys go global -> registers -> LDS (double-buffered, clamped branch-free loads, predicated
-// stores, one barrier per tile).  K is staged ONE TILE AHEAD of V so that QK^T of tile j+1 (MFMA) is issued
-// before the softmax of tile j (VALU) and the two pipes overlap inside every wave.  LDS rows are padded so
-// that the 16-byte-slot stride is odd (K rows DP+8 halves, V^T rows 72 halves): ds_read_b128 conflict-free.
+// Staging is LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a 3-stage ring: no staging VGPRs, no
+// ds_write.  The GLOBAL layouts are designed for it: K rows are stored with the padded stride DP+8 halves
+// (PRIMX_HEADS_KROWS), so a 64-key K tile is one contiguous block whose lane-linear LDS image has the odd 16-byte-slot
+// row stride that makes ds_read_b128 conflict-free; V^T tiles (DP rows x 128 B) land in unpadded 128-byte LDS rows with
+// the chunk index XOR-swizzled by ((row>>1)&7), applied on the per-lane SOURCE address.  Stage j % 3 holds the PAIR
+// {K(j+1), V(j)}: K runs ONE TILE AHEAD of V so that QK^T of tile j+1 (MFMA) is issued before the softmax of tile j
+// (VALU) and the two pipes overlap inside every wave.  Sync per tile: s_waitcnt vmcnt(N) + one raw s_barrier.
 // Head dim 72 is zero-padded to DP = 80 for QK^T (5 k-steps) and to 96 output rows for PV (3 tiles):
 // 22 MFMAs per 64 keys x 32 queries = 0.72 MFLOP issued for 0.59 MFLOP algorithmic (81.8 %).  The padding is put
 // to work: column 72 of Q/K carries the key-padding mask and row 72 of V^T is all ones, so the MFMAs themselves
@@ -32,7 +35,7 @@ namespace {
 
 constexpr int BQ = 128;   // query rows per workgroup
 constexpr int BKV = 64;   // keys per tile
-constexpr int VROW = BKV + 8;
+constexpr int WAITCNT_LGKM0 = 0xC07F;   // s_waitcnt simm16 on gfx9: vmcnt = 63 (no wait), expcnt = 7 (no wait), lgkmcnt = 0
 
 template <typename V8>
 __device__ __forceinline__ V8 ldg16(const void* ptr) {
@@ -46,40 +49,37 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
                                                       const typename T16<DT>::S* __restrict__ Kp,
                                                       const typename T16<DT>::S* __restrict__ Vt,
                                                       typename T16<DT>::S* __restrict__ out, int H, int nq, int nq_pad,
-                                                      int nkv, int nkv_pad, int dh, float c /* scale * log2(e) */, int stagger) {
+                                                      int nkv, int nkv_pad, int dh, float c /* scale * log2(e) */) {
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
     using V4 = typename T16<DT>::V4;
+    typedef __attribute__((address_space(1))) const void GV;
+    typedef __attribute__((address_space(3))) void LV;
     constexpr int DP = 16 * KSTEPS;
-    constexpr int KROW = DP + 8;
+    constexpr int KROW = DP + 8;               // K row stride in halves - in GLOBAL memory and in LDS
     constexpr int VR = 32 * DTILES;            // V^T rows an MFMA A-operand can touch
-    constexpr int KT = BKV * KROW;             // halves in one K tile
-    constexpr int VT_ = VR * VROW;             // halves in one V^T tile
+    constexpr int KT = BKV * KROW;             // halves in one K tile: whole 1 KiB DMA instructions
+    constexpr int VT_ = VR * 64;               // halves in one V^T tile image (unpadded 128-byte rows)
     constexpr int BUF = KT + VT_;
-    constexpr int KCH = BKV * DP / 8, VCH = DP * 8;  // 16-byte chunks per tile
-    constexpr int KIT = (KCH + 255) / 256, VIT = (VCH + 255) / 256;
-    __shared__ __attribute__((aligned(16))) S smem[2 * BUF];
+    constexpr int NK = KT / 512;               // DMA wave-instructions per K tile   (11 / 9 / 5 for dh 72 / 64 / 32)
+    constexpr int NV = DP / 8;                 // per V^T tile, 8 rows each          (10 / 8 / 4)
+    constexpr int NSLOT = (NK > NV ? NK + 1 : NV + 1) / 2;   // DMAs per wave per pair (K pieces: 2 waves, V^T pieces: 2 waves)
+    static_assert(KT % 512 == 0, "K tile must be whole DMA instructions");
+    __shared__ __attribute__((aligned(16))) S smem[3 * BUF];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.x;  // (batch, head) fastest: with B*H % 8 == 0 all query tiles of a head share an XCD's L2
     const int q0 = blockIdx.y * BQ;
-    const S* Kbase = Kp + (int64_t)bh * nkv_pad * DP;
+    const S* Kbase = Kp + (int64_t)bh * nkv_pad * KROW;
     const S* Vbase = Vt + (int64_t)bh * DP * nkv_pad;
 
-    // Phase stagger: the two workgroups that share a CU start together and would stay phase-locked (both in
-    // their MFMA bursts, then both in their softmax VALU bursts - measured: per-tile time = MFMA + VALU of both
-    // waves).  Delaying every second "generation" of workgroups by ~half a tile period lets one wave's MFMAs
-    // overlap its SIMD partner's VALU work.
-    if (stagger > 0 && (((blockIdx.y * gridDim.x + blockIdx.x) >> 8) & 1)) {
-        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(8);  // 8 * 64 cycles per iteration
-    }
-
-    // zero the V^T rows >= DP (they only feed discarded output rows, but keep them finite)
+    // zero the V^T rows >= DP of every stage once (the DMA never writes them; they only feed discarded output rows)
     if (VR > DP) {
-        for (int i = tid; i < (VR - DP) * VROW; i += 256) {
-            smem[KT + DP * VROW + i] = (S)0.f;
-            smem[BUF + KT + DP * VROW + i] = (S)0.f;
+        for (int i = tid; i < (VR - DP) * 64; i += 256) {
+#pragma unroll
+            for (int stg = 0; stg < 3; ++stg) smem[stg * BUF + KT + DP * 64 + i] = (S)0.f;
         }
     }
 
@@ -91,49 +91,34 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
         for (int s = 0; s < KSTEPS; ++s) qf[s] = ldg16<V8>(qrow + s * 16);
     }
 
-    // ---- loader geometry (chunk ids past the tile are clamped for the load and skipped for the store)
-    int k_goff[KIT], k_loff[KIT], v_loff[VIT];
-    int64_t v_goff[VIT];
-    bool k_on[KIT], v_on[VIT];
-#pragma unroll
-    for (int i = 0; i < KIT; ++i) {
-        const int ch = tid + 256 * i;
-        k_on[i] = ch < KCH;
-        const int cc = k_on[i] ? ch : KCH - 1;
-        k_goff[i] = cc * 8;                                      // the K tile is one contiguous block
-        k_loff[i] = (cc / (DP / 8)) * KROW + (cc % (DP / 8)) * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < VIT; ++i) {
-        const int ch = tid + 256 * i;
-        v_on[i] = ch < VCH;
-        const int cc = v_on[i] ? ch : VCH - 1;
-        v_goff[i] = (int64_t)(cc >> 3) * nkv_pad + (cc & 7) * 8;
-        v_loff[i] = (cc >> 3) * VROW + (cc & 7) * 8;
-    }
+    // ---- DMA issue.  Piece t of a pair: t < NK -> 1 KiB piece t of the (contiguous) K tile; else V^T rows
+    // 8(t-NK) .. +7, lane (row = lane>>3, LDS chunk = lane&7) fetching the source chunk (lane&7) ^ ((row>>1)&7).  The
+    // LDS image of a pair is contiguous (K tile, then V^T rows), so piece t always lands at stage + t KiB.
+    // Roles are static: waves 0,1 copy the K pieces, waves 2,3 the V^T pieces, each a contiguous run; a wave whose run
+    // is shorter than NSLOT re-issues its last piece (same bytes, harmless) and tile indices past the end are clamped,
+    // so EVERY wave issues exactly NSLOT DMAs per pair with scalar-only address arithmetic - no branches, and the
+    // vmcnt bookkeeping is static: "vmcnt(NSLOT)" = everything older than the newest pair has landed.
     const int ntiles = (nkv + BKV - 1) / BKV;
-    auto load_k = [&](int j, V8 (&kr)[KIT]) {
-        const S* kt = Kbase + (int64_t)min(j, ntiles - 1) * BKV * DP;
+    const int is_v = wave >> 1, odd = wave & 1;                               // wave-uniform
+    const int run_first = is_v ? odd * ((NV + 1) / 2) : odd * ((NK + 1) / 2);
+    const int run_len = is_v ? (odd ? NV / 2 : (NV + 1) / 2) : (odd ? NK / 2 : (NK + 1) / 2);
+    const int64_t piece_stride = is_v ? (int64_t)8 * nkv_pad : 512;           // halves between consecutive pieces
+    const int tile_stride = is_v ? BKV : KT;
+    const S* role_base = is_v ? Vbase : Kbase;
+    const int v_lrow = lane >> 3, v_lc = lane & 7;
+    // per-lane source offset inside a piece; for V^T it depends on the parity of the 8-row group (swizzle term 4*tv & 7)
+    const int lane_off0 = is_v ? v_lrow * nkv_pad + ((v_lc ^ ((v_lrow >> 1) & 7)) * 8) : lane * 8;
+    const int lane_off1 = is_v ? v_lrow * nkv_pad + ((v_lc ^ ((4 + (v_lrow >> 1)) & 7)) * 8) : lane * 8;
+    auto issue_run = [&](int tile, int stage, int n) {   // this wave's pieces of K(tile) or V(tile)
+        const S* tb = role_base + (int64_t)min(tile, ntiles - 1) * tile_stride;
 #pragma unroll
-        for (int i = 0; i < KIT; ++i) kr[i] = ldg16<V8>(kt + k_goff[i]);
+        for (int i = 0; i < n; ++i) {
+            const int pc = run_first + min(i, run_len - 1);
+            const S* src = tb + pc * piece_stride + ((pc & 1) ? lane_off1 : lane_off0);
+            __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)src, (LV*)(smem + stage * BUF + (is_v * NK + pc) * 512), 16, 0, 0);
+        }
     };
-    auto load_v = [&](int j, V8 (&vr)[VIT]) {
-        const S* vt = Vbase + min(j, ntiles - 1) * BKV;
-#pragma unroll
-        for (int i = 0; i < VIT; ++i) vr[i] = ldg16<V8>(vt + v_goff[i]);
-    };
-    auto store_k = [&](int buf, V8 (&kr)[KIT]) {
-        S* kb = smem + buf * BUF;
-#pragma unroll
-        for (int i = 0; i < KIT; ++i)
-            if (k_on[i]) *reinterpret_cast<V8*>(kb + k_loff[i]) = kr[i];
-    };
-    auto store_v = [&](int buf, V8 (&vr)[VIT]) {
-        S* vb = smem + buf * BUF + KT;
-#pragma unroll
-        for (int i = 0; i < VIT; ++i)
-            if (v_on[i]) *reinterpret_cast<V8*>(vb + v_loff[i]) = vr[i];
-    };
+    auto issue_pair = [&](int jp, int stage) { issue_run(jp + 1 - is_v, stage, NSLOT); };   // {K(jp+1), V(jp)}
 
     f32x16 o[DTILES];
 #pragma unroll
@@ -157,16 +142,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
                 kf[kt][s] = (ABL == 5) ? qf[s] : *reinterpret_cast<const V8*>(kb + kt * 32 * KROW + s * 16);
     };
     auto read_v = [&](int buf, int half, V8 (&vf)[DTILES][2]) {   // key-steps 2*half, 2*half+1 of the tile
-        const S* vb = smem + buf * BUF + KT + l31 * VROW + hi * 8 + half * 32;
+        const S* vb = smem + buf * BUF + KT + l31 * 64;
+        const int sw = (l31 >> 1) & 7;                              // rows t*32 + l31: (row>>1)&7 does not depend on t
 #pragma unroll
         for (int t = 0; t < DTILES; ++t)
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
-                vf[t][k2] = (ABL == 5) ? qf[k2] : *reinterpret_cast<const V8*>(vb + t * 32 * VROW + k2 * 16);
+                vf[t][k2] = (ABL == 5) ? qf[k2]
+                                       : *reinterpret_cast<const V8*>(vb + t * 32 * 64 + (((4 * half + 2 * k2 + hi) ^ sw) * 8));
     };
     auto fence_lds = [&]() {  // every ds_read issued so far has landed; keep the compiler from moving MFMAs above it
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(WAITCNT_LGKM0);   // the builtin (not inline asm): hipcc's own waitcnt pass sees it and
+        __builtin_amdgcn_sched_barrier(0);           // does not add a second, stricter wait in front of the consumers
     };
     // S^T(tile t) = K(t) Q^T.  Keys >= nkv: when the head dim has a spare padded column (dh < DP, e.g. 72 -> 80) they
     // are masked BY THE OPERANDS (Q[:, dh] = 1, K[pad rows, dh] = -30000, see primx_hip.h) and no code is needed here;
@@ -190,18 +177,61 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
                 }
         }
     };
-    // ---- one pipeline step on buffer `buf` = {K(next), V(cur)}:
-    //   K-fragment reads -> [max / rare rescale of S(cur): VALU] -> wait -> QK^T MFMAs of the next tile
-    //   V-fragment reads -> [exponentials of S(cur): VALU]       -> wait -> PV MFMAs of the current tile
+    auto pv = [&](const V8 (&vf)[DTILES][2], const V8 (&pb)[2]) {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int t = 0; t < DTILES; ++t) {
+                if (ABL == 3) { asm volatile("" :: "v"(vf[t][k2]), "v"(pb[k2])); }
+                else o[t] = T16<DT>::mfma32(vf[t][k2], pb[k2], o[t]);
+            }
+    };
+    // probabilities of one 32-key half of the tile (two 16-key MFMA steps): packed-fp32 FMA, v_exp, 16-bit pack
+    auto probs = [&](const f32x16& sh, float mc, float& psum, V8 (&pb)[2]) {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2 sv = {sh[8 * k2 + e], sh[8 * k2 + e + 1]};
+                const f32x2 arg = __builtin_elementwise_fma(sv, (f32x2){c, c}, (f32x2){-mc, -mc});   // v_pk_fma_f32
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float pvv;
+                    if (ABL == 1) pvv = arg[u];
+                    else if (ABL == 2) pvv = sh[0];
+                    else pvv = __builtin_amdgcn_exp2f(arg[u]);
+                    if (KMASK) psum += pvv;   // !KMASK: the row sum comes out of the PV MFMA (V^T row dh is all ones)
+                    pb[k2][e + u] = (S)pvv;
+                }
+            }
+    };
+    // ---- one pipeline step on stage `buf` = {K(next), V(cur)}; dvf / dpb carry the second half of the previous
+    // tile's PV across the barrier:
+    //   K-fragment reads -> [deferred PV MFMAs of the previous tile + max / rare rescale of S(cur)] cover their latency
+    //   -> QK^T MFMAs of the next tile | V-fragment reads, exponentials of half 0 -> PV MFMAs of half 0 | V reads and
+    //   exponentials of half 1 -> (deferred to the next step's head)
+    V8 dvf[DTILES][2], dpb[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dpb[k2][e] = (S)0.f;
+#pragma unroll
+        for (int t = 0; t < DTILES; ++t) dvf[t][k2] = dpb[k2];
+    }
     auto step = [&](int buf, int t_next, const f32x16 (&sc)[2], f32x16 (&sn)[2]) {
         V8 kf[2][KSTEPS];
         read_k(buf, kf);
+        __builtin_amdgcn_sched_barrier(0);        // the reads go out first ...
+        pv(dvf, dpb);                             // ... and these MFMAs (plus the max below) run while they fly
         float mx = sc[0][0];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        {   // exchange with lane ^ 32: v_permlane32_swap, a VALU op (no LDS round trip behind the fragment reads)
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
         if (!__all(mx <= m_run)) {  // exact: when no row's max moves, alpha == 1 and the rescale is the identity
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
@@ -214,74 +244,63 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
         }
         fence_lds();
         qk(kf, t_next, sn);
-        // PV in two halves of two key-steps each (keeps the live V^T fragments + probabilities at 32 VGPRs)
         const float mc = m_run * c;
         float psum = 0.f;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            V8 vf[DTILES][2];
-            read_v(buf, half, vf);
-            V8 pb[2];
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float sv = sc[half][8 * k2 + e];
-                    float pv;
-                    if (ABL == 1) pv = sv * c - mc;
-                    else if (ABL == 2) pv = sc[half][0];
-                    else pv = __builtin_amdgcn_exp2f(sv * c - mc);
-                    if (KMASK) psum += pv;   // !KMASK: the row sum comes out of the PV MFMA (V^T row dh is all ones)
-                    pb[k2][e] = (S)pv;
-                }
+        {
+            V8 vf[DTILES][2], pb[2];
+            read_v(buf, 0, vf);
+            probs(sc[0], mc, psum, pb);
             fence_lds();
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-                for (int t = 0; t < DTILES; ++t) {
-                    if (ABL == 3) { asm volatile("" :: "v"(vf[t][k2]), "v"(pb[k2])); }
-                    else o[t] = T16<DT>::mfma32(vf[t][k2], pb[k2], o[t]);
-                }
+            pv(vf, pb);
         }
+        read_v(buf, 1, dvf);
+        probs(sc[1], mc, psum, dpb);
         if (KMASK) l_run += psum;
+        __builtin_amdgcn_sched_barrier(0);        // finish the VALU work BEFORE queueing at the barrier
     };
 
-    // ---- software pipeline.  LDS buffer b = j & 1 holds the PAIR {K(j+1), V(j)}: the QK^T MFMAs of tile j+1 sit in
-    // the same basic block as the exponentials and PV MFMAs of tile j, so the matrix pipe works while the VALU
-    // exponentiates; the scores are double-buffered in registers (sA / sB).  Tile indices past the end are clamped
-    // (the last QK^T is redundant) so the loop body has no data-dependent control flow besides the rescale.
-    V8 kr[KIT], vr[VIT];
+    // ---- ring.  Pair j lives in stage j % 3; the scores are double-buffered in registers (sA / sB).  Prologue: K(0)
+    // parks in stage 2's K area, pairs 0 and 1 are issued.  Step j: [pair j has landed for every wave and every wave is
+    // done reading stage (j-1) % 3] -> DMA pair j+2 into that stage -> compute on stage j % 3.
+#define PRIMX_ATTN_WAIT()                                                          \
+    do {                                                                           \
+        __builtin_amdgcn_s_waitcnt((NSLOT & 15) | 0x70 | ((NSLOT >> 4) << 14)); /* vmcnt(NSLOT) lgkmcnt(0) */ \
+        asm volatile("s_barrier" ::: "memory");                                    \
+    } while (0)
+    if (!is_v) issue_run(0, 2, NSLOT);     // K(0) parks in stage 2 (waves 2,3 would fetch V here: nothing to park)
+    issue_pair(0, 0);
+    issue_pair(1, 1);
     f32x16 sA[2], sB[2];
-    load_k(0, kr);
-    store_k(1, kr);                       // K(0) parks in buffer 1's K area for the prologue
-    load_k(1, kr);
-    load_v(0, vr);
-    __syncthreads();
+    PRIMX_ATTN_WAIT();                    // K(0) and pair 0 landed
     {
         V8 kf0[2][KSTEPS];
-        read_k(1, kf0);
+        read_k(2, kf0);
         fence_lds();
         qk(kf0, 0, sA);                   // S(0)
     }
-    store_k(0, kr);                       // pair 0 = {K(1), V(0)}
-    store_v(0, vr);
-    __syncthreads();
+    int st = 0, st_free = 2;              // stage of pair j / stage to refill (pair j-1's; K(0)'s parking at j = 0)
     int j = 0;
     for (; j + 1 < ntiles; j += 2) {
-        load_k(j + 2, kr);                // pair j+1 = {K(j+2), V(j+1)} -> buffer 1
-        load_v(j + 1, vr);
-        step(0, j + 1, sA, sB);           // softmax + PV of tile j, QK^T of tile j+1
-        store_k(1, kr);
-        store_v(1, vr);
-        __syncthreads();
-        load_k(j + 3, kr);                // pair j+2 = {K(j+3), V(j+2)} -> buffer 0
-        load_v(j + 2, vr);
-        step(1, min(j + 2, ntiles - 1), sB, sA);
-        store_k(0, kr);
-        store_v(0, vr);
-        __syncthreads();
+        PRIMX_ATTN_WAIT();
+        issue_pair(j + 2, st_free);
+        step(st, j + 1, sA, sB);          // softmax + PV of tile j, QK^T of tile j+1
+        st_free = st;
+        st = (st == 2) ? 0 : st + 1;
+        PRIMX_ATTN_WAIT();
+        issue_pair(j + 3, st_free);
+        step(st, min(j + 2, ntiles - 1), sB, sA);
+        st_free = st;
+        st = (st == 2) ? 0 : st + 1;
     }
-    if (j < ntiles) step(0, ntiles - 1, sA, sB);   // odd tile count: the last tile's V sits in buffer 0
+    if (j < ntiles) {                     // odd tile count
+        PRIMX_ATTN_WAIT();
+        issue_pair(j + 2, st_free);       // clamped and redundant: keeps the vmcnt bookkeeping uniform
+        step(st, ntiles - 1, sA, sB);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): also drains the clamped tail DMAs
+    __builtin_amdgcn_sched_barrier(0);
+    pv(dvf, dpb);                         // second half of the last tile
+#undef PRIMX_ATTN_WAIT
 
     // ---- epilogue: normalise and store out[b, q, h*dh + d]
     float l_tot;
@@ -291,8 +310,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
         // sum_k P[k, q] was accumulated by the PV MFMAs in output row d = dh (the all-ones row of V^T, primx_hip.h):
         // tile dh/32, register (rr&3) + 4*(rr>>3), half-wave (rr>>2)&1 with rr = dh % 32; rescaled together with O.
         const int rr = dh & 31;
-        const float mine = o[DTILES - 1][0] * 0.f;  // placeholder to keep types simple
-        float lsum = mine;
+        float lsum = 0.f;
 #pragma unroll
         for (int t = 0; t < DTILES; ++t)
 #pragma unroll
@@ -320,12 +338,6 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
     }
 }
 
-// PRIMX_ATTN_STAGGER=<n>: start-up delay (n * 512 cycles) of odd workgroup generations; default tuned on MI355X
-static const int g_attn_stagger = [] {
-    const char* e = getenv("PRIMX_ATTN_STAGGER");
-    return e ? atoi(e) : 0;
-}();
-
 static const int g_attn_abl = [] {
     const char* e = getenv("PRIMX_ATTN_ABL");
     return e ? atoi(e) : 0;
@@ -338,8 +350,8 @@ void launch_attn(const void* Qp, const void* Kp, const void* Vt, void* out, int 
     dim3 grid(B * H, nq_pad / BQ);
 #define PRIMX_ATTN_LAUNCH(A)                                                                                         \
     hipLaunchKernelGGL((attn_kernel<DT, KSTEPS, DTILES, KMASK, A>), grid, dim3(256), 0, st, (const S*)Qp, (const S*)Kp, \
-                       (const S*)Vt, (S*)out, H, nq, nq_pad, nkv, nkv_pad, dh, c, g_attn_stagger)
-    if (DT == PRIMX_F16 && KSTEPS == 5 && g_attn_abl != 0) {
+                       (const S*)Vt, (S*)out, H, nq, nq_pad, nkv, nkv_pad, dh, c)
+    if constexpr (DT == PRIMX_F16 && KSTEPS == 5) if (g_attn_abl != 0) {
         switch (g_attn_abl) {
             case 1: PRIMX_ATTN_LAUNCH(1); break;
             case 2: PRIMX_ATTN_LAUNCH(2); break;

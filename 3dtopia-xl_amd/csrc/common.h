@@ -108,6 +108,9 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
         }                                                                    \
     } while (0)
 
+// Row stride (elements) of the token-major head layouts: PRIMX_HEADS_ROWS = DP, PRIMX_HEADS_KROWS = DP + 8.
+__host__ __device__ __forceinline__ int heads_row_stride(int kind, int DP) { return kind == PRIMX_HEADS_KROWS ? DP + 8 : DP; }
+
 // Position of key k inside its group of 16 in the PRIMX_HEADS_VT layout: the 4-key quads are
 // stored in the order {0,2,1,3} so that the lane half (hi) of a 32x32x16 MFMA reads the 8 keys
 // its own accumulator registers hold as one contiguous 16-byte vector (see attention.hip).

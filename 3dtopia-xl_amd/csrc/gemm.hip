@@ -69,7 +69,7 @@ struct GemmArgs {
     int kind[3];
     S* dst[3];
     float scale0;
-    int64_t rep_stride;  // the n_seg column groups repeat; repetition r writes at dst[s] + r * rep_stride
+    int64_t rep_stride[3];  // the n_seg column groups repeat; repetition r writes at dst[s] + r * rep_stride[s]
     // EPI_RES: out = cast16((acc + bias + res) * out_scale); res may be null
     const S* res;
     // conv gather (GATHER) and EPI_CONVT geometry
@@ -187,9 +187,10 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs<DT>& p, const ColIn
         for (int j = 0; j < 4; ++j) v[j] = rnd16<DT>(a[j] + c.bias);
         S* dst = p.dst[0];
         int kind = p.kind[0];
-        if (c.seg == 1) { dst = p.dst[1]; kind = p.kind[1]; }
-        if (c.seg == 2) { dst = p.dst[2]; kind = p.kind[2]; }
-        dst += c.rep * p.rep_stride;
+        int64_t rstride = p.rep_stride[0];
+        if (c.seg == 1) { dst = p.dst[1]; kind = p.kind[1]; rstride = p.rep_stride[1]; }
+        if (c.seg == 2) { dst = p.dst[2]; kind = p.kind[2]; rstride = p.rep_stride[2]; }
+        dst += c.rep * rstride;
         if (c.seg == 0 && p.scale0 != 1.0f) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = rnd16<DT>(p.scale0 * v[j]);
@@ -210,7 +211,7 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs<DT>& p, const ColIn
                 if (m >= p.M) continue;
                 const int b = m / p.rows_per_batch, tok = m - b * p.rows_per_batch;
                 const int64_t head = (int64_t)b * p.heads + c.hh;
-                if (kind == PRIMX_HEADS_ROWS) dst[(head * p.n_pad + tok) * p.DP + c.dd] = (S)v[j];
+                if (kind != PRIMX_HEADS_VT) dst[(head * p.n_pad + tok) * heads_row_stride(kind, p.DP) + c.dd] = (S)v[j];
                 else dst[(head * p.DP + c.dd) * p.n_pad + vt_key_pos(tok)] = (S)v[j];
             }
         }
@@ -259,13 +260,15 @@ __device__ __forceinline__ void epilogue_row4(const GemmArgs<DT>& p, int m, int 
 #pragma unroll
         for (int j = 0; j < 4; ++j) xv[j] = xv[j] + rnd16<DT>((float)gv[j] * rnd16<DT>(a[j] + b[j]));
         *xp = xv;
-    } else if (EPI == EPI_HEADS) {  // PRIMX_HEADS_ROWS segments only (VT segments keep the quad form)
+    } else if (EPI == EPI_HEADS) {  // PRIMX_HEADS_ROWS / KROWS segments only (VT segments keep the quad form)
         const int per = p.heads * p.dh;
         const int seg_all = n / per;
         const int rep = seg_all / p.n_seg, seg = seg_all - rep * p.n_seg;
         const int w = n - seg_all * per;
         const int hh = w / p.dh, dd = w - hh * p.dh;
-        S* dst = (seg == 0 ? p.dst[0] : seg == 1 ? p.dst[1] : p.dst[2]) + rep * p.rep_stride;
+        S* dst = (seg == 0 ? p.dst[0] : seg == 1 ? p.dst[1] : p.dst[2]) +
+                 rep * (seg == 0 ? p.rep_stride[0] : seg == 1 ? p.rep_stride[1] : p.rep_stride[2]);
+        const int rs = heads_row_stride(seg == 0 ? p.kind[0] : seg == 1 ? p.kind[1] : p.kind[2], p.DP);
         const int bb = m / p.rows_per_batch, tok = m - bb * p.rows_per_batch;
         V4 o;
 #pragma unroll
@@ -274,7 +277,7 @@ __device__ __forceinline__ void epilogue_row4(const GemmArgs<DT>& p, int m, int 
             if (seg == 0 && p.scale0 != 1.0f) y = rnd16<DT>(p.scale0 * y);
             o[j] = (S)y;
         }
-        *reinterpret_cast<V4*>(dst + (((int64_t)bb * p.heads + hh) * p.n_pad + tok) * p.DP + dd) = o;
+        *reinterpret_cast<V4*>(dst + (((int64_t)bb * p.heads + hh) * p.n_pad + tok) * rs + dd) = o;
     }
 }
 
@@ -1002,7 +1005,7 @@ extern "C" int primx_linear_gate_residual(const void* A, const void* W, const vo
 
 extern "C" int primx_linear_heads(const void* A, const void* W, const void* bias, int M, int N, int K,
                                   int rows_per_batch, int heads, int dh, int n_seg, const int* kind, void* const* dst,
-                                  int n_rep, int64_t rep_stride, int n_pad, float scale0, int dtype, void* stream) {
+                                  int n_rep, int rep_batches, int n_pad, float scale0, int dtype, void* stream) {
     PRIMX_REQUIRE(kind && dst && n_seg >= 1 && n_seg <= 3 && n_rep >= 1, "primx_linear_heads: n_seg must be 1..3, n_rep >= 1");
     PRIMX_REQUIRE(heads > 0 && dh > 0 && N == n_rep * n_seg * heads * dh,
                   "primx_linear_heads: N must equal n_rep*n_seg*heads*dh");
@@ -1010,7 +1013,8 @@ extern "C" int primx_linear_heads(const void* A, const void* W, const void* bias
                   "primx_linear_heads: need M %% rows_per_batch == 0, n_pad >= rows_per_batch, n_pad %% 16 == 0");
     for (int s = 0; s < n_seg; ++s) {
         PRIMX_REQUIRE(dst[s] != nullptr, "primx_linear_heads: null destination");
-        PRIMX_REQUIRE(kind[s] == PRIMX_HEADS_ROWS || kind[s] == PRIMX_HEADS_VT, "primx_linear_heads: bad kind");
+        PRIMX_REQUIRE(kind[s] == PRIMX_HEADS_ROWS || kind[s] == PRIMX_HEADS_VT || kind[s] == PRIMX_HEADS_KROWS,
+                      "primx_linear_heads: bad kind");
     }
     PRIMX_DISPATCH_16(dtype, "primx_linear_heads", {
         using S = typename T16<DT>::S;
@@ -1018,9 +1022,11 @@ extern "C" int primx_linear_heads(const void* A, const void* W, const void* bias
         a.A = (const S*)A; a.W = (const S*)W; a.bias = (const S*)bias;
         a.M = M; a.N = N; a.K = K;
         a.rows_per_batch = rows_per_batch; a.heads = heads; a.dh = dh; a.DP = primx_padded_head_dim(dh);
-        a.n_pad = n_pad; a.n_seg = n_seg; a.scale0 = scale0; a.rep_stride = rep_stride;
+        a.n_pad = n_pad; a.n_seg = n_seg; a.scale0 = scale0;
         for (int s = 0; s < 3; ++s) {
             a.kind[s] = s < n_seg ? kind[s] : 0;
+            // one (batch, head) block holds n_pad * row-stride elements in the token-major layouts, DP * n_pad in VT
+            a.rep_stride[s] = (int64_t)rep_batches * heads * n_pad * (a.kind[s] == PRIMX_HEADS_VT ? a.DP : heads_row_stride(a.kind[s], a.DP));
             a.dst[s] = s < n_seg ? (S*)dst[s] : nullptr;
         }
         return launch<DT, EPI_HEADS>(a, (hipStream_t)stream, "primx_linear_heads");

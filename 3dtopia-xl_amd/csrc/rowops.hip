@@ -484,7 +484,7 @@ __global__ void pack_heads_kernel(const typename T16<DT>::S* __restrict__ src, i
         const int b = (int)(r / M);
         const auto v = src[b * sb + m * sm + h * sh + d];
         const int64_t head = (int64_t)b * H + h;
-        if (kind == PRIMX_HEADS_ROWS) dst[(head * m_pad + m) * DP + d] = v;
+        if (kind != PRIMX_HEADS_VT) dst[(head * m_pad + m) * heads_row_stride(kind, DP) + d] = v;
         else dst[(head * DP + d) * m_pad + vt_key_pos(m)] = v;
     }
 }
@@ -494,7 +494,7 @@ extern "C" int primx_pack_heads(const void* src, int64_t sb, int64_t sm, int64_t
     PRIMX_REQUIRE(src && dst, "primx_pack_heads: null pointer");
     PRIMX_REQUIRE(B > 0 && M > 0 && H > 0 && dh > 0 && m_pad >= M && m_pad % 16 == 0,
                   "primx_pack_heads: need m_pad >= M and m_pad %% 16 == 0");
-    PRIMX_REQUIRE(kind == PRIMX_HEADS_ROWS || kind == PRIMX_HEADS_VT, "primx_pack_heads: bad kind");
+    PRIMX_REQUIRE(kind == PRIMX_HEADS_ROWS || kind == PRIMX_HEADS_VT || kind == PRIMX_HEADS_KROWS, "primx_pack_heads: bad kind");
     const int DP = primx_padded_head_dim(dh);
     const int64_t total = (int64_t)B * M * H * dh;
     int blocks = (int)((total + 255) / 256);

@@ -29,7 +29,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._lib import ACT_GELU_TANH, HEADS_ROWS, HEADS_VT
+from ._lib import ACT_GELU_TANH, HEADS_KROWS, HEADS_ROWS, HEADS_VT
 from .attention import MemEffAttention, MemEffCrossAttention, _c16
 
 
@@ -242,15 +242,15 @@ class DiT(nn.Module):
         nq_pad = ops.round_up(N, ops.BQ)
         Qc = self._heads("Qc", Be, N, HEADS_ROWS, dt, dev, ops.BQ)
         # cross-attention K / V of every block in ONE projection GEMM (N = depth * 2D): [depth*Be, H, L_pad, DP]
-        Kc = self._heads("Kc", self.depth * Be, L, HEADS_ROWS, dt, dev, ops.BKV)
+        Kc = self._heads("Kc", self.depth * Be, L, HEADS_KROWS, dt, dev, ops.BKV)
         Vc = self._heads("Vc", self.depth * Be, L, HEADS_VT, dt, dev, ops.BKV)
         Kc_blk = Kc.view(self.depth, Be, *Kc.shape[1:])
         Vc_blk = Vc.view(self.depth, Be, *Vc.shape[1:])
         if self.depth:
-            ops.linear_heads(y16, pk["w_kv_all"], pk["b_kv_all"], L, H, dh, [HEADS_ROWS, HEADS_VT], [Kc, Vc],
-                             Kc.shape[2], n_rep=self.depth, rep_stride=Kc_blk[0].numel())
+            ops.linear_heads(y16, pk["w_kv_all"], pk["b_kv_all"], L, H, dh, [HEADS_KROWS, HEADS_VT], [Kc, Vc],
+                             Kc.shape[2], n_rep=self.depth, rep_batches=Be)
         Qs = self._heads("Qs", Be, N, HEADS_ROWS, dt, dev, ops.BQ)
-        Ks = self._heads("Ks", Be, N, HEADS_ROWS, dt, dev, ops.BQ)
+        Ks = self._heads("Ks", Be, N, HEADS_KROWS, dt, dev, ops.BQ)
         Vs = self._heads("Vs", Be, N, HEADS_VT, dt, dev, ops.BQ)
         xn = torch.empty(T, D, dtype=dt, device=dev)
         att = torch.empty(Be, N, D, dtype=dt, device=dev)
@@ -267,7 +267,7 @@ class DiT(nn.Module):
             ops.linear_gate_residual(att.view(T, D), w["w_cproj"], w["b_cproj"], ch[2], h, N)
             # ---- self-attention over the primitive tokens (dit_crossattn.py:56, attention.py:48-59)
             ops.layernorm_modulate(h, ch[3], ch[4], N, xn, self.LN_EPS)
-            ops.linear_heads(xn, w["w_qkv"], w["b_qkv"], N, H, dh, [HEADS_ROWS, HEADS_ROWS, HEADS_VT], [Qs, Ks, Vs],
+            ops.linear_heads(xn, w["w_qkv"], w["b_qkv"], N, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT], [Qs, Ks, Vs],
                              nq_pad)
             ops.attention(Qs, Ks, Vs, N, N, dh, scale, out=att)
             ops.linear_gate_residual(att.view(T, D), w["w_proj"], w["b_proj"], ch[5], h, N)

@@ -12,7 +12,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU_TANH, ACT_NONE, BF16, F16, F32, HEADS_ROWS, HEADS_VT, check
+from ._lib import ACT_GELU_TANH, ACT_NONE, BF16, F16, F32, HEADS_KROWS, HEADS_ROWS, HEADS_VT, check
 
 _DT = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}
 BQ, BKV = 128, 64  # attention query-tile / key-tile sizes (csrc/attention.hip)
@@ -172,8 +172,8 @@ def linear_gate_residual(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.
 
 def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], rows_per_batch: int, heads: int,
                  dh: int, kinds: Sequence[int], dsts: Sequence[torch.Tensor], n_pad: int,
-                 scale0: float = 1.0, n_rep: int = 1, rep_stride: int = 0) -> None:
-    """n_rep > 1: the column groups repeat; repetition r is written at dsts[s] + r * rep_stride elements."""
+                 scale0: float = 1.0, n_rep: int = 1, rep_batches: int = 0) -> None:
+    """n_rep > 1: the column groups repeat; repetition r fills batch entries [r*rep_batches, (r+1)*rep_batches) of dsts."""
     M, K = A.shape
     N = W.shape[0]
     n_seg = len(kinds)
@@ -181,7 +181,7 @@ def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     dst_arr = (C.c_void_p * n_seg)(*[_dev(d, "dst", A.dtype) for d in dsts])
     _timed(_gemm_tag(2, M, N, K, A.dtype), 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_heads(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None, M, N, K,
-        rows_per_batch, heads, dh, n_seg, kind_arr, dst_arr, n_rep, rep_stride, n_pad, scale0, dtype_code(A.dtype),
+        rows_per_batch, heads, dh, n_seg, kind_arr, dst_arr, n_rep, rep_batches, n_pad, scale0, dtype_code(A.dtype),
         _stream()),
         "primx_linear_heads"))
 
@@ -199,9 +199,9 @@ def alloc_heads(B: int, H: int, n: int, dh: int, kind: int, dtype: torch.dtype, 
     all-ones row dh (valid keys only) that makes the PV MFMA produce the softmax row sum (include/primx_hip.h)."""
     DP = padded_head_dim(dh)
     n_pad = round_up(n, pad_to)
-    shape = (B, H, n_pad, DP) if kind == HEADS_ROWS else (B, H, DP, n_pad)
+    shape = {HEADS_ROWS: (B, H, n_pad, DP), HEADS_KROWS: (B, H, n_pad, DP + 8), HEADS_VT: (B, H, DP, n_pad)}[kind]
     buf = torch.zeros(shape, dtype=dtype, device=device)
-    if kind == HEADS_ROWS and DP > dh:
+    if kind != HEADS_VT and DP > dh:
         if role == "q":
             buf[:, :, :, dh] = 1.0
         elif role == "k" and n_pad > n:
@@ -220,7 +220,7 @@ def attention(Qp: torch.Tensor, Kp: torch.Tensor, Vt: torch.Tensor, nq: int, nkv
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     B, H, nq_pad, DP = Qp.shape
     nkv_pad = Kp.shape[2]
-    if Vt.shape != (B, H, DP, nkv_pad) or Kp.shape != (B, H, nkv_pad, DP):
+    if Vt.shape != (B, H, DP, nkv_pad) or Kp.shape != (B, H, nkv_pad, DP + 8):
         raise RuntimeError("attention: operand layout mismatch")
     if out is None:
         out = torch.empty(B, nq, H * dh, dtype=Qp.dtype, device=Qp.device)
@@ -238,7 +238,7 @@ def pack_heads(src: torch.Tensor, kind: int, pad_to: int, role: Optional[str] = 
     if src.stride(3) != 1 or not src.is_cuda:
         raise RuntimeError("pack_heads: last dim must be contiguous on a HIP device")
     dst = alloc_heads(B, H, M, dh, kind, src.dtype, src.device, pad_to, role)
-    m_pad = dst.shape[2] if kind == HEADS_ROWS else dst.shape[3]
+    m_pad = dst.shape[3] if kind == HEADS_VT else dst.shape[2]
     check(_lib.load().primx_pack_heads(src.data_ptr(), src.stride(0), src.stride(1), src.stride(2), dst.data_ptr(),
                                        kind, B, M, H, dh, m_pad, dtype_code(src.dtype), _stream()), "primx_pack_heads")
     return dst
@@ -253,7 +253,7 @@ def memory_efficient_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor
     B, Mq, H, dh = q.shape
     Mk = k.shape[1]
     Qp = pack_heads(q, HEADS_ROWS, BQ, "q")
-    Kp = pack_heads(k, HEADS_ROWS, BKV, "k")
+    Kp = pack_heads(k, HEADS_KROWS, BKV, "k")
     Vt = pack_heads(v, HEADS_VT, BKV)
     out = attention(Qp, Kp, Vt, Mq, Mk, dh, dh ** -0.5 if scale is None else scale)
     return out.view(B, Mq, H, dh)

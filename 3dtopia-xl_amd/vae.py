@@ -24,7 +24,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._lib import HEADS_ROWS, HEADS_VT
+from ._lib import HEADS_KROWS, HEADS_ROWS, HEADS_VT
 from .attention import MemEffAttention
 
 
@@ -247,9 +247,9 @@ class VAE(nn.Module):
         dh = Cc // H
         t = ops.groupnorm_silu(h, w["g"], w["b"], w["groups"], w["eps"], False)
         Q = ops.alloc_heads(P, H, V, dh, HEADS_ROWS, h.dtype, h.device, ops.BQ, "q")
-        K = ops.alloc_heads(P, H, V, dh, HEADS_ROWS, h.dtype, h.device, ops.BQ, "k")
+        K = ops.alloc_heads(P, H, V, dh, HEADS_KROWS, h.dtype, h.device, ops.BQ, "k")
         Vt = ops.alloc_heads(P, H, V, dh, HEADS_VT, h.dtype, h.device, ops.BQ)
-        ops.linear_heads(t.view(P * V, Cc), w["w_qkv"], w["b_qkv"], V, H, dh, [HEADS_ROWS, HEADS_ROWS, HEADS_VT],
+        ops.linear_heads(t.view(P * V, Cc), w["w_qkv"], w["b_qkv"], V, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT],
                          [Q, K, Vt], Q.shape[2])
         att = ops.attention(Q, K, Vt, V, V, dh, dh ** -0.5)
         if w["residual"]:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 7
+#define PRIMX_ABI_VERSION 8
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -47,6 +47,8 @@ extern "C" {
 /* head-layout kinds for primx_linear_heads / primx_pack_heads */
 #define PRIMX_HEADS_ROWS 0 /* [B, H, n_pad, DP]  token-major rows, head dim zero-padded to DP   */
 #define PRIMX_HEADS_VT 1   /* [B, H, DP, n_pad]  transposed, keys permuted inside 16-groups     */
+#define PRIMX_HEADS_KROWS 2 /* [B, H, n_pad, DP+8] rows with the padded stride of the attention kernel's LDS image: a
+                             * 64-key tile is ONE contiguous block that LDS-DMA copies verbatim (K operand only)  */
 
 int primx_abi_version(void);
 const char* primx_last_error(void);
@@ -110,7 +112,7 @@ int primx_linear_gate_residual(const void* A, const void* W, const void* bias, c
 
 /* Projection whose output columns are `n_rep` repetitions of `n_seg` groups of (heads * dh) features
  * (N = n_rep * n_seg * heads * dh), each group written straight into an attention operand layout (see
- * PRIMX_HEADS_*): group s of repetition r goes to dst[s] + r * rep_stride (elements) with kind[s]; rows of
+ * PRIMX_HEADS_*): group s of repetition r goes to batch entries [r * rep_batches, (r+1) * rep_batches) of dst[s] with kind[s]; rows of
  * batch b (= m / rows_per_batch) go to [b, h, m % rows_per_batch, :].  Group 0 is multiplied by `scale0`
  * (after rounding) - the cross-attention `self.scale * to_q(q)` (attention.py:105).  Pad rows/cols of the
  * destinations are never written (callers zero them once).  n_rep > 1 batches the SAME projection of several
@@ -119,14 +121,14 @@ int primx_linear_gate_residual(const void* A, const void* W, const void* bias, c
  * (attention.py:105-107). */
 int primx_linear_heads(const void* A, const void* W, const void* bias, int M, int N, int K, int rows_per_batch,
                        int heads, int dh, int n_seg, const int* kind, void* const* dst, int n_rep,
-                       int64_t rep_stride, int n_pad, float scale0, int dtype, void* stream);
+                       int rep_batches, int n_pad, float scale0, int dtype, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Attention (flash-style, fp32 online softmax, MFMA 32x32x16)
  * -------------------------------------------------------------------------------------------- */
 
 /* out[b, q, h*dh + d] = sum_k softmax_k( scale * <Q[b,h,q,:], K[b,h,k,:]> ) V[b,h,k,d]
- * Qp: [B, H, nq_pad, DP] rows layout (nq_pad % 128 == 0); Kp: [B, H, nkv_pad, DP] rows layout;
+ * Qp: [B, H, nq_pad, DP] ROWS layout (nq_pad % 128 == 0); Kp: [B, H, nkv_pad, DP+8] KROWS layout;
  * Vt: [B, H, DP, nkv_pad] VT layout (nkv_pad % 64 == 0).  out: [B, nq, H*dh] 16-bit.  dh in {32, 64, 72}.
  * Keys >= nkv are masked.  For dh == DP (32, 64) the kernel overwrites their scores; for dh < DP (72 -> 80)
  * the mask is carried BY THE OPERANDS, which the caller prepares once (the pads are never written by any

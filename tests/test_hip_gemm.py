@@ -74,21 +74,42 @@ def test_linear_gate_residual(ops, dtype):
     assert max_abs(xd, want) < 5e-2
 
 
+@pytest.mark.parametrize("B,n,H,dh,K,n_rep", [(2, 70, 4, 72, 64, 3), (1, 1370, 16, 72, 768, 2)])
+def test_linear_heads_repeated(ops, B, n, H, dh, K, n_rep):
+    """to_k / to_v of several blocks batched in one GEMM (N = n_rep * 2 * D): repetition r fills batch entries
+    [r*B, (r+1)*B) of the K (padded row stride) and V^T destinations."""
+    from topia_xl_amd._lib import HEADS_KROWS, HEADS_VT
+    dtype = torch.float16
+    D = H * dh
+    A, W, b, ref = _mk(15, B * n, n_rep * 2 * D, K, dtype)
+    kv = ref.to(dtype).view(B, n, n_rep, 2, H, dh)
+    Kb = ops.alloc_heads(n_rep * B, H, n, dh, HEADS_KROWS, dtype, DEV, 64, "k")
+    Vt = ops.alloc_heads(n_rep * B, H, n, dh, HEADS_VT, dtype, DEV, 64)
+    ops.linear_heads(A.to(DEV), W.to(DEV), b.to(DEV), n, H, dh, [HEADS_KROWS, HEADS_VT], [Kb, Vt], Kb.shape[2],
+                     n_rep=n_rep, rep_batches=B)
+    for r in range(n_rep):
+        assert rel_l2(unpack_rows(Kb[r * B:(r + 1) * B], n, dh), kv[:, :, r, 0]) < 2 * TOL[dtype]
+        assert rel_l2(unpack_vt(Vt[r * B:(r + 1) * B], n, dh), kv[:, :, r, 1]) < 2 * TOL[dtype]
+    # operand-level mask / denominator markers survive the projection (include/primx_hip.h)
+    assert torch.all(Kb[:, :, n:, dh] == ops.KEY_MASK_VALUE) and torch.all(Kb[:, :, :n, dh] == 0)
+    assert float(Vt[:, :, dh].float().sum()) == n_rep * B * H * n
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("B,n,H,dh,K", [(2, 256, 16, 72, 1152), (3, 70, 4, 72, 64), (1, 1370, 16, 72, 768),
                                        (2, 64, 8, 32, 256), (1, 1, 6, 64, 128)])
 def test_linear_heads_layouts(ops, dtype, B, n, H, dh, K):
     """qkv projection written straight into the attention layouts == Linear + reshape + unbind."""
-    from topia_xl_amd._lib import HEADS_ROWS, HEADS_VT
+    from topia_xl_amd._lib import HEADS_KROWS, HEADS_ROWS, HEADS_VT
     D = H * dh
     A, W, b, ref = _mk(14, B * n, 3 * D, K, dtype)
     scale0 = dh ** -0.5
     r = lambda t: t.to(dtype)
     qkv = r(ref).view(B, n, 3, H, dh)
     Q = ops.alloc_heads(B, H, n, dh, HEADS_ROWS, dtype, DEV, 128)
-    Kb = ops.alloc_heads(B, H, n, dh, HEADS_ROWS, dtype, DEV, 128)
+    Kb = ops.alloc_heads(B, H, n, dh, HEADS_KROWS, dtype, DEV, 128)   # padded row stride DP + 8
     Vt = ops.alloc_heads(B, H, n, dh, HEADS_VT, dtype, DEV, 128)
-    ops.linear_heads(A.to(DEV), W.to(DEV), b.to(DEV), n, H, dh, [HEADS_ROWS, HEADS_ROWS, HEADS_VT], [Q, Kb, Vt],
+    ops.linear_heads(A.to(DEV), W.to(DEV), b.to(DEV), n, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT], [Q, Kb, Vt],
                      Q.shape[2], scale0=scale0)
     tol = 2 * TOL[dtype]
     assert rel_l2(unpack_rows(Q, n, dh), r(scale0 * qkv[:, :, 0].float())) < tol

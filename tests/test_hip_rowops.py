@@ -118,15 +118,16 @@ def test_ancestral_step(ops):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_pack_heads_layouts(ops, dtype):
-    from topia_xl_amd._lib import HEADS_ROWS, HEADS_VT
+    from topia_xl_amd._lib import HEADS_KROWS, HEADS_ROWS, HEADS_VT
     B, M, H, dh = 2, 70, 3, 72
     qkv = synth.tensor(7, "qkv", (B, M, 3, H, dh)).to(dtype).to(DEV)
-    for which, kind in ((0, HEADS_ROWS), (2, HEADS_VT)):
+    for which, kind in ((0, HEADS_ROWS), (1, HEADS_KROWS), (2, HEADS_VT)):
         src = qkv[:, :, which]                       # strided BMHK view like the reference's unbind()
         buf = ops.pack_heads(src, kind, 64)
-        back = unpack_rows(buf, M, dh) if kind == HEADS_ROWS else unpack_vt(buf, M, dh)
+        back = unpack_vt(buf, M, dh) if kind == HEADS_VT else unpack_rows(buf, M, dh)
         assert torch.equal(back, src)
-        data = buf[:, :, :, :dh] if kind == HEADS_ROWS else buf[:, :, :dh, :]
+        data = buf[:, :, :dh, :] if kind == HEADS_VT else buf[:, :, :, :dh]
+        assert buf.shape[-1] == {HEADS_ROWS: 80, HEADS_KROWS: 88, HEADS_VT: 128}[kind]
         assert float(data.float().abs().sum()) == pytest.approx(float(src.float().abs().sum()), rel=1e-3)  # pads stay 0
         if kind == HEADS_VT:   # spare rows: row dh = ones at the valid keys (softmax denominator row), the rest zero
             assert float(buf[:, :, dh].float().sum()) == B * H * M and float(buf[:, :, dh + 1:].float().abs().sum()) == 0.0

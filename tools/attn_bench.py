@@ -5,7 +5,7 @@ import torch
 import __graft_entry__
 __graft_entry__.build()
 from topia_xl_amd import ops
-from topia_xl_amd._lib import HEADS_ROWS, HEADS_VT
+from topia_xl_amd._lib import HEADS_KROWS, HEADS_ROWS, HEADS_VT
 
 dev, dt, reps = "cuda:0", torch.float16, int(os.environ.get("REPS", "20"))
 for name, B, H, nq, nkv, dh in [("self_b1", 2, 16, 2048, 2048, 72), ("cross_b1", 2, 16, 2048, 1370, 72),
@@ -13,7 +13,7 @@ for name, B, H, nq, nkv, dh in [("self_b1", 2, 16, 2048, 2048, 72), ("cross_b1",
     q = torch.randn(B, nq, H, dh, device=dev).to(dt)
     k = torch.randn(B, nkv, H, dh, device=dev).to(dt)
     v = torch.randn(B, nkv, H, dh, device=dev).to(dt)
-    Q, K, Vt = ops.pack_heads(q, HEADS_ROWS, 128, "q"), ops.pack_heads(k, HEADS_ROWS, 64, "k"), ops.pack_heads(v, HEADS_VT, 64)
+    Q, K, Vt = ops.pack_heads(q, HEADS_ROWS, 128, "q"), ops.pack_heads(k, HEADS_KROWS, 64, "k"), ops.pack_heads(v, HEADS_VT, 64)
     out = torch.empty(B, nq, H * dh, device=dev, dtype=dt)
     for _ in range(3):
         ops.attention(Q, K, Vt, nq, nkv, dh, dh ** -0.5, out=out)

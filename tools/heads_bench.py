@@ -5,7 +5,7 @@ import torch
 import __graft_entry__
 __graft_entry__.build()
 from topia_xl_amd import ops
-from topia_xl_amd._lib import HEADS_ROWS, HEADS_VT
+from topia_xl_amd._lib import HEADS_KROWS, HEADS_ROWS, HEADS_VT
 dev, dt, H, dh = "cuda:0", torch.float16, 16, 72
 def run(name, M, rpb, K, kinds, n_rep):
     N = n_rep * len(kinds) * H * dh
@@ -13,8 +13,7 @@ def run(name, M, rpb, K, kinds, n_rep):
     B = M // rpb
     dsts = [ops.alloc_heads(n_rep * B, H, rpb, dh, k, dt, dev, 128) for k in kinds]
     n_pad = dsts[0].shape[2]
-    stride = dsts[0].numel() // n_rep
-    f = lambda: ops.linear_heads(A, W, b, rpb, H, dh, kinds, dsts, n_pad, n_rep=n_rep, rep_stride=stride)
+    f = lambda: ops.linear_heads(A, W, b, rpb, H, dh, kinds, dsts, n_pad, n_rep=n_rep, rep_batches=B)
     for _ in range(3): f()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -23,7 +22,7 @@ def run(name, M, rpb, K, kinds, n_rep):
     e.record(); torch.cuda.synchronize()
     us = s.elapsed_time(e) * 1e3 / 20
     print(f"{name:8s} M={M} N={N} K={K}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TFLOP/s", flush=True)
-run("qkv", 4096, 2048, 1152, [HEADS_ROWS, HEADS_ROWS, HEADS_VT], 1)
+run("qkv", 4096, 2048, 1152, [HEADS_ROWS, HEADS_KROWS, HEADS_VT], 1)
 run("to_q", 4096, 2048, 1152, [HEADS_ROWS], 1)
-run("kv_all", 2740, 1370, 768, [HEADS_ROWS, HEADS_VT], 28)
+run("kv_all", 2740, 1370, 768, [HEADS_KROWS, HEADS_VT], 28)
 run("k_only", 2740, 1370, 768, [HEADS_ROWS], 28)
