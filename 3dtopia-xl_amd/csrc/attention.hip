@@ -27,13 +27,26 @@
 // to work: column 72 of Q/K carries the key-padding mask and row 72 of V^T is all ones, so the MFMAs themselves
 // deliver masked scores and the softmax denominator - the kernel is issue-bound on softmax VALU at this head dim
 // (~230 non-MFMA instructions per 22 MFMAs per tile; profiles/r1_attn_pmc.txt), every removed instruction counts.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
 
 namespace {
 
-constexpr int BQ = 128;   // query rows per workgroup
+constexpr int QPAD = 128; // granularity of nq_pad (the Q operand buffers)
+#ifndef PRIMX_ATTN_NW
+#define PRIMX_ATTN_NW 8
+#endif
+#ifndef PRIMX_ATTN_NSTAGE
+#define PRIMX_ATTN_NSTAGE 3
+#endif
+#ifndef PRIMX_ATTN_SPREAD
+#define PRIMX_ATTN_SPREAD 1
+#endif
+constexpr int NW = PRIMX_ATTN_NW;          // waves per workgroup: all of them share every K / V^T tile the workgroup stages
+constexpr int BQ = 32 * NW;                // query rows per workgroup
+constexpr int NSTAGE = PRIMX_ATTN_NSTAGE;  // LDS ring depth
 constexpr int BKV = 64;   // keys per tile
 constexpr int WAITCNT_LGKM0 = 0xC07F;   // s_waitcnt simm16 on gfx9: vmcnt = 63 (no wait), expcnt = 7 (no wait), lgkmcnt = 0
 
@@ -43,9 +56,12 @@ __device__ __forceinline__ V8 ldg16(const void* ptr) {
     return *reinterpret_cast<GV8*>(reinterpret_cast<uintptr_t>(ptr));
 }
 
-// ABL != 0: measurement-only ablations (PRIMX_ATTN_ABL), results are wrong by design
+// ABL == 8: phase profile - s_memtime stamps at the three sync points of a step, summed per wave into g_attn_prof
+__device__ unsigned long long g_attn_prof[8];
+
+// ABL != 0: measurement-only ablations (PRIMX_ATTN_ABL), results are wrong by design (8: right, but instrumented)
 template <int DT, int KSTEPS, int DTILES, int KMASK, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S* __restrict__ Qp,
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_kernel(const typename T16<DT>::S* __restrict__ Qp,
                                                       const typename T16<DT>::S* __restrict__ Kp,
                                                       const typename T16<DT>::S* __restrict__ Vt,
                                                       typename T16<DT>::S* __restrict__ out, int H, int nq, int nq_pad,
@@ -63,9 +79,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
     constexpr int BUF = KT + VT_;
     constexpr int NK = KT / 512;               // DMA wave-instructions per K tile   (11 / 9 / 5 for dh 72 / 64 / 32)
     constexpr int NV = DP / 8;                 // per V^T tile, 8 rows each          (10 / 8 / 4)
-    constexpr int NSLOT = (NK > NV ? NK + 1 : NV + 1) / 2;   // DMAs per wave per pair (K pieces: 2 waves, V^T pieces: 2 waves)
+    constexpr int HW = NW / 2;                 // waves per DMA role (K pieces: waves 0..HW-1, V^T pieces: the rest)
+    constexpr int NSLOT = ((NK > NV ? NK : NV) + HW - 1) / HW;   // DMAs per wave per pair
     static_assert(KT % 512 == 0, "K tile must be whole DMA instructions");
-    __shared__ __attribute__((aligned(16))) S smem[3 * BUF];
+    __shared__ __attribute__((aligned(16))) S smem[NSTAGE * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,16 +94,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
 
     // zero the V^T rows >= DP of every stage once (the DMA never writes them; they only feed discarded output rows)
     if (VR > DP) {
-        for (int i = tid; i < (VR - DP) * 64; i += 256) {
+        for (int i = tid; i < (VR - DP) * 64; i += 64 * NW) {
 #pragma unroll
-            for (int stg = 0; stg < 3; ++stg) smem[stg * BUF + KT + DP * 64 + i] = (S)0.f;
+            for (int stg = 0; stg < NSTAGE; ++stg) smem[stg * BUF + KT + DP * 64 + i] = (S)0.f;
         }
     }
 
     // Q^T B-operand fragments: lane (q = l31, hi) holds d = 16 s + 8 hi .. +7
     V8 qf[KSTEPS];
     {
-        const S* qrow = Qp + ((int64_t)bh * nq_pad + q0 + wave * 32 + l31) * DP + hi * 8;
+        const S* qrow = Qp + ((int64_t)bh * nq_pad + min(q0 + wave * 32 + l31, nq_pad - 1)) * DP + hi * 8;  // (waves past nq_pad idle along)
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) qf[s] = ldg16<V8>(qrow + s * 16);
     }
@@ -99,9 +116,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
     // so EVERY wave issues exactly NSLOT DMAs per pair with scalar-only address arithmetic - no branches, and the
     // vmcnt bookkeeping is static: "vmcnt(NSLOT)" = everything older than the newest pair has landed.
     const int ntiles = (nkv + BKV - 1) / BKV;
-    const int is_v = wave >> 1, odd = wave & 1;                               // wave-uniform
-    const int run_first = is_v ? odd * ((NV + 1) / 2) : odd * ((NK + 1) / 2);
-    const int run_len = is_v ? (odd ? NV / 2 : (NV + 1) / 2) : (odd ? NK / 2 : (NK + 1) / 2);
+    const int is_v = wave / HW, rw = wave % HW;                               // wave-uniform
+    const int n_pc = is_v ? NV : NK, per = (n_pc + HW - 1) / HW;
+    const int run_first = min(rw * per, n_pc - 1);
+    const int run_len = max(min(per, n_pc - rw * per), 1);
     const int64_t piece_stride = is_v ? (int64_t)8 * nkv_pad : 512;           // halves between consecutive pieces
     const int tile_stride = is_v ? BKV : KT;
     const S* role_base = is_v ? Vbase : Kbase;
@@ -109,16 +127,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
     // per-lane source offset inside a piece; for V^T it depends on the parity of the 8-row group (swizzle term 4*tv & 7)
     const int lane_off0 = is_v ? v_lrow * nkv_pad + ((v_lc ^ ((v_lrow >> 1) & 7)) * 8) : lane * 8;
     const int lane_off1 = is_v ? v_lrow * nkv_pad + ((v_lc ^ ((4 + (v_lrow >> 1)) & 7)) * 8) : lane * 8;
-    auto issue_run = [&](int tile, int stage, int n) {   // this wave's pieces of K(tile) or V(tile)
+    auto issue_run = [&](int tile, int stage, int i0, int i1) {   // slots [i0, i1) of this wave's pieces of K(tile) / V(tile)
         const S* tb = role_base + (int64_t)min(tile, ntiles - 1) * tile_stride;
 #pragma unroll
-        for (int i = 0; i < n; ++i) {
+        for (int i = i0; i < (ABL == 7 ? 0 : i1); ++i) {
             const int pc = run_first + min(i, run_len - 1);
             const S* src = tb + pc * piece_stride + ((pc & 1) ? lane_off1 : lane_off0);
             __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)src, (LV*)(smem + stage * BUF + (is_v * NK + pc) * 512), 16, 0, 0);
         }
     };
-    auto issue_pair = [&](int jp, int stage) { issue_run(jp + 1 - is_v, stage, NSLOT); };   // {K(jp+1), V(jp)}
+    // {K(jp+1), V(jp)}, third `part` of the wave's slots: the VMEM path accepts LDS-DMA slowly (6 back-to-back issues
+    // stalled a wave for ~1500 cycles with two workgroups per CU), so a step issues them in three spaced groups
+    auto issue_pair = [&](int jp, int stage, int part) {
+        if (PRIMX_ATTN_SPREAD) issue_run(jp + 1 - is_v, stage, part * NSLOT / 3, (part + 1) * NSLOT / 3);
+        else if (part == 0) issue_run(jp + 1 - is_v, stage, 0, NSLOT);
+    };
 
     f32x16 o[DTILES];
 #pragma unroll
@@ -218,9 +241,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
 #pragma unroll
         for (int t = 0; t < DTILES; ++t) dvf[t][k2] = dpb[k2];
     }
-    auto step = [&](int buf, int t_next, const f32x16 (&sc)[2], f32x16 (&sn)[2]) {
+    unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0, pa = 0, pb_ = 0, pc = 0, pd = 0, pn = 0, ptw = 0, pw = 0, pta = 0, ptb = 0, pe = 0, pf = 0;
+    auto step = [&](int buf, int t_next, const f32x16 (&sc)[2], f32x16 (&sn)[2], int jp, int st_refill) {
+        if (ABL == 8) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            if (pn) { pa += pt1 - pt0; pb_ += pt2 - pt1; pc += pt3 - pt2; pd += now - pt3; pw += ptw - pt3; pe += pta - pt0; pf += ptb - pta; }
+            ++pn;
+            pt0 = now;
+        }
         V8 kf[2][KSTEPS];
         read_k(buf, kf);
+        issue_pair(jp, st_refill, 0);
+        if (ABL == 8) pta = __builtin_readcyclecounter();
         __builtin_amdgcn_sched_barrier(0);        // the reads go out first ...
         pv(dvf, dpb);                             // ... and these MFMAs (plus the max below) run while they fly
         float mx = sc[0][0];
@@ -242,7 +274,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
         }
+        if (ABL == 8) { __builtin_amdgcn_sched_barrier(0); ptb = __builtin_readcyclecounter(); }
         fence_lds();
+        if (ABL == 8) pt1 = __builtin_readcyclecounter();
+        issue_pair(jp, st_refill, 1);
         qk(kf, t_next, sn);
         const float mc = m_run * c;
         float psum = 0.f;
@@ -251,12 +286,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
             read_v(buf, 0, vf);
             probs(sc[0], mc, psum, pb);
             fence_lds();
+            if (ABL == 8) pt2 = __builtin_readcyclecounter();
+            issue_pair(jp, st_refill, 2);
             pv(vf, pb);
         }
         read_v(buf, 1, dvf);
         probs(sc[1], mc, psum, dpb);
         if (KMASK) l_run += psum;
         __builtin_amdgcn_sched_barrier(0);        // finish the VALU work BEFORE queueing at the barrier
+        if (ABL == 8) pt3 = __builtin_readcyclecounter();
     };
 
     // ---- ring.  Pair j lives in stage j % 3; the scores are double-buffered in registers (sA / sB).  Prologue: K(0)
@@ -264,43 +302,47 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
     // done reading stage (j-1) % 3] -> DMA pair j+2 into that stage -> compute on stage j % 3.
 #define PRIMX_ATTN_WAIT()                                                          \
     do {                                                                           \
-        __builtin_amdgcn_s_waitcnt((NSLOT & 15) | 0x70 | ((NSLOT >> 4) << 14)); /* vmcnt(NSLOT) lgkmcnt(0) */ \
-        asm volatile("s_barrier" ::: "memory");                                    \
+        __builtin_amdgcn_s_waitcnt((NFLY & 15) | 0x70 | ((NFLY >> 4) << 14)); /* vmcnt(NFLY) lgkmcnt(0) */ \
+        if (ABL != 6) asm volatile("s_barrier" ::: "memory");                      \
     } while (0)
-    if (!is_v) issue_run(0, 2, NSLOT);     // K(0) parks in stage 2 (waves 2,3 would fetch V here: nothing to park)
-    issue_pair(0, 0);
-    issue_pair(1, 1);
+    constexpr int NFLY = NSLOT * (NSTAGE - 2);   // DMAs of the pairs newer than the one a step consumes
+    if (!is_v) issue_run(0, NSTAGE - 1, 0, NSLOT);     // K(0) parks in the last stage (V^T waves: nothing to park)
+#pragma unroll
+    for (int pr = 0; pr < NSTAGE - 1; ++pr) issue_run(pr + 1 - is_v, pr, 0, NSLOT);
     f32x16 sA[2], sB[2];
     PRIMX_ATTN_WAIT();                    // K(0) and pair 0 landed
     {
         V8 kf0[2][KSTEPS];
-        read_k(2, kf0);
+        read_k(NSTAGE - 1, kf0);
         fence_lds();
         qk(kf0, 0, sA);                   // S(0)
     }
-    int st = 0, st_free = 2;              // stage of pair j / stage to refill (pair j-1's; K(0)'s parking at j = 0)
+    int st = 0, st_free = NSTAGE - 1;     // stage of pair j / stage to refill (pair j-1's; K(0)'s parking at j = 0)
     int j = 0;
     for (; j + 1 < ntiles; j += 2) {
         PRIMX_ATTN_WAIT();
-        issue_pair(j + 2, st_free);
-        step(st, j + 1, sA, sB);          // softmax + PV of tile j, QK^T of tile j+1
+        if (ABL == 8) ptw = __builtin_readcyclecounter();
+        step(st, j + 1, sA, sB, j + NSTAGE - 1, st_free);          // softmax + PV of tile j, QK^T of tile j+1; DMA of pair j+2
         st_free = st;
-        st = (st == 2) ? 0 : st + 1;
+        st = (st == NSTAGE - 1) ? 0 : st + 1;
         PRIMX_ATTN_WAIT();
-        issue_pair(j + 3, st_free);
-        step(st, min(j + 2, ntiles - 1), sB, sA);
+        if (ABL == 8) ptw = __builtin_readcyclecounter();
+        step(st, min(j + 2, ntiles - 1), sB, sA, j + NSTAGE, st_free);
         st_free = st;
-        st = (st == 2) ? 0 : st + 1;
+        st = (st == NSTAGE - 1) ? 0 : st + 1;
     }
     if (j < ntiles) {                     // odd tile count
         PRIMX_ATTN_WAIT();
-        issue_pair(j + 2, st_free);       // clamped and redundant: keeps the vmcnt bookkeeping uniform
-        step(st, ntiles - 1, sA, sB);
+        step(st, ntiles - 1, sA, sB, j + NSTAGE - 1, st_free);   // (its DMA is clamped and redundant: uniform vmcnt bookkeeping)
     }
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): also drains the clamped tail DMAs
     __builtin_amdgcn_sched_barrier(0);
     pv(dvf, dpb);                         // second half of the last tile
 #undef PRIMX_ATTN_WAIT
+    if (ABL == 8 && lane == 0) {
+        atomicAdd(&g_attn_prof[0], pa); atomicAdd(&g_attn_prof[1], pb_); atomicAdd(&g_attn_prof[2], pc);
+        atomicAdd(&g_attn_prof[3], pd); atomicAdd(&g_attn_prof[4], pn - 1); atomicAdd(&g_attn_prof[5], pw); atomicAdd(&g_attn_prof[6], pe); atomicAdd(&g_attn_prof[7], pf);
+    }
 
     // ---- epilogue: normalise and store out[b, q, h*dh + d]
     float l_tot;
@@ -338,6 +380,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const typename T16<DT>::S*
     }
 }
 
+// PRIMX_ATTN_XLDS=<bytes>: extra (unused) dynamic LDS per workgroup - occupancy experiments only
+static const int g_attn_xlds = [] {
+    const char* e = getenv("PRIMX_ATTN_XLDS");
+    return e ? atoi(e) : 0;
+}();
+
 static const int g_attn_abl = [] {
     const char* e = getenv("PRIMX_ATTN_ABL");
     return e ? atoi(e) : 0;
@@ -347,9 +395,9 @@ template <int DT, int KSTEPS, int DTILES, int KMASK>
 void launch_attn(const void* Qp, const void* Kp, const void* Vt, void* out, int B, int H, int nq, int nq_pad, int nkv,
                  int nkv_pad, int dh, float c, hipStream_t st) {
     using S = typename T16<DT>::S;
-    dim3 grid(B * H, nq_pad / BQ);
+    dim3 grid(B * H, (nq_pad + BQ - 1) / BQ);
 #define PRIMX_ATTN_LAUNCH(A)                                                                                         \
-    hipLaunchKernelGGL((attn_kernel<DT, KSTEPS, DTILES, KMASK, A>), grid, dim3(256), 0, st, (const S*)Qp, (const S*)Kp, \
+    hipLaunchKernelGGL((attn_kernel<DT, KSTEPS, DTILES, KMASK, A>), grid, dim3(64 * NW), g_attn_xlds, st, (const S*)Qp, (const S*)Kp, \
                        (const S*)Vt, (S*)out, H, nq, nq_pad, nkv, nkv_pad, dh, c)
     if constexpr (DT == PRIMX_F16 && KSTEPS == 5) if (g_attn_abl != 0) {
         switch (g_attn_abl) {
@@ -357,7 +405,20 @@ void launch_attn(const void* Qp, const void* Kp, const void* Vt, void* out, int 
             case 2: PRIMX_ATTN_LAUNCH(2); break;
             case 3: PRIMX_ATTN_LAUNCH(3); break;
             case 4: PRIMX_ATTN_LAUNCH(4); break;
-            default: PRIMX_ATTN_LAUNCH(5); break;
+            case 5: PRIMX_ATTN_LAUNCH(5); break;
+            case 6: PRIMX_ATTN_LAUNCH(6); break;
+            case 7: PRIMX_ATTN_LAUNCH(7); break;
+            default: {
+                unsigned long long z[8] = {0}, r[8];
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), z, sizeof(z));
+                PRIMX_ATTN_LAUNCH(8);
+                (void)hipStreamSynchronize(st);
+                (void)hipMemcpyFromSymbol(r, HIP_SYMBOL(g_attn_prof), sizeof(r));
+                const double n = r[4] ? (double)r[4] : 1.0;
+                fprintf(stderr, "attn phase profile (cycles per step per wave, %llu samples): barrier->K-frag fence %.0f (K reads + DMA issue %.0f, deferred PV + max %.0f) | ->V0 fence %.0f | ->end %.0f | "
+                                "end->step start %.0f (of which wait+barrier %.0f, DMA issue %.0f) | total %.0f\n", r[4], r[0] / n, r[6] / n, r[7] / n, r[1] / n, r[2] / n, r[3] / n, r[5] / n, (r[3] - r[5]) / n,
+                        (r[0] + r[1] + r[2] + r[3]) / n);
+            } break;
         }
         return;
     }
@@ -371,9 +432,9 @@ extern "C" int primx_attention(const void* Qp, const void* Kp, const void* Vt, v
                                int nq_pad, int nkv, int nkv_pad, int dh, float scale, int dtype, void* stream) {
     PRIMX_REQUIRE(Qp && Kp && Vt && out, "primx_attention: null pointer");
     PRIMX_REQUIRE(B > 0 && H > 0 && nq > 0 && nkv > 0, "primx_attention: empty problem");
-    PRIMX_REQUIRE(nq_pad >= nq && nq_pad % BQ == 0, "primx_attention: nq_pad must be a multiple of 128 and >= nq");
+    PRIMX_REQUIRE(nq_pad >= nq && nq_pad % QPAD == 0, "primx_attention: nq_pad must be a multiple of 128 and >= nq");
     PRIMX_REQUIRE(nkv_pad >= nkv && nkv_pad % BKV == 0, "primx_attention: nkv_pad must be a multiple of 64 and >= nkv");
-    PRIMX_REQUIRE(nq_pad / BQ <= 65535, "primx_attention: too many query tiles");
+    PRIMX_REQUIRE(nq_pad / QPAD <= 65535, "primx_attention: too many query tiles");
     const float c = scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
     PRIMX_DISPATCH_16(dtype, "primx_attention", {
