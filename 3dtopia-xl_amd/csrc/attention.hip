@@ -1,32 +1,41 @@
 // Flash-style attention forward for gfx950 on the pre-laid-out operands written by the projection
 // GEMMs' epilogues (primx_linear_heads) - the replacement for xformers.ops.memory_efficient_attention.
 //
-// Geometry: workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query rows
-// for the whole kernel and keeps them in the LANE dimension of both MFMAs:
+// Geometry: workgroup = 8 waves = 256 query rows of one (batch, head), ONE workgroup per CU (two waves per SIMD); each
+// wave owns 32 query rows for the whole kernel and keeps them in the LANE dimension of both MFMAs:
 //
 //   S^T[key, q]  = mfma_32x32x16( A = K tile rows (key-major, from LDS),  B = Q^T (registers) )
 //   O^T[d,   q] += mfma_32x32x16( A = V^T tile rows (d-major, from LDS),  B = P^T (registers) )
 //
 // so lane (q = lane & 31) holds, for ITS query, 16 scores per 32-key sub-tile and 16 output features
 // per 32-feature tile: running max / sum / rescale are per-lane scalars and the only cross-lane
-// traffic per KV tile is one exchange of the tile max between the two half-waves (lane ^ 32).
+// traffic per KV tile is one exchange of the tile max between the two half-waves (v_permlane32_swap).
 // The accumulator register r of S^T holds key (r&3) + 8*(r>>2) + 4*hi of its 32-key sub-tile; the
 // PRIMX_HEADS_VT layout stores V^T with the 4-key quads of every 16 keys in the order {0,2,1,3}, which
 // makes the 8 keys a lane owns in one 16-key MFMA step a contiguous 16-byte LDS read - P never
 // leaves registers and needs no permute.
 //
-// Staging is LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a 3-stage ring: no staging VGPRs, no
-// ds_write.  The GLOBAL layouts are designed for it: K rows are stored with the padded stride DP+8 halves
-// (PRIMX_HEADS_KROWS), so a 64-key K tile is one contiguous block whose lane-linear LDS image has the odd 16-byte-slot
-// row stride that makes ds_read_b128 conflict-free; V^T tiles (DP rows x 128 B) land in unpadded 128-byte LDS rows with
-// the chunk index XOR-swizzled by ((row>>1)&7), applied on the per-lane SOURCE address.  Stage j % 3 holds the PAIR
-// {K(j+1), V(j)}: K runs ONE TILE AHEAD of V so that QK^T of tile j+1 (MFMA) is issued before the softmax of tile j
-// (VALU) and the two pipes overlap inside every wave.  Sync per tile: s_waitcnt vmcnt(N) + one raw s_barrier.
+// Staging is LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a 3-stage ring shared by all 8 waves:
+// no staging VGPRs, no ds_write.  The GLOBAL layouts are designed for it: K rows are stored with the padded stride
+// DP+8 halves (PRIMX_HEADS_KROWS), so a 64-key K tile is one contiguous block whose lane-linear LDS image has the odd
+// 16-byte-slot row stride that makes ds_read_b128 conflict-free; V^T tiles (DP rows x 128 B) land in unpadded
+// 128-byte LDS rows with the chunk index XOR-swizzled by ((row>>1)&7), applied on the per-lane SOURCE address.
+// Stage j % 3 holds the PAIR {K(j+1), V(j)}: K runs one tile ahead of V (scores double-buffered in registers).
+//
+// Schedule ("ping-pong", MI355X_MICROARCH.md "Two waves per SIMD"): a step of a wave is a LIGHT segment L - DMA issue,
+// all LDS fragment reads of the step's first MFMAs, row max / rare rescale - and a MATRIX segment M - 22 MFMAs with
+// the exponentials in their shadow.  Waves 0-3 (group 0) and waves 4-7 (group 1) sit on the same four SIMDs and run
+// the SAME code half a step apart, separated by workgroup barriers:
+//        group 0:   L0 | M0 | L1 | M1 | L2 | ...
+//        group 1:      | L0 | M0 | L1 | M1 | ...
+// so each SIMD's matrix pipe always has one wave in M while its partner does the latency-bound work.  Measured before
+// this schedule (profiles/r1_attn_ablation.txt): with both waves of a SIMD in phase, the non-matrix part of a step
+// (~1500 of ~2900 cycles: LDS-read bursts of all 8 waves at once, LDS-DMA issue back-pressure, barrier skew) was
+// fully exposed.
 // Head dim 72 is zero-padded to DP = 80 for QK^T (5 k-steps) and to 96 output rows for PV (3 tiles):
 // 22 MFMAs per 64 keys x 32 queries = 0.72 MFLOP issued for 0.59 MFLOP algorithmic (81.8 %).  The padding is put
 // to work: column 72 of Q/K carries the key-padding mask and row 72 of V^T is all ones, so the MFMAs themselves
-// deliver masked scores and the softmax denominator - the kernel is issue-bound on softmax VALU at this head dim
-// (~230 non-MFMA instructions per 22 MFMAs per tile; profiles/r1_attn_pmc.txt), every removed instruction counts.
+// deliver masked scores and the softmax denominator.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -34,20 +43,11 @@
 
 namespace {
 
-constexpr int QPAD = 128; // granularity of nq_pad (the Q operand buffers)
-#ifndef PRIMX_ATTN_NW
-#define PRIMX_ATTN_NW 8
-#endif
-#ifndef PRIMX_ATTN_NSTAGE
-#define PRIMX_ATTN_NSTAGE 3
-#endif
-#ifndef PRIMX_ATTN_SPREAD
-#define PRIMX_ATTN_SPREAD 1
-#endif
-constexpr int NW = PRIMX_ATTN_NW;          // waves per workgroup: all of them share every K / V^T tile the workgroup stages
-constexpr int BQ = 32 * NW;                // query rows per workgroup
-constexpr int NSTAGE = PRIMX_ATTN_NSTAGE;  // LDS ring depth
-constexpr int BKV = 64;   // keys per tile
+constexpr int QPAD = 128;   // granularity of nq_pad (the Q operand buffers)
+constexpr int NW = 8;       // waves per workgroup: all of them share every K / V^T tile the workgroup stages
+constexpr int BQ = 32 * NW; // query rows per workgroup
+constexpr int BKV = 64;     // keys per tile
+constexpr int NSTAGE = 3;   // LDS ring depth
 constexpr int WAITCNT_LGKM0 = 0xC07F;   // s_waitcnt simm16 on gfx9: vmcnt = 63 (no wait), expcnt = 7 (no wait), lgkmcnt = 0
 
 template <typename V8>
@@ -56,16 +56,16 @@ __device__ __forceinline__ V8 ldg16(const void* ptr) {
     return *reinterpret_cast<GV8*>(reinterpret_cast<uintptr_t>(ptr));
 }
 
-// ABL == 8: phase profile - s_memtime stamps at the three sync points of a step, summed per wave into g_attn_prof
+// PROF: phase profile - s_memtime stamps at the segment boundaries, summed per wave into g_attn_prof (PRIMX_ATTN_PROF):
+// 1 = all waves, 2 = group 1 only keeps the barriers (what does a matrix segment cost without a partner?)
 __device__ unsigned long long g_attn_prof[8];
 
-// ABL != 0: measurement-only ablations (PRIMX_ATTN_ABL), results are wrong by design (8: right, but instrumented)
-template <int DT, int KSTEPS, int DTILES, int KMASK, int ABL = 0>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_kernel(const typename T16<DT>::S* __restrict__ Qp,
-                                                      const typename T16<DT>::S* __restrict__ Kp,
-                                                      const typename T16<DT>::S* __restrict__ Vt,
-                                                      typename T16<DT>::S* __restrict__ out, int H, int nq, int nq_pad,
-                                                      int nkv, int nkv_pad, int dh, float c /* scale * log2(e) */) {
+template <int DT, int KSTEPS, int DTILES, int KMASK, int PROF = 0>
+__global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>::S* __restrict__ Qp,
+                                                          const typename T16<DT>::S* __restrict__ Kp,
+                                                          const typename T16<DT>::S* __restrict__ Vt,
+                                                          typename T16<DT>::S* __restrict__ out, int H, int nq, int nq_pad,
+                                                          int nkv, int nkv_pad, int dh, float c /* scale * log2(e) */) {
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
     using V4 = typename T16<DT>::V4;
@@ -79,13 +79,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_kernel(const ty
     constexpr int BUF = KT + VT_;
     constexpr int NK = KT / 512;               // DMA wave-instructions per K tile   (11 / 9 / 5 for dh 72 / 64 / 32)
     constexpr int NV = DP / 8;                 // per V^T tile, 8 rows each          (10 / 8 / 4)
-    constexpr int HW = NW / 2;                 // waves per DMA role (K pieces: waves 0..HW-1, V^T pieces: the rest)
+    constexpr int HW = NW / 2;                 // waves per group = per DMA role (group 0: K pieces, group 1: V^T pieces)
     constexpr int NSLOT = ((NK > NV ? NK : NV) + HW - 1) / HW;   // DMAs per wave per pair
     static_assert(KT % 512 == 0, "K tile must be whole DMA instructions");
     __shared__ __attribute__((aligned(16))) S smem[NSTAGE * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave / HW, rw = wave % HW;                                  // wave-uniform
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.x;  // (batch, head) fastest: with B*H % 8 == 0 all query tiles of a head share an XCD's L2
     const int q0 = blockIdx.y * BQ;
@@ -100,10 +101,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_kernel(const ty
         }
     }
 
-    // Q^T B-operand fragments: lane (q = l31, hi) holds d = 16 s + 8 hi .. +7
+    // Q^T B-operand fragments: lane (q = l31, hi) holds d = 16 s + 8 hi .. +7   (waves past nq_pad idle along on row nq_pad-1)
     V8 qf[KSTEPS];
     {
-        const S* qrow = Qp + ((int64_t)bh * nq_pad + min(q0 + wave * 32 + l31, nq_pad - 1)) * DP + hi * 8;  // (waves past nq_pad idle along)
+        const S* qrow = Qp + ((int64_t)bh * nq_pad + min(q0 + wave * 32 + l31, nq_pad - 1)) * DP + hi * 8;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) qf[s] = ldg16<V8>(qrow + s * 16);
     }
@@ -111,37 +112,31 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_kernel(const ty
     // ---- DMA issue.  Piece t of a pair: t < NK -> 1 KiB piece t of the (contiguous) K tile; else V^T rows
     // 8(t-NK) .. +7, lane (row = lane>>3, LDS chunk = lane&7) fetching the source chunk (lane&7) ^ ((row>>1)&7).  The
     // LDS image of a pair is contiguous (K tile, then V^T rows), so piece t always lands at stage + t KiB.
-    // Roles are static: waves 0,1 copy the K pieces, waves 2,3 the V^T pieces, each a contiguous run; a wave whose run
-    // is shorter than NSLOT re-issues its last piece (same bytes, harmless) and tile indices past the end are clamped,
-    // so EVERY wave issues exactly NSLOT DMAs per pair with scalar-only address arithmetic - no branches, and the
-    // vmcnt bookkeeping is static: "vmcnt(NSLOT)" = everything older than the newest pair has landed.
+    // Roles are static: group 0 copies the K pieces, group 1 the V^T pieces, each wave a contiguous run; a wave whose
+    // run is shorter than NSLOT re-issues its last piece (same bytes, harmless) and tile indices past the end are
+    // clamped, so EVERY wave issues exactly NSLOT DMAs per pair with scalar-only address arithmetic - no branches, and
+    // the vmcnt bookkeeping is static: "vmcnt(NSLOT)" = everything older than the newest pair has landed.
     const int ntiles = (nkv + BKV - 1) / BKV;
-    const int is_v = wave / HW, rw = wave % HW;                               // wave-uniform
-    const int n_pc = is_v ? NV : NK, per = (n_pc + HW - 1) / HW;
+    const int n_pc = grp ? NV : NK, per = (n_pc + HW - 1) / HW;
     const int run_first = min(rw * per, n_pc - 1);
     const int run_len = max(min(per, n_pc - rw * per), 1);
-    const int64_t piece_stride = is_v ? (int64_t)8 * nkv_pad : 512;           // halves between consecutive pieces
-    const int tile_stride = is_v ? BKV : KT;
-    const S* role_base = is_v ? Vbase : Kbase;
+    const int64_t piece_stride = grp ? (int64_t)8 * nkv_pad : 512;              // halves between consecutive pieces
+    const int tile_stride = grp ? BKV : KT;
+    const S* role_base = grp ? Vbase : Kbase;
     const int v_lrow = lane >> 3, v_lc = lane & 7;
     // per-lane source offset inside a piece; for V^T it depends on the parity of the 8-row group (swizzle term 4*tv & 7)
-    const int lane_off0 = is_v ? v_lrow * nkv_pad + ((v_lc ^ ((v_lrow >> 1) & 7)) * 8) : lane * 8;
-    const int lane_off1 = is_v ? v_lrow * nkv_pad + ((v_lc ^ ((4 + (v_lrow >> 1)) & 7)) * 8) : lane * 8;
-    auto issue_run = [&](int tile, int stage, int i0, int i1) {   // slots [i0, i1) of this wave's pieces of K(tile) / V(tile)
+    const int lane_off0 = grp ? v_lrow * nkv_pad + ((v_lc ^ ((v_lrow >> 1) & 7)) * 8) : lane * 8;
+    const int lane_off1 = grp ? v_lrow * nkv_pad + ((v_lc ^ ((4 + (v_lrow >> 1)) & 7)) * 8) : lane * 8;
+    auto issue_run = [&](int tile, int stage) {   // this wave's pieces of K(tile) (group 0) / V(tile) (group 1)
         const S* tb = role_base + (int64_t)min(tile, ntiles - 1) * tile_stride;
 #pragma unroll
-        for (int i = i0; i < (ABL == 7 ? 0 : i1); ++i) {
+        for (int i = 0; i < NSLOT; ++i) {
             const int pc = run_first + min(i, run_len - 1);
             const S* src = tb + pc * piece_stride + ((pc & 1) ? lane_off1 : lane_off0);
-            __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)src, (LV*)(smem + stage * BUF + (is_v * NK + pc) * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)src, (LV*)(smem + stage * BUF + (grp * NK + pc) * 512), 16, 0, 0);
         }
     };
-    // {K(jp+1), V(jp)}, third `part` of the wave's slots: the VMEM path accepts LDS-DMA slowly (6 back-to-back issues
-    // stalled a wave for ~1500 cycles with two workgroups per CU), so a step issues them in three spaced groups
-    auto issue_pair = [&](int jp, int stage, int part) {
-        if (PRIMX_ATTN_SPREAD) issue_run(jp + 1 - is_v, stage, part * NSLOT / 3, (part + 1) * NSLOT / 3);
-        else if (part == 0) issue_run(jp + 1 - is_v, stage, 0, NSLOT);
-    };
+    auto issue_pair = [&](int jp, int stage) { issue_run(jp + 1 - grp, stage); };   // {K(jp+1), V(jp)}
 
     f32x16 o[DTILES];
 #pragma unroll
@@ -153,42 +148,37 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_kernel(const ty
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 
-    // ---- LDS fragment reads are BATCHED and issued early (ablation: with per-MFMA "ds_read, wait, mfma" the exposed
-    // LDS latency was 46 % of the kernel, profiles/r1_attn_ablation.txt): all K fragments of a tile in one burst, all
-    // V^T fragments in another, each consumed after ONE pinned wait while VALU work covers the latency.
-    auto read_k = [&](int buf, V8 (&kf)[2][KSTEPS]) {
-        const S* kb = smem + buf * BUF + l31 * KROW + hi * 8;
+    // ---- LDS fragment reads: batched, each batch consumed after ONE wait (builtin s_waitcnt: hipcc's own waitcnt
+    // pass sees it and does not add a second, stricter wait in front of the consumers)
+    auto read_k = [&](int stage, V8 (&kf)[2][KSTEPS]) {
+        const S* kb = smem + stage * BUF + l31 * KROW + hi * 8;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int s = 0; s < KSTEPS; ++s)
-                kf[kt][s] = (ABL == 5) ? qf[s] : *reinterpret_cast<const V8*>(kb + kt * 32 * KROW + s * 16);
+            for (int s = 0; s < KSTEPS; ++s) kf[kt][s] = *reinterpret_cast<const V8*>(kb + kt * 32 * KROW + s * 16);
     };
-    auto read_v = [&](int buf, int half, V8 (&vf)[DTILES][2]) {   // key-steps 2*half, 2*half+1 of the tile
-        const S* vb = smem + buf * BUF + KT + l31 * 64;
-        const int sw = (l31 >> 1) & 7;                              // rows t*32 + l31: (row>>1)&7 does not depend on t
+    auto read_v = [&](int stage, int half, V8 (&vf)[DTILES][2]) {   // key-steps 2*half, 2*half+1 of the tile
+        const S* vb = smem + stage * BUF + KT + l31 * 64;
+        const int sw = (l31 >> 1) & 7;                                // rows t*32 + l31: (row>>1)&7 does not depend on t
 #pragma unroll
         for (int t = 0; t < DTILES; ++t)
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
-                vf[t][k2] = (ABL == 5) ? qf[k2]
-                                       : *reinterpret_cast<const V8*>(vb + t * 32 * 64 + (((4 * half + 2 * k2 + hi) ^ sw) * 8));
+                vf[t][k2] = *reinterpret_cast<const V8*>(vb + t * 32 * 64 + (((4 * half + 2 * k2 + hi) ^ sw) * 8));
     };
-    auto fence_lds = [&]() {  // every ds_read issued so far has landed; keep the compiler from moving MFMAs above it
-        __builtin_amdgcn_s_waitcnt(WAITCNT_LGKM0);   // the builtin (not inline asm): hipcc's own waitcnt pass sees it and
-        __builtin_amdgcn_sched_barrier(0);           // does not add a second, stricter wait in front of the consumers
+    auto fence_lds = [&]() {
+        __builtin_amdgcn_s_waitcnt(WAITCNT_LGKM0);
+        __builtin_amdgcn_sched_barrier(0);
     };
     // S^T(tile t) = K(t) Q^T.  Keys >= nkv: when the head dim has a spare padded column (dh < DP, e.g. 72 -> 80) they
     // are masked BY THE OPERANDS (Q[:, dh] = 1, K[pad rows, dh] = -30000, see primx_hip.h) and no code is needed here;
     // otherwise (KMASK) the scores are overwritten.
     auto qk = [&](const V8 (&kf)[2][KSTEPS], int t, f32x16 (&sc)[2]) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                if (ABL == 4) { if (s == 0) sc[kt] = zero16; asm volatile("" :: "v"(kf[kt][s])); }
-                else sc[kt] = T16<DT>::mfma32(kf[kt][s], qf[s], s == 0 ? zero16 : sc[kt]);  // shared zero C operand
-            }
+            for (int kt = 0; kt < 2; ++kt)   // the two 32-key chains alternate
+                sc[kt] = T16<DT>::mfma32(kf[kt][s], qf[s], s == 0 ? zero16 : sc[kt]);  // shared zero C operand
         if (KMASK && (t + 1) * BKV > nkv) {
             const int kbase = t * BKV + 4 * hi;
 #pragma unroll
@@ -204,10 +194,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_kernel(const ty
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-            for (int t = 0; t < DTILES; ++t) {
-                if (ABL == 3) { asm volatile("" :: "v"(vf[t][k2]), "v"(pb[k2])); }
-                else o[t] = T16<DT>::mfma32(vf[t][k2], pb[k2], o[t]);
-            }
+            for (int t = 0; t < DTILES; ++t) o[t] = T16<DT>::mfma32(vf[t][k2], pb[k2], o[t]);
     };
     // probabilities of one 32-key half of the tile (two 16-key MFMA steps): packed-fp32 FMA, v_exp, 16-bit pack
     auto probs = [&](const f32x16& sh, float mc, float& psum, V8 (&pb)[2]) {
@@ -219,42 +206,41 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_kernel(const ty
                 const f32x2 arg = __builtin_elementwise_fma(sv, (f32x2){c, c}, (f32x2){-mc, -mc});   // v_pk_fma_f32
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    float pvv;
-                    if (ABL == 1) pvv = arg[u];
-                    else if (ABL == 2) pvv = sh[0];
-                    else pvv = __builtin_amdgcn_exp2f(arg[u]);
+                    const float pvv = __builtin_amdgcn_exp2f(arg[u]);
                     if (KMASK) psum += pvv;   // !KMASK: the row sum comes out of the PV MFMA (V^T row dh is all ones)
                     pb[k2][e + u] = (S)pvv;
                 }
             }
     };
-    // ---- one pipeline step on stage `buf` = {K(next), V(cur)}; dvf / dpb carry the second half of the previous
-    // tile's PV across the barrier:
-    //   K-fragment reads -> [deferred PV MFMAs of the previous tile + max / rare rescale of S(cur)] cover their latency
-    //   -> QK^T MFMAs of the next tile | V-fragment reads, exponentials of half 0 -> PV MFMAs of half 0 | V reads and
-    //   exponentials of half 1 -> (deferred to the next step's head)
-    V8 dvf[DTILES][2], dpb[2];
-#pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dpb[k2][e] = (S)0.f;
-#pragma unroll
-        for (int t = 0; t < DTILES; ++t) dvf[t][k2] = dpb[k2];
-    }
-    unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0, pa = 0, pb_ = 0, pc = 0, pd = 0, pn = 0, ptw = 0, pw = 0, pta = 0, ptb = 0, pe = 0, pf = 0;
-    auto step = [&](int buf, int t_next, const f32x16 (&sc)[2], f32x16 (&sn)[2], int jp, int st_refill) {
-        if (ABL == 8) {
+
+    // ---- segments.  WAITB: every DMA older than the newest pair has landed (each wave waits for its OWN pieces), all
+    // LDS reads of the segment are home, then the workgroup barrier publishes both.
+#define PRIMX_ATTN_WAITB()                                                                                         \
+    do {                                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                     /* nothing of the next segment moves above ... */     \
+        __builtin_amdgcn_s_waitcnt((NSLOT & 15) | 0x70 | ((NSLOT >> 4) << 14)); /* vmcnt(NSLOT) lgkmcnt(0) */      \
+        asm volatile("s_barrier" ::: "memory");                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                     /* ... and nothing of this one sinks below */        \
+    } while (0)
+    unsigned long long pt = 0, pl = 0, pm = 0, pw = 0, pn = 0, pl_dma = 0, pl_rd = 0;
+    auto stamp = [&](unsigned long long& acc) {
+        if (PROF) {
             const unsigned long long now = __builtin_readcyclecounter();
-            if (pn) { pa += pt1 - pt0; pb_ += pt2 - pt1; pc += pt3 - pt2; pd += now - pt3; pw += ptw - pt3; pe += pta - pt0; pf += ptb - pta; }
-            ++pn;
-            pt0 = now;
+            acc += now - pt;
+            pt = now;
         }
-        V8 kf[2][KSTEPS];
-        read_k(buf, kf);
-        issue_pair(jp, st_refill, 0);
-        if (ABL == 8) pta = __builtin_readcyclecounter();
-        __builtin_amdgcn_sched_barrier(0);        // the reads go out first ...
-        pv(dvf, dpb);                             // ... and these MFMAs (plus the max below) run while they fly
+    };
+    const bool idle = PROF == 2 && grp;   // profiling only: this wave keeps the barriers and does nothing else
+    // LIGHT segment of step j on stage `st` = {K(j+1), V(j)}: DMA of pair j+2 into `st_refill` (last read, by either
+    // group, before the barrier this segment started behind), fragment reads for QK^T(j+1) and the first half of PV(j),
+    // row max of S(j) and the (rare) rescale of O.
+    auto seg_light = [&](int st, int st_refill, int jp, const f32x16 (&sc)[2], V8 (&kf)[2][KSTEPS], V8 (&vf0)[DTILES][2]) {
+        if (idle) return;
+        issue_pair(jp, st_refill);
+        if (PROF) { __builtin_amdgcn_sched_barrier(0); stamp(pl_dma); }
+        read_k(st, kf);
+        read_v(st, 0, vf0);
+        if (PROF) { __builtin_amdgcn_sched_barrier(0); stamp(pl_rd); }
         float mx = sc[0][0];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -274,74 +260,85 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_kernel(const ty
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
         }
-        if (ABL == 8) { __builtin_amdgcn_sched_barrier(0); ptb = __builtin_readcyclecounter(); }
-        fence_lds();
-        if (ABL == 8) pt1 = __builtin_readcyclecounter();
-        issue_pair(jp, st_refill, 1);
-        qk(kf, t_next, sn);
+    };
+    // MATRIX segment of step j: QK^T(j+1) with the exponentials of the first 32 keys of tile j in its shadow, PV of
+    // those keys with the exponentials of the other 32 in its shadow, PV of the rest.  All operands of the first 16
+    // MFMAs are in registers on entry; the second V^T half is read under the QK^T MFMAs.
+    // (Moving the first exponentials into the light segment was measured: the matrix segment did not get shorter.)
+    auto seg_matrix = [&](int st, int t_next, const f32x16 (&sc)[2], f32x16 (&sn)[2], const V8 (&kf)[2][KSTEPS],
+                          const V8 (&vf0)[DTILES][2]) {
+        if (idle) return;
         const float mc = m_run * c;
         float psum = 0.f;
-        {
-            V8 vf[DTILES][2], pb[2];
-            read_v(buf, 0, vf);
-            probs(sc[0], mc, psum, pb);
-            fence_lds();
-            if (ABL == 8) pt2 = __builtin_readcyclecounter();
-            issue_pair(jp, st_refill, 2);
-            pv(vf, pb);
-        }
-        read_v(buf, 1, dvf);
-        probs(sc[1], mc, psum, dpb);
+        V8 vf1[DTILES][2], pb0[2], pb1[2];
+        read_v(st, 1, vf1);
+        qk(kf, t_next, sn);
+        probs(sc[0], mc, psum, pb0);
+        __builtin_amdgcn_sched_barrier(0);
+        pv(vf0, pb0);
+        probs(sc[1], mc, psum, pb1);
+        fence_lds();
+        pv(vf1, pb1);
         if (KMASK) l_run += psum;
-        __builtin_amdgcn_sched_barrier(0);        // finish the VALU work BEFORE queueing at the barrier
-        if (ABL == 8) pt3 = __builtin_readcyclecounter();
     };
 
-    // ---- ring.  Pair j lives in stage j % 3; the scores are double-buffered in registers (sA / sB).  Prologue: K(0)
-    // parks in stage 2's K area, pairs 0 and 1 are issued.  Step j: [pair j has landed for every wave and every wave is
-    // done reading stage (j-1) % 3] -> DMA pair j+2 into that stage -> compute on stage j % 3.
-#define PRIMX_ATTN_WAIT()                                                          \
-    do {                                                                           \
-        __builtin_amdgcn_s_waitcnt((NFLY & 15) | 0x70 | ((NFLY >> 4) << 14)); /* vmcnt(NFLY) lgkmcnt(0) */ \
-        if (ABL != 6) asm volatile("s_barrier" ::: "memory");                      \
-    } while (0)
-    constexpr int NFLY = NSLOT * (NSTAGE - 2);   // DMAs of the pairs newer than the one a step consumes
-    if (!is_v) issue_run(0, NSTAGE - 1, 0, NSLOT);     // K(0) parks in the last stage (V^T waves: nothing to park)
-#pragma unroll
-    for (int pr = 0; pr < NSTAGE - 1; ++pr) issue_run(pr + 1 - is_v, pr, 0, NSLOT);
+    // ---- prologue: K(0) parks in the last stage, pairs 0 and 1 are issued; S(0) = K(0) Q^T
+    if (!grp) issue_run(0, NSTAGE - 1);
+    issue_pair(0, 0);
+    issue_pair(1, 1);
     f32x16 sA[2], sB[2];
-    PRIMX_ATTN_WAIT();                    // K(0) and pair 0 landed
+    PRIMX_ATTN_WAITB();                   // K(0) and pair 0 landed
     {
         V8 kf0[2][KSTEPS];
         read_k(NSTAGE - 1, kf0);
         fence_lds();
+        asm volatile("s_barrier" ::: "memory");   // group 0's L(0) refills this stage: everyone's K(0) reads are home first
         qk(kf0, 0, sA);                   // S(0)
     }
-    int st = 0, st_free = NSTAGE - 1;     // stage of pair j / stage to refill (pair j-1's; K(0)'s parking at j = 0)
+    if (PROF) pt = __builtin_readcyclecounter();
+    // ---- main loop.  Group 0 runs  L B M B,  group 1 runs  B L B M  per step: the same number of barriers, group 1 half
+    // a step late.  Ring safety (NSTAGE = 3): pair j+2 goes to the stage of pair j-1, whose K part was last read in
+    // group 1's L(j-1) and whose V^T part in group 1's M(j-1) - both behind a barrier that precedes the issuing
+    // segment (group 0 issues K pieces in its L(j), group 1 V^T pieces in its L(j)); pair j is complete before the
+    // barrier in front of group 0's L(j) because every wave waits vmcnt(NSLOT) before EVERY barrier.
+    int st = 0, st_free = NSTAGE - 1;
+    V8 kf[2][KSTEPS], vf0[DTILES][2];
     int j = 0;
     for (; j + 1 < ntiles; j += 2) {
-        PRIMX_ATTN_WAIT();
-        if (ABL == 8) ptw = __builtin_readcyclecounter();
-        step(st, j + 1, sA, sB, j + NSTAGE - 1, st_free);          // softmax + PV of tile j, QK^T of tile j+1; DMA of pair j+2
+        if (grp) { PRIMX_ATTN_WAITB(); stamp(pw); }
+        seg_light(st, st_free, j + NSTAGE - 1, sA, kf, vf0);
+        stamp(pl);
+        PRIMX_ATTN_WAITB();
+        stamp(pw);
+        seg_matrix(st, j + 1, sA, sB, kf, vf0);      // softmax + PV of tile j, QK^T of tile j+1
+        stamp(pm);
+        if (!grp) { PRIMX_ATTN_WAITB(); stamp(pw); }
         st_free = st;
         st = (st == NSTAGE - 1) ? 0 : st + 1;
-        PRIMX_ATTN_WAIT();
-        if (ABL == 8) ptw = __builtin_readcyclecounter();
-        step(st, min(j + 2, ntiles - 1), sB, sA, j + NSTAGE, st_free);
+        if (grp) { PRIMX_ATTN_WAITB(); stamp(pw); }
+        seg_light(st, st_free, j + NSTAGE, sB, kf, vf0);
+        stamp(pl);
+        PRIMX_ATTN_WAITB();
+        stamp(pw);
+        seg_matrix(st, min(j + 2, ntiles - 1), sB, sA, kf, vf0);
+        stamp(pm);
+        if (!grp) { PRIMX_ATTN_WAITB(); stamp(pw); }
         st_free = st;
         st = (st == NSTAGE - 1) ? 0 : st + 1;
+        if (PROF) pn += 2;
     }
-    if (j < ntiles) {                     // odd tile count
-        PRIMX_ATTN_WAIT();
-        step(st, ntiles - 1, sA, sB, j + NSTAGE - 1, st_free);   // (its DMA is clamped and redundant: uniform vmcnt bookkeeping)
+    if (j < ntiles) {                     // odd tile count (the DMAs are clamped and redundant: uniform vmcnt bookkeeping)
+        if (grp) PRIMX_ATTN_WAITB();
+        seg_light(st, st_free, j + NSTAGE - 1, sA, kf, vf0);
+        PRIMX_ATTN_WAITB();
+        seg_matrix(st, ntiles - 1, sA, sB, kf, vf0);
+        if (!grp) PRIMX_ATTN_WAITB();
     }
-    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): also drains the clamped tail DMAs
-    __builtin_amdgcn_sched_barrier(0);
-    pv(dvf, dpb);                         // second half of the last tile
-#undef PRIMX_ATTN_WAIT
-    if (ABL == 8 && lane == 0) {
-        atomicAdd(&g_attn_prof[0], pa); atomicAdd(&g_attn_prof[1], pb_); atomicAdd(&g_attn_prof[2], pc);
-        atomicAdd(&g_attn_prof[3], pd); atomicAdd(&g_attn_prof[4], pn - 1); atomicAdd(&g_attn_prof[5], pw); atomicAdd(&g_attn_prof[6], pe); atomicAdd(&g_attn_prof[7], pf);
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): drain the clamped tail DMAs before the workgroup retires
+#undef PRIMX_ATTN_WAITB
+    if (PROF && lane == 0 && !idle) {
+        atomicAdd(&g_attn_prof[0], pl); atomicAdd(&g_attn_prof[1], pm); atomicAdd(&g_attn_prof[2], pw);
+        atomicAdd(&g_attn_prof[3], pn); atomicAdd(&g_attn_prof[4], pl_dma); atomicAdd(&g_attn_prof[5], pl_rd);
     }
 
     // ---- epilogue: normalise and store out[b, q, h*dh + d]
@@ -380,14 +377,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_kernel(const ty
     }
 }
 
-// PRIMX_ATTN_XLDS=<bytes>: extra (unused) dynamic LDS per workgroup - occupancy experiments only
-static const int g_attn_xlds = [] {
-    const char* e = getenv("PRIMX_ATTN_XLDS");
-    return e ? atoi(e) : 0;
-}();
-
-static const int g_attn_abl = [] {
-    const char* e = getenv("PRIMX_ATTN_ABL");
+// PRIMX_ATTN_PROF=1|2: run the instrumented variant (dh 72, fp16) synchronously and print the per-segment cycle profile
+static const int g_attn_prof_on = [] {
+    const char* e = getenv("PRIMX_ATTN_PROF");
     return e ? atoi(e) : 0;
 }();
 
@@ -396,31 +388,23 @@ void launch_attn(const void* Qp, const void* Kp, const void* Vt, void* out, int 
                  int nkv_pad, int dh, float c, hipStream_t st) {
     using S = typename T16<DT>::S;
     dim3 grid(B * H, (nq_pad + BQ - 1) / BQ);
-#define PRIMX_ATTN_LAUNCH(A)                                                                                         \
-    hipLaunchKernelGGL((attn_kernel<DT, KSTEPS, DTILES, KMASK, A>), grid, dim3(64 * NW), g_attn_xlds, st, (const S*)Qp, (const S*)Kp, \
-                       (const S*)Vt, (S*)out, H, nq, nq_pad, nkv, nkv_pad, dh, c)
-    if constexpr (DT == PRIMX_F16 && KSTEPS == 5) if (g_attn_abl != 0) {
-        switch (g_attn_abl) {
-            case 1: PRIMX_ATTN_LAUNCH(1); break;
-            case 2: PRIMX_ATTN_LAUNCH(2); break;
-            case 3: PRIMX_ATTN_LAUNCH(3); break;
-            case 4: PRIMX_ATTN_LAUNCH(4); break;
-            case 5: PRIMX_ATTN_LAUNCH(5); break;
-            case 6: PRIMX_ATTN_LAUNCH(6); break;
-            case 7: PRIMX_ATTN_LAUNCH(7); break;
-            default: {
-                unsigned long long z[8] = {0}, r[8];
-                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), z, sizeof(z));
-                PRIMX_ATTN_LAUNCH(8);
-                (void)hipStreamSynchronize(st);
-                (void)hipMemcpyFromSymbol(r, HIP_SYMBOL(g_attn_prof), sizeof(r));
-                const double n = r[4] ? (double)r[4] : 1.0;
-                fprintf(stderr, "attn phase profile (cycles per step per wave, %llu samples): barrier->K-frag fence %.0f (K reads + DMA issue %.0f, deferred PV + max %.0f) | ->V0 fence %.0f | ->end %.0f | "
-                                "end->step start %.0f (of which wait+barrier %.0f, DMA issue %.0f) | total %.0f\n", r[4], r[0] / n, r[6] / n, r[7] / n, r[1] / n, r[2] / n, r[3] / n, r[5] / n, (r[3] - r[5]) / n,
-                        (r[0] + r[1] + r[2] + r[3]) / n);
-            } break;
+#define PRIMX_ATTN_LAUNCH(P)                                                                                         \
+    hipLaunchKernelGGL((attn_kernel<DT, KSTEPS, DTILES, KMASK, P>), grid, dim3(64 * NW), 0, st, (const S*)Qp,         \
+                       (const S*)Kp, (const S*)Vt, (S*)out, H, nq, nq_pad, nkv, nkv_pad, dh, c)
+    if constexpr (DT == PRIMX_F16 && KSTEPS == 5) {
+        if (g_attn_prof_on) {
+            unsigned long long z[8] = {0}, r[8];
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), z, sizeof(z));
+            if (g_attn_prof_on == 2) PRIMX_ATTN_LAUNCH(2);
+            else PRIMX_ATTN_LAUNCH(1);
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpyFromSymbol(r, HIP_SYMBOL(g_attn_prof), sizeof(r));
+            const double n = r[3] ? (double)r[3] : 1.0;
+            fprintf(stderr, "attn segment profile (cycles per step per wave, %llu wave-steps): light %.0f (DMA issue %.0f, LDS read "
+                            "issue %.0f, max/rescale %.0f) | matrix %.0f | waits + barriers %.0f | total %.0f\n", r[3],
+                    (r[0] + r[4] + r[5]) / n, r[4] / n, r[5] / n, r[0] / n, r[1] / n, r[2] / n, (r[0] + r[1] + r[2] + r[4] + r[5]) / n);
+            return;
         }
-        return;
     }
     PRIMX_ATTN_LAUNCH(0);
 #undef PRIMX_ATTN_LAUNCH

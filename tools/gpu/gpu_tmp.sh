@@ -1,3 +1,6 @@
 #!/bin/bash
-L=$PWD/3dtopia-xl_amd/csrc
-for v in w8s3p0 w8s3p1; do PRIMX_LIB=$L/libprimx_$v.so PRIMX_ATTN_ABL=8 REPS=2 timeout 120 python tools/attn_bench.py 2>&1 | grep -v amdgpu | grep "phase" | head -1; done
+timeout 900 python -m pytest tests/test_hip_attention.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -2
+PRIMX_ATTN_PROF=1 REPS=2 timeout 120 python tools/attn_bench.py 2>&1 | grep -v amdgpu | grep "segment" | awk 'NR==1'
+echo "--- new"; REPS=50 timeout 120 python tools/attn_bench.py 2>&1 | grep -v amdgpu | tail -4
+echo "--- prev"; (cd prev_tree && REPS=50 timeout 120 python tools/attn_bench.py 2>&1 | grep -v amdgpu | tail -4)
+echo "--- new"; REPS=50 timeout 120 python tools/attn_bench.py 2>&1 | grep -v amdgpu | tail -4
