@@ -74,7 +74,8 @@ def test_linear_gate_residual(ops, dtype):
     assert max_abs(xd, want) < 5e-2
 
 
-@pytest.mark.parametrize("B,n,H,dh,K,n_rep", [(2, 70, 4, 72, 64, 3), (1, 1370, 16, 72, 768, 2)])
+@pytest.mark.parametrize("B,n,H,dh,K,n_rep", [(2, 70, 4, 72, 64, 3), (1, 1370, 16, 72, 768, 2),
+                                             (2, 1370, 16, 72, 768, 5)])   # the last one takes the 256x288 tile
 def test_linear_heads_repeated(ops, B, n, H, dh, K, n_rep):
     """to_k / to_v of several blocks batched in one GEMM (N = n_rep * 2 * D): repetition r fills batch entries
     [r*B, (r+1)*B) of the K (padded row stride) and V^T destinations."""

@@ -12,7 +12,7 @@ def run(name, M, rpb, K, kinds, n_rep):
     A = torch.randn(M, K, device=dev).to(dt); W = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt); b = torch.randn(N, device=dev).to(dt)
     B = M // rpb
     dsts = [ops.alloc_heads(n_rep * B, H, rpb, dh, k, dt, dev, 128) for k in kinds]
-    n_pad = dsts[0].shape[2]
+    n_pad = dsts[0].shape[3] if kinds[0] == HEADS_VT else dsts[0].shape[2]
     f = lambda: ops.linear_heads(A, W, b, rpb, H, dh, kinds, dsts, n_pad, n_rep=n_rep, rep_batches=B)
     for _ in range(3): f()
     torch.cuda.synchronize()
@@ -26,3 +26,6 @@ run("qkv", 4096, 2048, 1152, [HEADS_ROWS, HEADS_KROWS, HEADS_VT], 1)
 run("to_q", 4096, 2048, 1152, [HEADS_ROWS], 1)
 run("kv_all", 2740, 1370, 768, [HEADS_KROWS, HEADS_VT], 28)
 run("k_only", 2740, 1370, 768, [HEADS_ROWS], 28)
+run("v_only", 2740, 1370, 768, [HEADS_VT], 28)
+run("kk_all", 2740, 1370, 768, [HEADS_KROWS, HEADS_KROWS], 28)
+run("qkk", 4096, 2048, 1152, [HEADS_ROWS, HEADS_KROWS, HEADS_KROWS], 1)
