@@ -25,6 +25,8 @@
 // GATHER = 1 turns the A loader into the implicit-GEMM gather of a 3x3x3 / stride 1 / pad 1 convolution
 // over channels-last [P, S^3, Cin] activations: k = tap * Cin + ci, row m = (p, voxel); out-of-volume taps
 // and any K tail read a 16-byte zero block instead of branching.
+#include <stdio.h>
+
 #include "common.h"
 
 namespace {
@@ -67,6 +69,7 @@ struct GemmArgs {
     // EPI_HEADS
     int heads, dh, DP, n_pad, n_seg;
     int kind[3];
+    int prof;  // PRIMX_GEMM_PROF=1: per-workgroup timeline stamps into g_gemm_prof (128x144 LDS-DMA kernel only)
     S* dst[3];
     float scale0;
     int64_t rep_stride[3];  // the n_seg column groups repeat; repetition r writes at dst[s] + r * rep_stride[s]
@@ -195,15 +198,22 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs<DT>& p, const ColIn
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = rnd16<DT>(p.scale0 * v[j]);
         }
-        const bool quad_ok = (p.rows_per_batch % 4 == 0) && (mq + 3 < p.M);
-        if (kind == PRIMX_HEADS_VT && quad_ok) {
-            // 4 consecutive tokens of one batch entry = one contiguous quad of the VT layout
-            const int b = mq / p.rows_per_batch, tok = mq - b * p.rows_per_batch;
-            const int64_t head = (int64_t)b * p.heads + c.hh;
-            V4 o;
+        const int b0 = mq / p.rows_per_batch, tok0 = mq - b0 * p.rows_per_batch;
+        if (kind == PRIMX_HEADS_VT && mq + 3 < p.M && tok0 + 3 < p.rows_per_batch && (tok0 & 1) == 0) {
+            // 4 consecutive tokens of one batch entry.  tok0 % 4 == 0: one contiguous quad of the VT layout (8-byte store);
+            // tok0 % 4 == 2 (rows_per_batch % 4 == 2, e.g. 1370 conditioning tokens, second batch entry): the second half
+            // of one quad + the first half of the next (two 4-byte stores) - never 2-byte scalars.
+            typedef S V2 __attribute__((ext_vector_type(2)));
+            S* row = dst + (((int64_t)b0 * p.heads + c.hh) * p.DP + c.dd) * p.n_pad;
+            if ((tok0 & 3) == 0) {
+                V4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (S)v[j];
-            *reinterpret_cast<V4*>(dst + (head * p.DP + c.dd) * p.n_pad + vt_key_pos(tok)) = o;
+                for (int j = 0; j < 4; ++j) o[j] = (S)v[j];
+                *reinterpret_cast<V4*>(row + vt_key_pos(tok0)) = o;
+            } else {
+                *reinterpret_cast<V2*>(row + vt_key_pos(tok0)) = V2{(S)v[0], (S)v[1]};
+                *reinterpret_cast<V2*>(row + vt_key_pos(tok0 + 2)) = V2{(S)v[2], (S)v[3]};
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -588,8 +598,14 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const GemmArgs<DT> p) {
 // per-lane SOURCE address: lane (r = lane>>3, c' = lane&7) fetches global chunk c' ^ ((row>>1)&7) of its row
 // (cdna_hip_programming.md rule 21).  Sync per k-tile: s_waitcnt vmcnt(4) (this wave's DMAs of tile kt have
 // landed, tile kt+1's stay in flight) + raw s_barrier; __syncthreads() would drain the ring.
+// timeline profile (PRIMX_GEMM_PROF=1): [0] min start, [1] max end (s_memrealtime, 100 MHz), sums of core-clock cycles:
+// [2] entry -> tile 0 landed, [3] main loop, [4] epilogue, [5] workgroups, [6] sum of (start - min start) in 10 ns ticks
+__device__ unsigned long long g_gemm_prof[8];
+
 template <int DT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> p) {
+    unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pc2 = 0;
+    if (p.prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
     typedef __attribute__((address_space(1))) const void GV;
@@ -682,6 +698,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     issue(min(1, nk - 1), 1);
     issue(min(2, nk - 1), 2);
     asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // tile 0 landed (4..5 DMAs per tile per wave)
+    if (p.prof) pc1 = __builtin_readcyclecounter();
     V8 a0[MI], b0[NI], a1[MI], b1[NI];
     read_frags(0, a0, b0);
     int st_cur = 0, st_next = 1;  // stage of tile kt / tile kt+1
@@ -702,6 +719,18 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     }
     if (kt < nk) step(kt, a0, b0, a1, b1);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // drain the (redundant) tail DMAs before LDS reuse
+    if (p.prof) pc2 = __builtin_readcyclecounter();
+    auto prof_end = [&]() {
+        if (p.prof) {
+            __builtin_amdgcn_s_waitcnt(0);   // the epilogue's stores have been issued AND acknowledged
+            const unsigned long long pc3 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0) {
+                atomicMin(&g_gemm_prof[0], pr0); atomicMax(&g_gemm_prof[1], pr1);
+                atomicAdd(&g_gemm_prof[2], pc1 - pc0); atomicAdd(&g_gemm_prof[3], pc2 - pc1);
+                atomicAdd(&g_gemm_prof[4], pc3 - pc2); atomicAdd(&g_gemm_prof[5], 1ull); atomicAdd(&g_gemm_prof[6], pr0);
+            }
+        }
+    };
 
     // ---- epilogue.  Default: both K halves park their accumulators in LDS as fp32 [half][128][148]; after one
     // barrier all 512 threads walk the tile ROW-MAJOR, 4 consecutive columns each (sum of the two halves ->
@@ -714,6 +743,27 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
         quad_form = (per % BN != 0) || p.kind[(n0 / per) % p.n_seg] == PRIMX_HEADS_VT;
     }
     float* red = reinterpret_cast<float*>(smem);
+    // EPI_HEADS fast path: the tile lies inside ONE (repetition, segment), so everything that needs a division is
+    // tile-uniform and computed once on the scalar unit; per unit only compares remain (the generic
+    // epilogue_row4 does five integer divisions per unit: +2.5 us per round, PRIMX_GEMM_PROF).
+    int h_hh0 = 0, h_dd0 = 0, h_bb0 = 0, h_tok0 = 0, h_rs = 0, h_seg = 0, h_rep = 0;
+    S* h_dst = nullptr;
+    bool h_fast = false;
+    if (EPI == EPI_HEADS) {
+        h_fast = p.dh >= 48 && (p.dh & 3) == 0 && p.rows_per_batch >= BM;
+        const int per = p.heads * p.dh;
+        const int seg_all = n0 / per, rep_i = seg_all / p.n_seg;
+        h_rep = rep_i;
+        h_seg = seg_all - rep_i * p.n_seg;
+        const int w0 = n0 - seg_all * per;
+        h_hh0 = w0 / p.dh;
+        h_dd0 = w0 - h_hh0 * p.dh;
+        h_bb0 = m0 / p.rows_per_batch;
+        h_tok0 = m0 - h_bb0 * p.rows_per_batch;
+        h_rs = heads_row_stride(h_seg == 0 ? p.kind[0] : h_seg == 1 ? p.kind[1] : p.kind[2], p.DP);
+        h_dst = (h_seg == 0 ? p.dst[0] : h_seg == 1 ? p.dst[1] : p.dst[2]) +
+                rep_i * (h_seg == 0 ? p.rep_stride[0] : h_seg == 1 ? p.rep_stride[1] : p.rep_stride[2]);
+    }
     if (!quad_form) {
         float* mine = red + kg * (BM * RS);
 #pragma unroll
@@ -730,7 +780,25 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(red + row * RS + 4 * c4);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(red + BM * RS + row * RS + 4 * c4);
             if (m0 + row >= p.M) continue;
-            if (EPI == EPI_GATE_RESIDUAL) {
+            if (EPI == EPI_HEADS && h_fast) {
+                using V4 = typename T16<DT>::V4;
+                int d = h_dd0 + 4 * c4, hh = h_hh0;          // d < dh + 144 <= 4 dh
+                if (d >= p.dh) { d -= p.dh; ++hh; }
+                if (d >= p.dh) { d -= p.dh; ++hh; }
+                if (d >= p.dh) { d -= p.dh; ++hh; }
+                int tok = h_tok0 + row, bb = h_bb0;          // tok < rows_per_batch + 128 <= 2 rows_per_batch
+                if (tok >= p.rows_per_batch) { tok -= p.rows_per_batch; ++bb; }
+                V4 bv = {};
+                if (p.bias) bv = *reinterpret_cast<const V4*>(p.bias + n0 + 4 * c4);
+                V4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float y = rnd16<DT>(v0[j] + v1[j] + (p.bias ? (float)bv[j] : 0.f));
+                    if (h_seg == 0 && p.scale0 != 1.0f) y = rnd16<DT>(p.scale0 * y);
+                    o[j] = (S)y;
+                }
+                *reinterpret_cast<V4*>(h_dst + (((int64_t)bb * p.heads + hh) * p.n_pad + tok) * h_rs + d) = o;
+            } else if (EPI == EPI_GATE_RESIDUAL) {
                 using V4 = typename T16<DT>::V4;
                 const int m = m0 + row, n = n0 + 4 * c4;
                 const V4 gv = *reinterpret_cast<const V4*>(p.gate + (int64_t)(m / p.rows_per_batch) * p.gate_stride + n);
@@ -745,6 +813,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
                 epilogue_row4<DT, EPI>(p, m0 + row, n0 + 4 * c4, v0 + v1);
             }
         }
+        prof_end();
         return;
     }
     // ---- quad form: K-half 0 owns column tiles 0..4, K-half 1 owns 5..8
@@ -773,6 +842,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
             epilogue_quad<DT, EPI>(p, c, m0 + wm * 32 + mi * 16 + 4 * lg, q);
         }
     }
+    prof_end();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -914,6 +984,37 @@ static const bool g_no_big = [] {   // PRIMX_GEMM_NOBIG=1 disables the 256x288 t
     return e && e[0] == '1';
 }();
 
+static const bool g_gemm_prof_on = [] {   // PRIMX_GEMM_PROF=1: synchronous launches of the 128x144 LDS-DMA kernel + timeline print
+    const char* e = getenv("PRIMX_GEMM_PROF");
+    return e && e[0] == '1';
+}();
+
+template <int DT, int EPI>
+void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
+    if (!g_gemm_prof_on) {
+        hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI>), dim3(mt * (a.N / 144)), dim3(512), 0, st, a);
+        return;
+    }
+    GemmArgs<DT> b = a;
+    b.prof = 1;
+    unsigned long long z[8] = {~0ull, 0, 0, 0, 0, 0, 0, 0}, r[8];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof(z));
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, st);
+    hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI>), dim3(mt * (a.N / 144)), dim3(512), 0, st, b);
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipMemcpyFromSymbol(r, HIP_SYMBOL(g_gemm_prof), sizeof(r));
+    const double n = r[5] ? (double)r[5] : 1.0;
+    fprintf(stderr, "gemm144_dma<%d,%d> M=%d N=%d K=%d: %llu workgroups, events %.1f us, first start -> last end %.1f us, mean start offset "
+                    "%.1f us; per workgroup (core cycles): entry->tile0 %.0f | main loop %.0f | epilogue %.0f\n", DT, EPI, a.M, a.N, a.K,
+            r[5], ms * 1e3, (r[1] - r[0]) * 0.01, (r[6] / n - (double)r[0]) * 0.01, r[2] / n, r[3] / n, r[4] / n);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+}
+
 template <int DT, int EPI, int GATHER = 0>
 int launch(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
     PRIMX_REQUIRE(a.A && a.W, "%s: null operand", name);
@@ -936,7 +1037,7 @@ int launch(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
                                st, a);                                                                                \
         } else if (a.N % 144 == 0 && !GATHER) {                                                                       \
             if (KT == 0 && !g_force_regstage)                                                                        \
-                hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI>), dim3(mt * (a.N / 144)), dim3(512), 0, st, a);       \
+                launch144_dma<DT, EPI>(a, mt, st);                                                                    \
             else                                                                                                      \
                 hipLaunchKernelGGL((gemm144_kernel<DT, EPI, KT>), dim3(mt * (a.N / 144)), dim3(512), 0, st, a);       \
         } else {                                                                                                      \

@@ -178,12 +178,12 @@ class GaussianDiffusion(DiffusionTables):
         if progress:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
-        with torch.no_grad():
-            for i in indices:
+        for i in indices:
+            with torch.no_grad():   # scoped to the step: a generator must not hold the grad-mode context across yields
                 out = self._step(kind, model, img, i, clip_denoised=clip_denoised,
                                  model_kwargs=model_kwargs, eta=eta, coef=coef, tmap=tmap)
-                yield out
-                img = out["sample"]
+            yield out
+            img = out["sample"]
 
     # ------------------------------------------------------------------ public API (reference names)
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,

@@ -177,8 +177,6 @@ class DiT(nn.Module):
                 ca, sa, mlp = blk.crossattn, blk.attn, blk.mlp
                 blocks.append({
                     "w_q": _c16(ca.to_q.weight, dtype), "b_q": _c16(ca.to_q.bias, dtype),
-                    "w_kv": _c16(torch.cat([ca.to_k.weight, ca.to_v.weight], 0), dtype),
-                    "b_kv": _c16(torch.cat([ca.to_k.bias, ca.to_v.bias], 0), dtype),
                     "w_cproj": _c16(ca.proj.weight, dtype), "b_cproj": _c16(ca.proj.bias, dtype),
                     "w_qkv": _c16(sa.qkv.weight, dtype), "b_qkv": _c16(sa.qkv.bias, dtype),
                     "w_proj": _c16(sa.proj.weight, dtype), "b_proj": _c16(sa.proj.bias, dtype),

@@ -145,3 +145,17 @@ def test_long_token_bf16_stress(pkg):
     assert got.dtype == torch.bfloat16 and torch.isfinite(got.float()).all()
     ref = dit_ref.dit_forward(sd, x, t, y, 16, torch.bfloat16)
     assert rel_l2(got, ref) < TOL_EMU[torch.bfloat16], rel_l2(got, ref)
+
+
+def test_sharded_sampler_single_rank_matches_plain_loop(pkg):
+    """world_size 1 (no process group): ShardedSampler = seeded CPU noise -> device -> the same DDIM loop."""
+    from topia_xl_amd.sharding import ShardedSampler
+    name, sd, heads, m, x, y, t = _case(pkg, 1)
+    d = pkg.create_diffusion("ddim5", noise_schedule="squaredcos_cap_v2", parameterization="v")
+    kw = dict(cfg_scale=6.0, precision_dtype=torch.float16, enable_amp=True)
+    B, N, Cc = x.shape
+    out = ShardedSampler(m, d, DEV).sample(B, N, Cc, y, seed=7, **kw)
+    noise = torch.randn(B, N, Cc, generator=torch.Generator().manual_seed(7))
+    want = d.ddim_sample_loop(m.forward_with_cfg, (B, N, Cc), noise=noise.to(DEV), clip_denoised=False,
+                              model_kwargs=dict(y=y.to(DEV), **kw))
+    assert out.shape == (B, N, Cc) and torch.equal(out.cpu(), want.cpu())
