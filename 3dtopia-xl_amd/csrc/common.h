@@ -87,10 +87,14 @@ __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)
 
 // tanh-approximated GELU as torch evaluates it in fp32: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
-    const float kKappa = 0.044715f;
-    float inner = kBeta * (x + kKappa * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(inner));
+    // 0.5 x (1 + tanh(u)) = x / (1 + exp(-2u)),  u = sqrt(2/pi) (x + 0.044715 x^3): one v_exp_f32 + one v_rcp_f32 + 5 VALU
+    // instead of libm's tanhf (~40 instructions with range branches; 144 of them per thread made up a third of the
+    // fc1 kernel, PRIMX_GEMM_PROF).  exp2 overflow -> inf -> result 0 (x << 0), underflow -> result x: both limits
+    // are exact; elsewhere the error is a few fp32 ulp, far below the 16-bit rounding that follows.
+    const float kC1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;  // -2 sqrt(2/pi) log2(e)
+    const float kC2 = kC1 * 0.044715f;
+    const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(kC2, x * x, kC1));
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // Dispatch a 16-bit dtype code to a template instantiation.

@@ -231,13 +231,16 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs<DT>& p, const ColIn
 // Row-major epilogue unit: ONE row m, FOUR consecutive columns n..n+3 (n % 4 == 0, all inside one head / one
 // segment).  Every access is 8 bytes (16-bit destinations) or 16 bytes (the fp32 residual stream), and the 36 lanes
 // covering a 144-column tile row touch 288 / 576 contiguous bytes - the quad-per-lane form touches 32 / 64.
+// `bv`: the four bias values of columns n..n+3, loaded by the caller BEFORE its store loop (a load issued between
+// the stores cannot be hoisted by the compiler - the output may alias it - and each one then costs a full memory
+// round trip: 9 x ~775 cycles per tile, PRIMX_GEMM_PROF).
 template <int DT, int EPI>
-__device__ __forceinline__ void epilogue_row4(const GemmArgs<DT>& p, int m, int n, const f32x4 a) {
+__device__ __forceinline__ void epilogue_row4(const GemmArgs<DT>& p, int m, int n, const f32x4 a,
+                                              const typename T16<DT>::V4 bv) {
     using S = typename T16<DT>::S;
     using V4 = typename T16<DT>::V4;
     float b[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
-        const V4 bv = *reinterpret_cast<const V4*>(p.bias + n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j] = (float)bv[j];
     }
@@ -720,8 +723,11 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     if (kt < nk) step(kt, a0, b0, a1, b1);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // drain the (redundant) tail DMAs before LDS reuse
     if (p.prof) pc2 = __builtin_readcyclecounter();
+    unsigned long long pc_stg = 0;
     auto prof_end = [&]() {
         if (p.prof) {
+            const unsigned long long pc_iss = __builtin_readcyclecounter();
+            if (tid == 0) atomicAdd(&g_gemm_prof[7], ((pc_stg - pc2) << 32) | (pc_iss - pc_stg));
             __builtin_amdgcn_s_waitcnt(0);   // the epilogue's stores have been issued AND acknowledged
             const unsigned long long pc3 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
             if (tid == 0) {
@@ -765,6 +771,20 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
                 rep_i * (h_seg == 0 ? p.rep_stride[0] : h_seg == 1 ? p.rep_stride[1] : p.rep_stride[2]);
     }
     if (!quad_form) {
+        // bias / gate vectors of this thread's 9 row-chunks: loaded now, they land under the LDS staging below
+        using V4e = typename T16<DT>::V4;
+        V4e bpre[NROWCH], gpre[NROWCH];
+#pragma unroll
+        for (int i = 0; i < NROWCH; ++i) {
+            const int cid = tid + 512 * i;
+            const int row = cid / (BN / 4), c4 = cid - row * (BN / 4);
+            bpre[i] = V4e{};
+            if (p.bias && EPI != EPI_CONVT) bpre[i] = *reinterpret_cast<const V4e*>(p.bias + n0 + 4 * c4);
+            if (EPI == EPI_GATE_RESIDUAL) {
+                const int m = min(m0 + row, p.M - 1);
+                gpre[i] = *reinterpret_cast<const V4e*>(p.gate + (int64_t)(m / p.rows_per_batch) * p.gate_stride + n0 + 4 * c4);
+            }
+        }
         float* mine = red + kg * (BM * RS);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -773,6 +793,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mine[(wm * 32 + mi * 16 + 4 * lg + r) * RS + ni * 16 + lr] = acc[mi][ni][r];
         __syncthreads();
+        if (p.prof) pc_stg = __builtin_readcyclecounter();
 #pragma unroll
         for (int i = 0; i < (BM * (BN / 4)) / 512; ++i) {   // 4608 row-chunks / 512 threads = 9
             const int cid = tid + 512 * i;
@@ -788,8 +809,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
                 if (d >= p.dh) { d -= p.dh; ++hh; }
                 int tok = h_tok0 + row, bb = h_bb0;          // tok < rows_per_batch + 128 <= 2 rows_per_batch
                 if (tok >= p.rows_per_batch) { tok -= p.rows_per_batch; ++bb; }
-                V4 bv = {};
-                if (p.bias) bv = *reinterpret_cast<const V4*>(p.bias + n0 + 4 * c4);
+                const V4 bv = bpre[i];
                 V4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -801,16 +821,14 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
             } else if (EPI == EPI_GATE_RESIDUAL) {
                 using V4 = typename T16<DT>::V4;
                 const int m = m0 + row, n = n0 + 4 * c4;
-                const V4 gv = *reinterpret_cast<const V4*>(p.gate + (int64_t)(m / p.rows_per_batch) * p.gate_stride + n);
-                V4 bv = {};
-                if (p.bias) bv = *reinterpret_cast<const V4*>(p.bias + n);
+                const V4 gv = gpre[i], bv = bpre[i];
                 f32x4 xv = xpre[i];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     xv[j] = xv[j] + rnd16<DT>((float)gv[j] * rnd16<DT>(v0[j] + v1[j] + (p.bias ? (float)bv[j] : 0.f)));
                 *reinterpret_cast<f32x4*>(p.x + (int64_t)m * p.N + n) = xv;
             } else {
-                epilogue_row4<DT, EPI>(p, m0 + row, n0 + 4 * c4, v0 + v1);
+                epilogue_row4<DT, EPI>(p, m0 + row, n0 + 4 * c4, v0 + v1, bpre[i]);
             }
         }
         prof_end();
@@ -856,6 +874,8 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
 // PRIMX_HEADS_VT segments) with the same per-unit functions as the 128x144 kernel.
 template <int DT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm288_dma_kernel(const GemmArgs<DT> p) {
+    unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pc2 = 0;
+    if (p.prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
     typedef __attribute__((address_space(1))) const void GV;
@@ -928,14 +948,25 @@ __global__ __launch_bounds__(512, 2) void gemm288_dma_kernel(const GemmArgs<DT> 
     for (int kt = 0; kt < nk; ++kt) {
         // 8..9 DMAs per tile per wave: <= 8 outstanding means tile kt has landed (tile kt+1 may still fly)
         asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        if (p.prof && kt == 0) pc1 = __builtin_readcyclecounter();
         compute(kt & 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone is done reading this stage
         issue(min(kt + 2, nk - 1), kt & 1);
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (p.prof) pc2 = __builtin_readcyclecounter();
 
     // ---- epilogue: 4 slabs of 64 rows through LDS (fp32 [64][292])
     float* stg = reinterpret_cast<float*>(smem);
+    using V4e = typename T16<DT>::V4;
+    V4e bpre[(64 * (BN / 4)) / 512];   // bias of this thread's 9 row-chunks (the same columns in every slab)
+#pragma unroll
+    for (int it = 0; it < (64 * (BN / 4)) / 512; ++it) {
+        const int cid = tid + 512 * it;
+        const int c4 = cid % (BN / 4);
+        bpre[it] = V4e{};
+        if (p.bias && EPI != EPI_CONVT) bpre[it] = *reinterpret_cast<const V4e*>(p.bias + n0 + 4 * c4);
+    }
     bool col_walk = false;
     if (EPI == EPI_HEADS) col_walk = p.kind[(n0 / (p.heads * p.dh)) % p.n_seg] == PRIMX_HEADS_VT;
 #pragma unroll 1
@@ -956,7 +987,7 @@ __global__ __launch_bounds__(512, 2) void gemm288_dma_kernel(const GemmArgs<DT> 
                 const int cid = tid + 512 * it;
                 const int row = cid / (BN / 4), c4 = cid - row * (BN / 4);
                 const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * RS + 4 * c4);
-                if (mb + row < p.M) epilogue_row4<DT, EPI>(p, mb + row, n0 + 4 * c4, v);
+                if (mb + row < p.M) epilogue_row4<DT, EPI>(p, mb + row, n0 + 4 * c4, v, bpre[it]);
             }
         } else {
 #pragma unroll
@@ -970,6 +1001,15 @@ __global__ __launch_bounds__(512, 2) void gemm288_dma_kernel(const GemmArgs<DT> 
             }
         }
         __syncthreads();
+    }
+    if (p.prof) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long pc3 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            atomicMin(&g_gemm_prof[0], pr0); atomicMax(&g_gemm_prof[1], pr1);
+            atomicAdd(&g_gemm_prof[2], pc1 - pc0); atomicAdd(&g_gemm_prof[3], pc2 - pc1);
+            atomicAdd(&g_gemm_prof[4], pc3 - pc2); atomicAdd(&g_gemm_prof[5], 1ull); atomicAdd(&g_gemm_prof[6], pr0);
+        }
     }
 }
 
@@ -989,10 +1029,15 @@ static const bool g_gemm_prof_on = [] {   // PRIMX_GEMM_PROF=1: synchronous laun
     return e && e[0] == '1';
 }();
 
-template <int DT, int EPI>
+template <int DT, int EPI, int BIG = 0>
 void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
+    const dim3 grid(BIG ? ((a.M + 255) / 256) * (a.N / 288) : mt * (a.N / 144));
+    auto go = [&](const GemmArgs<DT>& x) {
+        if (BIG) hipLaunchKernelGGL((gemm288_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
+        else hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
+    };
     if (!g_gemm_prof_on) {
-        hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI>), dim3(mt * (a.N / 144)), dim3(512), 0, st, a);
+        go(a);
         return;
     }
     GemmArgs<DT> b = a;
@@ -1002,16 +1047,18 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, st);
-    hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI>), dim3(mt * (a.N / 144)), dim3(512), 0, st, b);
+    go(b);
     (void)hipEventRecord(e1, st);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipMemcpyFromSymbol(r, HIP_SYMBOL(g_gemm_prof), sizeof(r));
     const double n = r[5] ? (double)r[5] : 1.0;
-    fprintf(stderr, "gemm144_dma<%d,%d> M=%d N=%d K=%d: %llu workgroups, events %.1f us, first start -> last end %.1f us, mean start offset "
-                    "%.1f us; per workgroup (core cycles): entry->tile0 %.0f | main loop %.0f | epilogue %.0f\n", DT, EPI, a.M, a.N, a.K,
-            r[5], ms * 1e3, (r[1] - r[0]) * 0.01, (r[6] / n - (double)r[0]) * 0.01, r[2] / n, r[3] / n, r[4] / n);
+    fprintf(stderr, "%s<%d,%d> M=%d N=%d K=%d: %llu workgroups, events %.1f us, first start -> last end %.1f us, mean start offset "
+                    "%.1f us; per workgroup (core cycles): entry->tile0 %.0f | main loop %.0f | epilogue %.0f (LDS staging %.0f, read+store issue %.0f)\n",
+            BIG ? "gemm288_dma" : "gemm144_dma", DT, EPI, a.M, a.N, a.K,
+            r[5], ms * 1e3, (r[1] - r[0]) * 0.01, (r[6] / n - (double)r[0]) * 0.01, r[2] / n, r[3] / n, r[4] / n, (r[7] >> 32) / n,
+            (r[7] & 0xffffffffull) / n);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 }
 
@@ -1033,8 +1080,7 @@ int launch(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
             hipLaunchKernelGGL((gemm_kernel<DT, EPI, 32, 4, 1, 1, 1, GATHER, KT>), dim3(mt * ((a.N + 31) / 32)),      \
                                dim3(256), 0, st, a);                                                                  \
         } else if (use_big && KT == 0 && !GATHER) {                                                                   \
-            hipLaunchKernelGGL((gemm288_dma_kernel<DT, EPI>), dim3(((a.M + 255) / 256) * (a.N / 288)), dim3(512), 0,  \
-                               st, a);                                                                                \
+            launch144_dma<DT, EPI, 1>(a, mt, st);                                                                     \
         } else if (a.N % 144 == 0 && !GATHER) {                                                                       \
             if (KT == 0 && !g_force_regstage)                                                                        \
                 launch144_dma<DT, EPI>(a, mt, st);                                                                    \
