@@ -605,7 +605,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const GemmArgs<DT> p) {
 // [2] entry -> tile 0 landed, [3] main loop, [4] epilogue, [5] workgroups, [6] sum of (start - min start) in 10 ns ticks
 __device__ unsigned long long g_gemm_prof[8];
 
-template <int DT, int EPI>
+template <int DT, int EPI, int REGEPI>
 __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> p) {
     unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pc2 = 0;
     if (p.prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
@@ -660,6 +660,17 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Epilogue form (tile-uniform).  quad_form: column tiles of a PRIMX_HEADS_VT segment (4 consecutive TOKENS per lane is
+    // what that layout wants) or tiles straddling two head segments.  Otherwise `sw`: the MFMA operands are SWAPPED, the
+    // accumulator holds C^T and lane (lr, lg) owns row m = .. + lr and FOUR CONSECUTIVE columns n = .. + 4 lg + r, so the
+    // epilogue works straight from registers with 8 / 16-byte row-major accesses (PRIMX_GEMM_REGEPI=0: LDS row-major walk).
+    bool quad_form = false;
+    if (EPI == EPI_HEADS) {
+        const int per = p.heads * p.dh;
+        quad_form = (per % BN != 0) || p.kind[(n0 / per) % p.n_seg] == PRIMX_HEADS_VT;
+    }
+    const bool sw = REGEPI && !quad_form;   // compile-time true outside the heads epilogue
+
     const int a_row = wm * 32 + lr;
     const int chunk = kg * 4 + lg;
     // Fragment double buffering: tile kt+1's fragments are read from LDS (non-blocking ds_read_b128) BEFORE the
@@ -677,7 +688,8 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(a[i], b[j], acc[i][j]);
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = sw ? T16<DT>::mfma16(b[j], a[i], acc[i][j]) : T16<DT>::mfma16(a[i], b[j], acc[i][j]);
     };
 
     // Ring: tile j lives in stage j % 3.  Step kt: [tile kt+1 landed, everyone done reading tile kt] ->
@@ -686,7 +698,8 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     // (9 x 16 bytes per thread); they land during the main loop, so the epilogue only has to add and write.
     constexpr int NROWCH = (BM * (BN / 4)) / 512;
     f32x4 xpre[NROWCH];
-    if (EPI == EPI_GATE_RESIDUAL) {
+    const int m_own = m0 + wm * 32 + kg * 16 + lr;      // sw epilogue: K-half kg finalises M sub-tile mi = kg, all 9 column tiles
+    if (EPI == EPI_GATE_RESIDUAL && !REGEPI) {   // (register epilogue: the residual chunks are loaded after the main loop - 36 VGPRs less in it)
 #pragma unroll
         for (int i = 0; i < NROWCH; ++i) {
             const int cid = tid + 512 * i;
@@ -743,11 +756,6 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     // epilogue_row4): coalesced 8 / 16-byte accesses instead of 2 / 4-byte ones (the fp32 residual read-modify-write
     // alone cost +12 us per launch in quad form, tools/gemm_ksweep.py).  Column tiles that belong to a
     // PRIMX_HEADS_VT segment keep the quad form (4 consecutive TOKENS per lane is what that layout wants).
-    bool quad_form = false;
-    if (EPI == EPI_HEADS) {
-        const int per = p.heads * p.dh;                 // row-major only when no 144-column tile straddles a segment
-        quad_form = (per % BN != 0) || p.kind[(n0 / per) % p.n_seg] == PRIMX_HEADS_VT;
-    }
     float* red = reinterpret_cast<float*>(smem);
     // EPI_HEADS fast path: the tile lies inside ONE (repetition, segment), so everything that needs a division is
     // tile-uniform and computed once on the scalar unit; per unit only compares remain (the generic
@@ -770,7 +778,64 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
         h_dst = (h_seg == 0 ? p.dst[0] : h_seg == 1 ? p.dst[1] : p.dst[2]) +
                 rep_i * (h_seg == 0 ? p.rep_stride[0] : h_seg == 1 ? p.rep_stride[1] : p.rep_stride[2]);
     }
-    if (!quad_form) {
+    if (sw) {
+        // ---- register epilogue: the two K halves swap one M sub-tile each through LDS (16 bytes per lane per tile, lane-
+        // linear: 72 KB of ds_write_b128 instead of 147 KB of ds_write_b32), then every lane finishes 9 row-chunks
+        using V4e = typename T16<DT>::V4;
+        static_assert(NROWCH == NI, "xpre doubles as the 9 residual chunks of the register epilogue");
+        f32x4* red4 = reinterpret_cast<f32x4*>(smem);
+        const int nb = n0 + 4 * lg;
+        V4e bpre[NI], gpre[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            bpre[j] = V4e{};
+            if (p.bias && EPI != EPI_CONVT) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + nb + j * 16);
+            if (EPI == EPI_GATE_RESIDUAL) {
+                gpre[j] = *reinterpret_cast<const V4e*>(p.gate + (int64_t)(min(m_own, p.M - 1) / p.rows_per_batch) * p.gate_stride + nb + j * 16);
+                xpre[j] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)min(m_own, p.M - 1) * p.N + nb + j * 16);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) red4[((wm * 2 + (1 - kg)) * NI + j) * 64 + lane] = kg ? acc[0][j] : acc[1][j];
+        __syncthreads();
+        if (p.prof) pc_stg = __builtin_readcyclecounter();
+        f32x4 v[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) v[j] = (kg ? acc[1][j] : acc[0][j]) + red4[((wm * 2 + kg) * NI + j) * 64 + lane];
+        if (m_own < p.M) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = nb + j * 16;
+                if (EPI == EPI_HEADS && h_fast) {
+                    int d = h_dd0 + 4 * lg + j * 16, hh = h_hh0;
+                    if (d >= p.dh) { d -= p.dh; ++hh; }
+                    if (d >= p.dh) { d -= p.dh; ++hh; }
+                    if (d >= p.dh) { d -= p.dh; ++hh; }
+                    int tok = h_tok0 + (m_own - m0), bb = h_bb0;
+                    if (tok >= p.rows_per_batch) { tok -= p.rows_per_batch; ++bb; }
+                    V4e o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float y = rnd16<DT>(v[j][r] + (p.bias ? (float)bpre[j][r] : 0.f));
+                        if (h_seg == 0 && p.scale0 != 1.0f) y = rnd16<DT>(p.scale0 * y);
+                        o[r] = (S)y;
+                    }
+                    *reinterpret_cast<V4e*>(h_dst + (((int64_t)bb * p.heads + hh) * p.n_pad + tok) * h_rs + d) = o;
+                } else if (EPI == EPI_GATE_RESIDUAL) {
+                    f32x4 xv = xpre[j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        xv[r] += rnd16<DT>((float)gpre[j][r] * rnd16<DT>(v[j][r] + (p.bias ? (float)bpre[j][r] : 0.f)));
+                    *reinterpret_cast<f32x4*>(p.x + (int64_t)m_own * p.N + n) = xv;
+                } else {
+                    epilogue_row4<DT, EPI>(p, m_own, n, v[j], bpre[j]);
+                }
+            }
+        }
+        prof_end();
+        return;
+    }
+    if (!REGEPI && !quad_form) {
         // bias / gate vectors of this thread's 9 row-chunks: loaded now, they land under the LDS staging below
         using V4e = typename T16<DT>::V4;
         V4e bpre[NROWCH], gpre[NROWCH];
@@ -885,8 +950,6 @@ __global__ __launch_bounds__(512, 2) void gemm288_dma_kernel(const GemmArgs<DT> 
     constexpr int STAGE = ROWS * 64;         // halves
     constexpr int NINST = ROWS / 8;          // 68 wave-instructions per stage
     constexpr int NSLOT = (NINST + 7) / 8;   // 9 (waves 0..3), 8 for waves 4..7
-    constexpr int RS = BN + 4;               // fp32 row stride of the epilogue slab
-    static_assert(64 * RS * 4 <= 2 * STAGE * 2, "slab fits in the ring");
     __shared__ __attribute__((aligned(16))) S smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -935,10 +998,13 @@ __global__ __launch_bounds__(512, 2) void gemm288_dma_kernel(const GemmArgs<DT> 
             for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const V8*>(As + lds_off(a_row + i * 16, chunk));
 #pragma unroll
             for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(Ws + lds_off(w_row + j * 16, chunk));
+            // operands SWAPPED (W fragment as A, activation fragment as B): the accumulator holds C^T, i.e. lane
+            // (lr, lg) owns row m = .. + lr and the FOUR CONSECUTIVE columns n = .. + 4 lg + r - the epilogue then works
+            // straight from registers with 8 / 16-byte row-major accesses and no LDS round trip
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(b[j], a[i], acc[i][j]);
         }
     };
 
@@ -956,51 +1022,44 @@ __global__ __launch_bounds__(512, 2) void gemm288_dma_kernel(const GemmArgs<DT> 
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (p.prof) pc2 = __builtin_readcyclecounter();
 
-    // ---- epilogue: 4 slabs of 64 rows through LDS (fp32 [64][292])
-    float* stg = reinterpret_cast<float*>(smem);
+    // ---- epilogue from registers: acc[i][j][r] = C[m0 + wm*64 + i*16 + lr][n0 + wn*144 + j*16 + 4*lg + r].
+    // Everything the store loop needs from memory (bias, gate, fp32 residual) is loaded BEFORE it, one M-group (9 column
+    // tiles) at a time: a load between stores cannot be hoisted (the output may alias it) and would cost a round trip.
     using V4e = typename T16<DT>::V4;
-    V4e bpre[(64 * (BN / 4)) / 512];   // bias of this thread's 9 row-chunks (the same columns in every slab)
+    const int nb = n0 + wn * 144 + 4 * lg;
+    V4e bpre[NI];
 #pragma unroll
-    for (int it = 0; it < (64 * (BN / 4)) / 512; ++it) {
-        const int cid = tid + 512 * it;
-        const int c4 = cid % (BN / 4);
-        bpre[it] = V4e{};
-        if (p.bias && EPI != EPI_CONVT) bpre[it] = *reinterpret_cast<const V4e*>(p.bias + n0 + 4 * c4);
+    for (int j = 0; j < NI; ++j) {
+        bpre[j] = V4e{};
+        if (p.bias && EPI != EPI_CONVT) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + nb + j * 16);
     }
-    bool col_walk = false;
-    if (EPI == EPI_HEADS) col_walk = p.kind[(n0 / (p.heads * p.dh)) % p.n_seg] == PRIMX_HEADS_VT;
-#pragma unroll 1
-    for (int slab = 0; slab < 4; ++slab) {
-        if (wm == slab) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + lr;
+        const bool ok = m < p.M;
+        const int mc = ok ? m : p.M - 1;
+        if (EPI == EPI_GATE_RESIDUAL) {
+            const S* grow = p.gate + (int64_t)(mc / p.rows_per_batch) * p.gate_stride + nb;
+            float* xrow = p.x + (int64_t)mc * p.N + nb;
+            V4e gv[NI];
+            f32x4 xv[NI];
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
+            for (int j = 0; j < NI; ++j) {
+                gv[j] = *reinterpret_cast<const V4e*>(grow + j * 16);
+                xv[j] = *reinterpret_cast<const f32x4*>(xrow + j * 16);
+            }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) stg[(i * 16 + 4 * lg + r) * RS + wn * 144 + j * 16 + lr] = acc[i][j][r];
-        }
-        __syncthreads();
-        const int mb = m0 + slab * 64;
-        if (!col_walk) {
+            for (int j = 0; j < NI; ++j) {
 #pragma unroll
-            for (int it = 0; it < (64 * (BN / 4)) / 512; ++it) {      // 4608 row-chunks / 512 threads = 9
-                const int cid = tid + 512 * it;
-                const int row = cid / (BN / 4), c4 = cid - row * (BN / 4);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * RS + 4 * c4);
-                if (mb + row < p.M) epilogue_row4<DT, EPI>(p, mb + row, n0 + 4 * c4, v, bpre[it]);
+                for (int r = 0; r < 4; ++r)
+                    xv[j][r] += rnd16<DT>((float)gv[j][r] * rnd16<DT>(acc[i][j][r] + (p.bias ? (float)bpre[j][r] : 0.f)));
+                if (ok) *reinterpret_cast<f32x4*>(xrow + j * 16) = xv[j];
             }
         } else {
 #pragma unroll
-            for (int it = 0; it < (16 * BN) / 512; ++it) {            // 16 row-quads x 288 columns / 512 threads = 9
-                const int uid = tid + 512 * it;
-                const int rq = uid / BN, col = uid - rq * BN;
-                const float q[4] = {stg[(4 * rq) * RS + col], stg[(4 * rq + 1) * RS + col], stg[(4 * rq + 2) * RS + col],
-                                    stg[(4 * rq + 3) * RS + col]};
-                const ColInfo c = make_col<DT, EPI>(p, n0 + col);
-                epilogue_quad<DT, EPI>(p, c, mb + 4 * rq, q);
-            }
+            for (int j = 0; j < NI; ++j)
+                if (ok) epilogue_row4<DT, EPI>(p, m, nb + j * 16, acc[i][j], bpre[j]);
         }
-        __syncthreads();
     }
     if (p.prof) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -1024,6 +1083,14 @@ static const bool g_no_big = [] {   // PRIMX_GEMM_NOBIG=1 disables the 256x288 t
     return e && e[0] == '1';
 }();
 
+// PRIMX_GEMM_REGEPI=1: register epilogue (swapped MFMA operands) in the 128x144 kernel.  Measured same-box: no gain
+// over the LDS row-major walk (configs[1] 12.00 vs 11.87 ms/step; 64-byte vs 576-byte runs per row), so it stays off;
+// the 256x288 kernel, which has no K split to exchange, always uses it (fc1 epilogue 22k -> 13.8k cycles).
+static const int g_reg_epi = [] {
+    const char* e = getenv("PRIMX_GEMM_REGEPI");
+    return (e && e[0] == '1') ? 1 : 0;
+}();
+
 static const bool g_gemm_prof_on = [] {   // PRIMX_GEMM_PROF=1: synchronous launches of the 128x144 LDS-DMA kernel + timeline print
     const char* e = getenv("PRIMX_GEMM_PROF");
     return e && e[0] == '1';
@@ -1034,7 +1101,8 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     const dim3 grid(BIG ? ((a.M + 255) / 256) * (a.N / 288) : mt * (a.N / 144));
     auto go = [&](const GemmArgs<DT>& x) {
         if (BIG) hipLaunchKernelGGL((gemm288_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
-        else hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
+        else if (g_reg_epi) hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI, 1>), grid, dim3(512), 0, st, x);
+        else hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI, 0>), grid, dim3(512), 0, st, x);
     };
     if (!g_gemm_prof_on) {
         go(a);

@@ -7,6 +7,7 @@ reference's extensions hard-code stream 0 (mvpraymarch.cpp:121), this does not.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -54,7 +55,8 @@ def _gemm_tag(epi: int, M: int, N: int, K: int, dtype) -> str:
     if epi != 2 and N % 288 == 0 and K % 64 == 0 and ((M + 255) // 256) * (N // 288) >= 224:
         return f"gemm288_dma_kernel<{dt}, {epi}>"
     if N % 144 == 0:
-        return f"gemm144_dma_kernel<{dt}, {epi}>" if K % 64 == 0 else f"gemm144_kernel<{dt}, {epi}, 1>"
+        regepi = int(os.environ.get("PRIMX_GEMM_REGEPI", "0") == "1")
+        return f"gemm144_dma_kernel<{dt}, {epi}, {regepi}>" if K % 64 == 0 else f"gemm144_kernel<{dt}, {epi}, 1>"
     return f"gemm_kernel<{dt}, {epi}, 32, 2, 2, 2, 2, 0, {int(K % 64 != 0)}>"
 
 
