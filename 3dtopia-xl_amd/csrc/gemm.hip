@@ -603,7 +603,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const GemmArgs<DT> p) {
 // landed, tile kt+1's stay in flight) + raw s_barrier; __syncthreads() would drain the ring.
 // timeline profile (PRIMX_GEMM_PROF=1): [0] min start, [1] max end (s_memrealtime, 100 MHz), sums of core-clock cycles:
 // [2] entry -> tile 0 landed, [3] main loop, [4] epilogue, [5] workgroups, [6] sum of (start - min start) in 10 ns ticks
-__device__ unsigned long long g_gemm_prof[8];
+__device__ unsigned long long g_gemm_prof[12];
 
 template <int DT, int EPI, int REGEPI>
 __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> p) {
@@ -1009,15 +1009,22 @@ __global__ __launch_bounds__(512, 2) void gemm288_dma_kernel(const GemmArgs<DT> 
     };
 
     const int nk = p.K / BK;
+    unsigned long long pq[4] = {0, 0, 0, 0};
     issue(0, 0);
     issue(min(1, nk - 1), 1);
     for (int kt = 0; kt < nk; ++kt) {
         // 8..9 DMAs per tile per wave: <= 8 outstanding means tile kt has landed (tile kt+1 may still fly)
+        unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+        if (p.prof) q0 = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
         if (p.prof && kt == 0) pc1 = __builtin_readcyclecounter();
+        if (p.prof) q1 = __builtin_readcyclecounter();
         compute(kt & 1);
+        if (p.prof) { __builtin_amdgcn_sched_barrier(0); q2 = __builtin_readcyclecounter(); }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone is done reading this stage
+        if (p.prof) q3 = __builtin_readcyclecounter();
         issue(min(kt + 2, nk - 1), kt & 1);
+        if (p.prof) { pq[0] += q1 - q0; pq[1] += q2 - q1; pq[2] += q3 - q2; pq[3] += __builtin_readcyclecounter() - q3; }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (p.prof) pc2 = __builtin_readcyclecounter();
@@ -1068,6 +1075,9 @@ __global__ __launch_bounds__(512, 2) void gemm288_dma_kernel(const GemmArgs<DT> 
             atomicMin(&g_gemm_prof[0], pr0); atomicMax(&g_gemm_prof[1], pr1);
             atomicAdd(&g_gemm_prof[2], pc1 - pc0); atomicAdd(&g_gemm_prof[3], pc2 - pc1);
             atomicAdd(&g_gemm_prof[4], pc3 - pc2); atomicAdd(&g_gemm_prof[5], 1ull); atomicAdd(&g_gemm_prof[6], pr0);
+            const unsigned long long nkk = p.K / BK;
+            atomicAdd(&g_gemm_prof[8], pq[0] / nkk); atomicAdd(&g_gemm_prof[9], pq[1] / nkk);
+            atomicAdd(&g_gemm_prof[10], pq[2] / nkk); atomicAdd(&g_gemm_prof[11], pq[3] / nkk);
         }
     }
 }
@@ -1110,7 +1120,7 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     }
     GemmArgs<DT> b = a;
     b.prof = 1;
-    unsigned long long z[8] = {~0ull, 0, 0, 0, 0, 0, 0, 0}, r[8];
+    unsigned long long z[12] = {~0ull, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, r[12];
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof(z));
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -1127,6 +1137,9 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
             BIG ? "gemm288_dma" : "gemm144_dma", DT, EPI, a.M, a.N, a.K,
             r[5], ms * 1e3, (r[1] - r[0]) * 0.01, (r[6] / n - (double)r[0]) * 0.01, r[2] / n, r[3] / n, r[4] / n, (r[7] >> 32) / n,
             (r[7] & 0xffffffffull) / n);
+    if (BIG)
+        fprintf(stderr, "   per k-tile (wave 0 of each workgroup, core cycles): wait DMA + barrier %.0f | reads + 72 MFMAs %.0f | lgkm + barrier %.0f | DMA issue %.0f\n",
+                r[8] / n, r[9] / n, r[10] / n, r[11] / n);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 }
 
