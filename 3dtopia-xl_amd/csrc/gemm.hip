@@ -1082,6 +1082,153 @@ __global__ __launch_bounds__(512, 2) void gemm288_dma_kernel(const GemmArgs<DT> 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Big tile, second pipeline: the same 256 x 288 tile and register epilogue, but the k dimension is staged in 32-wide
+// slices through a 4-stage ring (4 x 34,816 B) with ONE barrier per slice.  The 2-stage 64-wide ring above needs two
+// barriers per tile and issues the next tile's DMAs only after the MFMAs (profile: 754 + 562 cycles per k-tile of DMA
+// wait + issue serial with 2304 MFMA cycles); here the DMAs of slice h+3 are spread between the MFMAs of slice h and
+// have two slices of MFMA time to land.
+// LDS rows are 64 bytes (4 chunks of 16 B); chunk' = chunk ^ 2*((row>>3)&1) makes the ds_read_b128 lane groups
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) hit 16 distinct 16-byte slots (rows r&3 pick the 64-byte quarter of a
+// 256-byte bank window, the XOR separates rows 0-7 from 8-15 which the groups pair with chunk c and c+1).
+template <int DT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT> p) {
+    using S = typename T16<DT>::S;
+    using V8 = typename T16<DT>::V8;
+    typedef __attribute__((address_space(1))) const void GV;
+    typedef __attribute__((address_space(3))) void LV;
+    constexpr int BM = 256, BN = 288, MI = 4, NI = 9, KS = 32, NST = 4;
+    constexpr int ROWS = BM + BN;            // 544 rows of 64 bytes per stage
+    constexpr int STAGE = ROWS * KS;         // halves per stage
+    constexpr int NINST = ROWS / 16;         // 34 wave-instructions (16 rows each) per stage
+    constexpr int NSLOT = (NINST + 7) / 8;   // 5 (waves 0,1) / 4
+    __shared__ __attribute__((aligned(16))) S smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    const int nt = p.N / BN, mt = (p.M + BM - 1) / BM;
+    const int id = xcd_remap(blockIdx.x, nt * mt);
+    const int m0 = (id / nt) * BM, n0 = (id % nt) * BN;
+
+    const S* gp[NSLOT];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+        const int t = min(wave + 8 * i, NINST - 1);
+        const int row = 16 * t + (lane >> 2);
+        const int c = (lane & 3) ^ (((row >> 3) & 1) << 1);
+        gp[i] = (row < BM) ? p.A + (int64_t)min(m0 + row, p.M - 1) * p.K + c * 8
+                           : p.W + (int64_t)(n0 + row - BM) * p.K + c * 8;
+    }
+    const bool last_slot = wave + 8 * (NSLOT - 1) < NINST;  // wave-uniform (waves 0,1)
+    auto issue_one = [&](int ks, int stage, int i) {        // slot i of this wave for k-slice ks
+        if (i < NSLOT - 1 || last_slot)
+            __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + ks * KS),
+                                             (LV*)(smem + stage * STAGE + (wave + 8 * i) * 512), 16, 0, 0);
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int sw2 = ((lr >> 3) & 1) << 1;
+    const int a_off = (wm * 64 + lr) * KS + ((lg ^ sw2) << 3);            // + i * 16 rows
+    const int w_off = (BM + wn * 144 + lr) * KS + ((lg ^ sw2) << 3);      // + j * 16 rows
+
+    const int nks = p.K / KS;
+#pragma unroll
+    for (int pre = 0; pre < NST - 1; ++pre)
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) issue_one(min(pre, nks - 1), pre, i);
+    // Fragment prefetch: the A fragments and the first NPF W fragments of slice ks+1 are read while the MFMAs of slice ks
+    // run (they need slice ks+1 to have landed one barrier earlier: "vmcnt(4)" = only slice ks+2 still in flight).
+    constexpr int NPF = 3;
+    V8 a_n[MI], b_n[NPF];
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");     // slice 0 landed
+    {
+        const S* base0 = smem;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a_n[i] = *reinterpret_cast<const V8*>(base0 + a_off + i * 16 * KS);
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) b_n[j] = *reinterpret_cast<const V8*>(base0 + w_off + j * 16 * KS);
+    }
+    int st = 0;
+    for (int ks = 0; ks < nks; ++ks) {
+        // slice ks+2 may stay in flight (4..5 DMAs per wave): <= 4 outstanding means slices ks and ks+1 have landed;
+        // lgkmcnt(0): this wave's reads of slice ks-1 (and its prefetch of slice ks) are done
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const S* base = smem + st * STAGE;
+        const int st_next = (st == NST - 1) ? 0 : st + 1;
+        const S* base_n = smem + st_next * STAGE;
+        const int st_fill = (st == 0) ? NST - 1 : st - 1;                // stage of slice ks-1
+        const int ks_fill = min(ks + NST - 1, nks - 1);
+        V8 a[MI], b[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = a_n[i];
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) b[j] = b_n[j];
+#pragma unroll
+        for (int j = NPF; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(base + w_off + j * 16 * KS);
+        // operands swapped: accumulator = C^T (see the epilogue); the DMAs of slice ks+3 go out between the MFMA groups
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (j < NSLOT) issue_one(ks_fill, st_fill, j);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[i][j] = T16<DT>::mfma16(b[j], a[i], acc[i][j]);
+            if (j == NPF) {   // the prefetched registers are free now: fetch slice ks+1's (clamped reads past the end are unused)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a_n[i] = *reinterpret_cast<const V8*>(base_n + a_off + i * 16 * KS);
+#pragma unroll
+                for (int jj = 0; jj < NPF; ++jj) b_n[jj] = *reinterpret_cast<const V8*>(base_n + w_off + jj * 16 * KS);
+            }
+        }
+        st = st_next;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (clamped tail DMAs)
+
+    // ---- epilogue from registers: acc[i][j][r] = C[m0 + wm*64 + i*16 + lr][n0 + wn*144 + j*16 + 4*lg + r]
+    using V4e = typename T16<DT>::V4;
+    const int nb = n0 + wn * 144 + 4 * lg;
+    V4e bpre[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        bpre[j] = V4e{};
+        if (p.bias && EPI != EPI_CONVT) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + nb + j * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + lr;
+        const bool ok = m < p.M;
+        const int mc = ok ? m : p.M - 1;
+        if (EPI == EPI_GATE_RESIDUAL) {
+            const S* grow = p.gate + (int64_t)(mc / p.rows_per_batch) * p.gate_stride + nb;
+            float* xrow = p.x + (int64_t)mc * p.N + nb;
+            V4e gv[NI];
+            f32x4 xv[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                gv[j] = *reinterpret_cast<const V4e*>(grow + j * 16);
+                xv[j] = *reinterpret_cast<const f32x4*>(xrow + j * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    xv[j][r] += rnd16<DT>((float)gv[j][r] * rnd16<DT>(acc[i][j][r] + (p.bias ? (float)bpre[j][r] : 0.f)));
+                if (ok) *reinterpret_cast<f32x4*>(xrow + j * 16) = xv[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                if (ok) epilogue_row4<DT, EPI>(p, m, nb + j * 16, acc[i][j], bpre[j]);
+        }
+    }
+}
+
 // PRIMX_GEMM_REGSTAGE=1 selects the register-staged T144 kernel instead of the LDS-DMA one (A/B measurements)
 static const bool g_force_regstage = [] {
     const char* e = getenv("PRIMX_GEMM_REGSTAGE");
@@ -1101,6 +1248,11 @@ static const int g_reg_epi = [] {
     return (e && e[0] == '1') ? 1 : 0;
 }();
 
+static const bool g_big_q = [] {   // PRIMX_GEMM_BIGQ=0: 256x288 kernel with the 2-stage 64-wide ring instead of the 4-stage 32-wide one
+    const char* e = getenv("PRIMX_GEMM_BIGQ");
+    return !(e && e[0] == '0');
+}();
+
 static const bool g_gemm_prof_on = [] {   // PRIMX_GEMM_PROF=1: synchronous launches of the 128x144 LDS-DMA kernel + timeline print
     const char* e = getenv("PRIMX_GEMM_PROF");
     return e && e[0] == '1';
@@ -1110,7 +1262,8 @@ template <int DT, int EPI, int BIG = 0>
 void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     const dim3 grid(BIG ? ((a.M + 255) / 256) * (a.N / 288) : mt * (a.N / 144));
     auto go = [&](const GemmArgs<DT>& x) {
-        if (BIG) hipLaunchKernelGGL((gemm288_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
+        if (BIG && g_big_q && !g_gemm_prof_on && x.K % 32 == 0) hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
+        else if (BIG) hipLaunchKernelGGL((gemm288_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
         else if (g_reg_epi) hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI, 1>), grid, dim3(512), 0, st, x);
         else hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI, 0>), grid, dim3(512), 0, st, x);
     };

@@ -53,7 +53,8 @@ def _gemm_tag(epi: int, M: int, N: int, K: int, dtype) -> str:
     if N <= 32:
         return f"gemm_kernel<{dt}, {epi}, 32, 4, 1, 1, 1, 0, {int(K % 64 != 0)}>"
     if epi != 2 and N % 288 == 0 and K % 64 == 0 and ((M + 255) // 256) * (N // 288) >= 224:
-        return f"gemm288_dma_kernel<{dt}, {epi}>"
+        q = "" if os.environ.get("PRIMX_GEMM_BIGQ", "1") == "0" or os.environ.get("PRIMX_GEMM_PROF") == "1" else "q"
+        return f"gemm288{q}_dma_kernel<{dt}, {epi}>"
     if N % 144 == 0:
         regepi = int(os.environ.get("PRIMX_GEMM_REGEPI", "0") == "1")
         return f"gemm144_dma_kernel<{dt}, {epi}, {regepi}>" if K % 64 == 0 else f"gemm144_kernel<{dt}, {epi}, 1>"
