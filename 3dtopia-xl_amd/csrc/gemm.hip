@@ -645,13 +645,14 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
                            : p.W + (int64_t)(n0 + row - BM) * p.K + c * 8;
     }
     const bool last_slot = wave + 8 * (NSLOT - 1) < NINST;  // wave-uniform
+    auto issue_one = [&](int kt, int stage, int i) {        // instruction t = wave + 8 i lands at stage + t * 1 KiB
+        if (i < NSLOT - 1 || last_slot)
+            __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + kt * BK),
+                                             (LV*)(smem + stage * STAGE + wave * 512 + i * 8 * 512), 16, 0, 0);
+    };
     auto issue = [&](int kt, int stage) {
-        S* base = smem + stage * STAGE + wave * 512;        // instruction t lands at stage + t * 1 KiB
 #pragma unroll
-        for (int i = 0; i < NSLOT; ++i) {
-            if (i < NSLOT - 1 || last_slot)
-                __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + kt * BK), (LV*)(base + i * 8 * 512), 16, 0, 0);
-        }
+        for (int i = 0; i < NSLOT; ++i) issue_one(kt, stage, i);
     };
 
     f32x4 acc[MI][NI];
@@ -722,9 +723,11 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
         // vmcnt(4): tile kt+1 landed for this wave (tile kt+2 may stay in flight); lgkmcnt(0): this wave's reads of
         // tile kt's stage have completed, so after the barrier that stage can be overwritten by the DMA below
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // (Spreading these DMA issues between the MFMA groups, which pays in the 256x288 kernel, measured worse here:
+        // main loop 78.2k -> 81.8k cycles at K = 4608.)
         issue(min(kt + 3, nk - 1), st_cur);
-        read_frags(st_next, an, bn);
-        multiply(ac, bc);
+        if (p.prof != 2) read_frags(st_next, an, bn);   // prof == 2 / 3: DMA-only / DMA + LDS reads (bound probes, results wrong)
+        if (p.prof < 2) multiply(ac, bc);
         st_cur = st_next;
         st_next = (st_next == 2) ? 0 : st_next + 1;
     };
@@ -760,14 +763,13 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     // EPI_HEADS fast path: the tile lies inside ONE (repetition, segment), so everything that needs a division is
     // tile-uniform and computed once on the scalar unit; per unit only compares remain (the generic
     // epilogue_row4 does five integer divisions per unit: +2.5 us per round, PRIMX_GEMM_PROF).
-    int h_hh0 = 0, h_dd0 = 0, h_bb0 = 0, h_tok0 = 0, h_rs = 0, h_seg = 0, h_rep = 0;
+    int h_hh0 = 0, h_dd0 = 0, h_bb0 = 0, h_tok0 = 0, h_rs = 0, h_seg = 0;
     S* h_dst = nullptr;
     bool h_fast = false;
     if (EPI == EPI_HEADS) {
         h_fast = p.dh >= 48 && (p.dh & 3) == 0 && p.rows_per_batch >= BM;
         const int per = p.heads * p.dh;
         const int seg_all = n0 / per, rep_i = seg_all / p.n_seg;
-        h_rep = rep_i;
         h_seg = seg_all - rep_i * p.n_seg;
         const int w0 = n0 - seg_all * per;
         h_hh0 = w0 / p.dh;
@@ -1253,10 +1255,11 @@ static const bool g_big_q = [] {   // PRIMX_GEMM_BIGQ=0: 256x288 kernel with the
     return !(e && e[0] == '0');
 }();
 
-static const bool g_gemm_prof_on = [] {   // PRIMX_GEMM_PROF=1: synchronous launches of the 128x144 LDS-DMA kernel + timeline print
-    const char* e = getenv("PRIMX_GEMM_PROF");
-    return e && e[0] == '1';
+static const int g_gemm_prof_mode = [] {   // PRIMX_GEMM_PROF=1: synchronous launches + timeline print; 2: without MFMAs and
+    const char* e = getenv("PRIMX_GEMM_PROF");   // fragment reads (DMA-only bound probe); 3: without MFMAs
+    return e ? atoi(e) : 0;
 }();
+static const bool g_gemm_prof_on = g_gemm_prof_mode != 0;
 
 template <int DT, int EPI, int BIG = 0>
 void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
@@ -1272,7 +1275,7 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
         return;
     }
     GemmArgs<DT> b = a;
-    b.prof = 1;
+    b.prof = g_gemm_prof_mode;
     unsigned long long z[12] = {~0ull, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, r[12];
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof(z));
     hipEvent_t e0, e1;

@@ -1,3 +1,7 @@
 #!/bin/bash
-timeout 900 python -m pytest tests -m gpu -q -x -p no:cacheprovider 2>&1 | tail -2
-for v in 1 0 1; do echo "--- bench BIGQ=$v"; PRIMX_GEMM_BIGQ=$v timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], {k[:24]: round(v['ms_per_step'],3) for k,v in d['kernels'].items()})"; done
+timeout 900 python -m pytest tests/test_hip_gemm.py tests/test_hip_dit.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -2
+PRIMX_GEMM_PROF=1 ONLY=proj,fc2 REPS=3 timeout 120 python tools/gemm_bench.py 2>&1 | grep -v amdgpu | grep "gemm144_dma" | awk 'NR%6==5'
+for r in 1 2; do
+echo "--- new"; REPS=100 ONLY=proj,fc2,qkv,kv timeout 120 python tools/gemm_bench.py 2>&1 | grep -v amdgpu | tail -4
+echo "--- prev"; (cd prev_tree && REPS=100 ONLY=proj,fc2,qkv,kv timeout 120 python tools/gemm_bench.py 2>&1 | grep -v amdgpu | tail -4)
+done
