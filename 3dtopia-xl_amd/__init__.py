@@ -10,7 +10,7 @@ library, calling any op does.
 """
 from .diffusion import create_diffusion, GaussianDiffusion, SpacedDiffusion, space_timesteps  # noqa: F401
 
-__all__ = ["create_diffusion", "GaussianDiffusion", "SpacedDiffusion", "space_timesteps", "DiT", "VAE",
+__all__ = ["create_diffusion", "GaussianDiffusion", "SpacedDiffusion", "space_timesteps", "DiT", "DiTAdditivePosEmb", "VAE",
            "memory_efficient_attention"]
 
 
@@ -18,6 +18,9 @@ def __getattr__(name):  # lazy: torch.nn modules are only built when asked for
     if name == "DiT":
         from .dit import DiT
         return DiT
+    if name == "DiTAdditivePosEmb":
+        from .dit import DiTAdditivePosEmb
+        return DiTAdditivePosEmb
     if name == "VAE":
         from .vae import VAE
         return VAE

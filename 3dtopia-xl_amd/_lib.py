@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PRIMX_LIB") or os.path.join(_HERE, "csrc", "libprimx_
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH = 0, 1
 HEADS_ROWS, HEADS_VT, HEADS_KROWS = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -26,6 +26,7 @@ SIGNATURES = {
     "primx_padded_head_dim": [_i],
     "primx_layernorm_modulate": [_p, _p, _p, _l, _p, _i, _i, _i, _i, _f, _p],
     "primx_timestep_embedding": [_p, _p, _p, _i, _i, _p],
+    "primx_point_features": [_p, _l, _p, _p, _l, _i, _i, _p],
     "primx_silu_cast": [_p, _p, _i, _l, _p],
     "primx_cast16": [_p, _p, _i, _l, _p],
     "primx_linear_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _p],

@@ -206,6 +206,36 @@ extern "C" int primx_timestep_embedding(const int64_t* t, const float* freqs, fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// PointEmbed features (dit_crossattn.py:80-108): point p = x[t, 1:4]; proj[3*d' .. ] = p_d * basis_d[k] with the
+// block-diagonal 3 x 3F basis (basis_d[k] = 2^k * pi); features = [sin(proj) (3F), cos(proj) (3F), p (3)].
+__global__ void point_features_kernel(const float* __restrict__ x, int64_t row_stride, const float* __restrict__ freqs,
+                                      float* __restrict__ feat, int64_t feat_stride, int T, int F) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = 3 * F;
+    if (idx >= T * per) return;
+    const int t = idx / per, c = idx - t * per;
+    const int d = c / F, k = c - d * F;
+    const float p = x[(int64_t)t * row_stride + 1 + d];
+    const float arg = p * freqs[k];                     // einsum('bnd,de->bne') with one non-zero term per column
+    float* row = feat + (int64_t)t * feat_stride;
+    row[c] = sinf(arg);
+    row[per + c] = cosf(arg);
+    if (k == 0) row[2 * per + d] = p;
+}
+
+extern "C" int primx_point_features(const float* x, int64_t row_stride, const float* freqs, float* feat,
+                                    int64_t feat_stride, int T, int F, void* stream) {
+    PRIMX_REQUIRE(x && freqs && feat, "primx_point_features: null pointer");
+    PRIMX_REQUIRE(T > 0 && F > 0 && row_stride >= 4 && feat_stride >= 6 * F + 3,
+                  "primx_point_features: need T, F > 0, at least 4 channels per token and feat_stride >= 6F+3");
+    const int n = T * 3 * F;
+    hipLaunchKernelGGL(point_features_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, row_stride,
+                       freqs, feat, feat_stride, T, F);
+    PRIMX_CHECK_LAUNCH("primx_point_features");
+    return PRIMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 template <int DT>
 __global__ void silu_cast_kernel(const float* __restrict__ in, typename T16<DT>::S* __restrict__ out, int64_t n) {
     using S = typename T16<DT>::S;

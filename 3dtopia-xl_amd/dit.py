@@ -23,6 +23,7 @@ runs at 1/16 rate (out of scope for this round).
 """
 from __future__ import annotations
 
+import math
 from typing import Dict, Optional
 
 import torch
@@ -229,9 +230,7 @@ class DiT(nn.Module):
         pk = self.packed(dt)
         dev = x.device
 
-        # fp32, outside autocast in the reference (dit_crossattn.py:191-192)
-        h = ops.linear_f32(x.reshape(T, Cin).float().contiguous(), self.x_embedder.weight.detach(),
-                           self.x_embedder.bias.detach())
+        h = self._embed_tokens(x.reshape(T, Cin).float().contiguous())
         t_emb = self.t_embedder(t)
         # adaLN for every block + final layer: SiLU -> one streaming GEMM (dit_crossattn.py:40-43,54,69-75)
         mod = ops.linear(ops.silu_cast(t_emb, dt), pk["w_ada"], pk["b_ada"])  # [Be, depth*9D + 2D]
@@ -280,6 +279,10 @@ class DiT(nn.Module):
         out = ops.linear(xn, pk["w_final"], pk["b_final"])
         return out.view(Be, N, self.out_channels)
 
+    def _embed_tokens(self, xf: torch.Tensor) -> torch.Tensor:
+        """[T, C] fp32 -> [T, D] fp32, outside autocast in the reference (dit_crossattn.py:191-192)."""
+        return ops.linear_f32(xf, self.x_embedder.weight.detach(), self.x_embedder.bias.detach())
+
     def forward_with_cfg(self, x, t, y, cfg_scale=0.0, precision_dtype=torch.float32, enable_amp=False):
         """Classifier-free guidance: one forward at 2B, combine on all channels, return the B-sized half
         (dit_crossattn.py:204-213)."""
@@ -289,3 +292,43 @@ class DiT(nn.Module):
         combined_y = torch.cat([y, y_null], dim=0)
         model_out = self.forward(combined, combined_t, combined_y, precision_dtype, enable_amp)
         return ops.cfg_combine(model_out.contiguous(), float(cfg_scale))
+
+
+class PointEmbed(nn.Module):
+    """Fourier features of the primitive position -> Linear (models/dit_crossattn.py:80-108).  Parameter container with
+    the reference's buffer (`basis`, 3 x hidden_dim/2, block-diagonal 2^k pi) and `mlp` Linear(hidden_dim + 3, dim)."""
+
+    def __init__(self, hidden_dim=48, dim=128):
+        super().__init__()
+        assert hidden_dim % 6 == 0
+        self.embedding_dim = hidden_dim
+        n = hidden_dim // 6
+        e = torch.pow(2, torch.arange(n)).float() * math.pi
+        z = torch.zeros(n)
+        self.register_buffer("basis", torch.stack([torch.cat([e, z, z]), torch.cat([z, e, z]), torch.cat([z, z, e])]))
+        self.mlp = nn.Linear(hidden_dim + 3, dim)
+
+
+class DiTAdditivePosEmb(DiT):
+    """The reference's second DiT class (models/dit_crossattn.py:215-301): token embedding = x_embedder(x) +
+    point_emb(x[:, :, 1:4]); no condition dropout, hence no `null_cond_embedding` and no `forward_with_cfg`."""
+
+    def __init__(self, seq_length=2, in_channels=4, condition_channels=512, hidden_size=1152, depth=28, num_heads=16,
+                 mlp_ratio=4.0, attn_proj_bias=False, learn_sigma=True, gradient_checkpointing=False):
+        super().__init__(seq_length=seq_length, in_channels=in_channels, condition_channels=condition_channels,
+                         hidden_size=hidden_size, depth=depth, num_heads=num_heads, mlp_ratio=mlp_ratio,
+                         cond_drop_prob=0.0, attn_proj_bias=attn_proj_bias, learn_sigma=learn_sigma,
+                         gradient_checkpointing=gradient_checkpointing)
+        self.point_emb = PointEmbed(hidden_dim=48, dim=hidden_size)
+
+    def _embed_tokens(self, xf: torch.Tensor) -> torch.Tensor:
+        pe = self.point_emb
+        n = pe.embedding_dim // 6
+        feat = ops.point_features(xf, pe.basis[0, :n].contiguous())       # the non-zero entries of the block-diagonal basis
+        w = pe.mlp.weight.detach()
+        w = torch.nn.functional.pad(w, (0, feat.shape[1] - w.shape[1]))   # K padded like the features (zero column)
+        return (ops.linear_f32(xf, self.x_embedder.weight.detach(), self.x_embedder.bias.detach()) +
+                ops.linear_f32(feat, w.contiguous(), pe.mlp.bias.detach()))
+
+    def forward_with_cfg(self, *args, **kwargs):
+        raise AttributeError("the reference's DiTAdditivePosEmb defines no forward_with_cfg (dit_crossattn.py:215-301)")

@@ -120,6 +120,18 @@ def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -
     return out
 
 
+def point_features(x: torch.Tensor, freqs: torch.Tensor) -> torch.Tensor:
+    """x: [T, C>=4] fp32 token rows (point = channels 1..3), freqs: [F] fp32 -> PointEmbed features [T, 6F+3], returned
+    zero-padded to a multiple of 4 columns (the K granularity of primx_linear_f32)."""
+    T, F = x.shape[0], freqs.shape[0]
+    if x.stride(1) != 1:
+        raise RuntimeError("point_features: channels must be contiguous")
+    out = torch.zeros(T, round_up(6 * F + 3, 4), dtype=torch.float32, device=x.device)
+    check(_lib.load().primx_point_features(_dev(x, "x", torch.float32), x.stride(0), _dev(freqs, "freqs", torch.float32),
+                                           out.data_ptr(), out.stride(0), T, F, _stream()), "primx_point_features")
+    return out
+
+
 def silu_cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     out = torch.empty(x.shape, dtype=dtype, device=x.device)
     check(_lib.load().primx_silu_cast(_dev(x, "x", torch.float32), out.data_ptr(), dtype_code(dtype), x.numel(),

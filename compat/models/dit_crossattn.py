@@ -1,1 +1,1 @@
-from topia_xl_amd.dit import DiT, DiTBlock, FinalLayer  # noqa: F401
+from topia_xl_amd.dit import DiT, DiTAdditivePosEmb, DiTBlock, FinalLayer, PointEmbed  # noqa: F401

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 8
+#define PRIMX_ABI_VERSION 9
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -75,6 +75,12 @@ int primx_layernorm_modulate(const float* x, const void* shift, const void* scal
  * moving it to the device (models/utils.py:51-54); the product and the sin/cos run here in fp32.
  * Replaces TimestepEmbedder.timestep_embedding, models/utils.py:40-59 (dim even). */
 int primx_timestep_embedding(const int64_t* t, const float* freqs, float* emb, int B, int dim, void* stream);
+
+/* PointEmbed features of the DiTAdditivePosEmb variant (models/dit_crossattn.py:80-108, 283-285): for token t with
+ * point p = x[t*row_stride + 1 .. 3] writes feat[t*feat_stride + :] = [sin(p_d * freqs[k]) (d-major, 3F), cos(...) (3F), p (3)]
+ * (freqs[k] = 2^k * pi, the non-zero entries of the reference's block-diagonal `basis` buffer). */
+int primx_point_features(const float* x, int64_t row_stride, const float* freqs, float* feat, int64_t feat_stride, int T,
+                         int F, void* stream);
 
 /* out = cast16( silu(in) ) elementwise.  The SiLU in front of every adaLN Linear
  * (models/dit_crossattn.py:40-43,69-72) producing the 16-bit GEMM operand. */

@@ -108,12 +108,22 @@ def dit_block(sd: Dict[str, Tensor], i: int, x: Tensor, y: Tensor, t_emb: Tensor
     return x
 
 
+def point_embed(sd: Dict[str, Tensor], point: Tensor) -> Tensor:
+    """PointEmbed.forward (dit_crossattn.py:99-108): projections = point @ basis (3 x 24, block diagonal 2^k pi),
+    features = [sin, cos, point] -> Linear(51, D).  fp32, outside autocast."""
+    proj = torch.einsum("bnd,de->bne", point, sd["point_emb.basis"])
+    feat = torch.cat([proj.sin(), proj.cos(), point], dim=2)
+    return F.linear(feat, sd["point_emb.mlp.weight"], sd["point_emb.mlp.bias"])
+
+
 def dit_forward(sd: Dict[str, Tensor], x: Tensor, t: Tensor, y: Tensor, num_heads: int,
                 emulate: Optional[torch.dtype] = None) -> Tensor:
     """DiT.forward in eval mode (dit_crossattn.py:184-202).  Returns fp32 holding 16-bit-representable
     values when ``emulate`` is set."""
     depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
     h = F.linear(x.float(), sd["x_embedder.weight"], sd["x_embedder.bias"])  # fp32, outside autocast
+    if "point_emb.mlp.weight" in sd:   # DiTAdditivePosEmb (dit_crossattn.py:283-285) + PointEmbed (80-108)
+        h = h + point_embed(sd, x.float()[:, :, 1:4])
     te = timestep_embedding(t)
     te = F.linear(F.silu(F.linear(te, sd["t_embedder.mlp.0.weight"], sd["t_embedder.mlp.0.bias"])),
                   sd["t_embedder.mlp.2.weight"], sd["t_embedder.mlp.2.bias"])

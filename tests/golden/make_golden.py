@@ -92,6 +92,24 @@ def gen_dit(dit_mod, diffusion_pkg):
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
+def gen_dit_addpos(dit_mod):
+    """The second DiT class of the reference file (DiTAdditivePosEmb, dit_crossattn.py:215-301)."""
+    cfg = dict(in_channels=68, condition_channels=64, hidden_size=288, depth=2)
+    N, L, B, heads = 96, 37, 2, 4
+    model = dit_mod.DiTAdditivePosEmb(seq_length=N, num_heads=heads, attn_proj_bias=True, **cfg).eval()
+    sd = synth.state_dict_like(SEED, model.state_dict())
+    sd["point_emb.basis"] = model.point_emb.basis.clone()            # a constant buffer, not a weight
+    model.load_state_dict(sd, strict=True)
+    x = synth.tensor(SEED, "addpos.x", (B, N, cfg["in_channels"]))
+    y = synth.tensor(SEED, "addpos.y", (B, L, cfg["condition_channels"]))
+    t = torch.tensor([960, 40], dtype=torch.int64)
+    with torch.no_grad():
+        out = model(x, t, y).numpy()
+        pe = model.point_emb(x[:, :, 1:4]).numpy()
+    np.savez_compressed(os.path.join(HERE, "dit_addpos.npz"), forward=out, point_emb=pe, seed=np.int64(SEED),
+                        keys=np.array(sorted(sd.keys())))
+
+
 def gen_attention(att_mod):
     out = {}
     with torch.no_grad():
@@ -128,6 +146,7 @@ def main():
     gen_schedule(diffusion_pkg)
     gen_dit(dit_mod, diffusion_pkg)
     gen_attention(att_mod)
+    gen_dit_addpos(dit_mod)
     gen_vae(vae_mod)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

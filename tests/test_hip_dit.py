@@ -159,3 +159,21 @@ def test_sharded_sampler_single_rank_matches_plain_loop(pkg):
     want = d.ddim_sample_loop(m.forward_with_cfg, (B, N, Cc), noise=noise.to(DEV), clip_denoised=False,
                               model_kwargs=dict(y=y.to(DEV), **kw))
     assert out.shape == (B, N, Cc) and torch.equal(out.cpu(), want.cpu())
+
+
+def test_additive_pos_emb_variant(pkg, golden):
+    """DiTAdditivePosEmb (the second class of models/dit_crossattn.py): HIP forward vs the REAL reference (fp32 golden)
+    and vs the oracle with emulated rounding; no forward_with_cfg, as in the reference."""
+    from tests.test_oracle_golden import _addpos_case
+    g = golden("dit_addpos")
+    m, sd, heads, x, y, t = _addpos_case(pkg.DiTAdditivePosEmb)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV)
+    for dtype in (torch.float16, torch.bfloat16):
+        out = m(x.to(DEV), t.to(DEV), y.to(DEV), precision_dtype=dtype, enable_amp=True)
+        assert out.shape == (2, 96, 136) and out.dtype == dtype
+        assert rel_l2(out, g["forward"]) < TOL_FWD[dtype], rel_l2(out, g["forward"])
+        emu = dit_ref.dit_forward(sd, x, t, y, heads, emulate=dtype)
+        assert rel_l2(out, emu) < TOL_EMU[dtype], rel_l2(out, emu)
+    with pytest.raises(AttributeError):
+        m.forward_with_cfg(x.to(DEV), t.to(DEV), y.to(DEV), cfg_scale=6.0)

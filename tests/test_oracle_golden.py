@@ -117,3 +117,32 @@ def test_vae_decode_matches_reference(golden):
     out = vae_ref.vae_decode(sd, z, VAE_CFG["up_channels"], VAE_CFG["layers_per_block"])
     assert out.shape == (3, 6, 8, 8, 8) and np.abs(g["decoded"]).max() > 0.05
     _close(out, g["decoded"], atol=2e-5)
+
+
+def _addpos_case(module_cls):
+    """State dict exactly as tests/golden/make_golden.py:gen_dit_addpos built it (key set taken from the module)."""
+    cfg = dict(in_channels=68, condition_channels=64, hidden_size=288, depth=2)
+    N, L, B, heads = 96, 37, 2, 4
+    m = module_cls(seq_length=N, num_heads=heads, attn_proj_bias=True, **cfg).eval()
+    sd = synth.state_dict_like(SEED, m.state_dict())
+    sd["point_emb.basis"] = m.point_emb.basis.clone()
+    x = synth.tensor(SEED, "addpos.x", (B, N, cfg["in_channels"]))
+    y = synth.tensor(SEED, "addpos.y", (B, L, cfg["condition_channels"]))
+    t = torch.tensor([960, 40], dtype=torch.int64)
+    return m, sd, heads, x, y, t
+
+
+def test_dit_additive_pos_emb_matches_reference(golden):
+    """DiTAdditivePosEmb (dit_crossattn.py:215-301): the module mirror has the reference's key set and the oracle
+    restatement (point embedding + the shared block stack) reproduces the real reference's output."""
+    from topia_xl_amd.dit import DiTAdditivePosEmb
+    g = golden("dit_addpos")
+    m, sd, heads, x, y, t = _addpos_case(DiTAdditivePosEmb)
+    assert sorted(sd.keys()) == list(g["keys"])                      # strict checkpoint compatibility
+    m.load_state_dict(sd, strict=True)
+    assert not hasattr(m, "null_cond_embedding")
+    with torch.no_grad():
+        pe = dit_ref.point_embed(sd, x[:, :, 1:4])
+        out = dit_ref.dit_forward(sd, x, t, y, heads)
+    _close(pe.numpy(), g["point_emb"], 2e-5)
+    _close(out.numpy(), g["forward"], 2e-4)
