@@ -97,6 +97,8 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+
 // Dispatch a 16-bit dtype code to a template instantiation.
 #define PRIMX_DISPATCH_16(dtype, NAME, ...)                                  \
     do {                                                                     \

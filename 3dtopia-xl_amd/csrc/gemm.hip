@@ -148,6 +148,7 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs<DT>& p, const ColIn
             if (m >= p.M) continue;
             float y = rnd16<DT>(a[j] + c.bias);
             if (p.act == PRIMX_ACT_GELU_TANH) y = rnd16<DT>(gelu_tanh_f(y));
+            else if (p.act == PRIMX_ACT_GELU_ERF) y = rnd16<DT>(gelu_erf_f(y));
             if (p.out_scale != 1.0f) y = rnd16<DT>(p.out_scale * y);
             p.out[(int64_t)m * p.N + n] = (S)y;
         }
@@ -250,6 +251,7 @@ __device__ __forceinline__ void epilogue_row4(const GemmArgs<DT>& p, int m, int 
         for (int j = 0; j < 4; ++j) {
             float y = rnd16<DT>(a[j] + b[j]);
             if (p.act == PRIMX_ACT_GELU_TANH) y = rnd16<DT>(gelu_tanh_f(y));
+            else if (p.act == PRIMX_ACT_GELU_ERF) y = rnd16<DT>(gelu_erf_f(y));
             if (p.out_scale != 1.0f) y = rnd16<DT>(p.out_scale * y);
             o[j] = (S)y;
         }
@@ -1346,7 +1348,7 @@ int ilog2_exact(int v) {
 extern "C" int primx_linear(const void* A, const void* W, const void* bias, void* out, int M, int N, int K, int dtype,
                             int act, float out_scale, void* stream) {
     PRIMX_REQUIRE(out, "primx_linear: null output");
-    PRIMX_REQUIRE(act == PRIMX_ACT_NONE || act == PRIMX_ACT_GELU_TANH, "primx_linear: bad activation code");
+    PRIMX_REQUIRE(act == PRIMX_ACT_NONE || act == PRIMX_ACT_GELU_TANH || act == PRIMX_ACT_GELU_ERF, "primx_linear: bad activation code");
     PRIMX_DISPATCH_16(dtype, "primx_linear", {
         using S = typename T16<DT>::S;
         GemmArgs<DT> a = {};

@@ -206,6 +206,38 @@ extern "C" int primx_timestep_embedding(const int64_t* t, const float* freqs, fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// ViT token assembly (DINOv2 prepare_tokens_with_masks): [cls + pos0 | registers | patches + pos]
+__global__ void vit_tokens_kernel(const float* __restrict__ patches, const float* __restrict__ cls,
+                                  const float* __restrict__ pos, const float* __restrict__ reg, float* __restrict__ out,
+                                  int B, int np, int R, int D) {
+    const int nt = 1 + R + np;
+    const int64_t total = (int64_t)B * nt * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int64_t r = i / D;
+        const int tok = (int)(r % nt), b = (int)(r / nt);
+        float v;
+        if (tok == 0) v = cls[d] + pos[d];
+        else if (tok <= R) v = reg[(tok - 1) * D + d];
+        else v = patches[((int64_t)b * np + (tok - 1 - R)) * D + d] + pos[(int64_t)(tok - R) * D + d];
+        out[i] = v;
+    }
+}
+
+extern "C" int primx_vit_tokens(const float* patches, const float* cls, const float* pos, const float* reg, float* out,
+                                int B, int np, int R, int D, void* stream) {
+    PRIMX_REQUIRE(patches && cls && pos && out && (R == 0 || reg), "primx_vit_tokens: null pointer");
+    PRIMX_REQUIRE(B > 0 && np > 0 && R >= 0 && D > 0, "primx_vit_tokens: empty problem");
+    const int64_t total = (int64_t)B * (1 + R + np) * D;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(vit_tokens_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, patches, cls, pos, reg, out, B,
+                       np, R, D);
+    PRIMX_CHECK_LAUNCH("primx_vit_tokens");
+    return PRIMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // PointEmbed features (dit_crossattn.py:80-108): point p = x[t, 1:4]; proj[3*d' .. ] = p_d * basis_d[k] with the
 // block-diagonal 3 x 3F basis (basis_d[k] = 2^k * pi); features = [sin(proj) (3F), cos(proj) (3F), p (3)].
 __global__ void point_features_kernel(const float* __restrict__ x, int64_t row_stride, const float* __restrict__ freqs,

@@ -382,3 +382,17 @@ def latent_denorm(x: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, nf: fl
                                           _dev(std, "std", torch.float32), float(nf), srt.data_ptr(), z.data_ptr(),
                                           rows, C, n_srt, _stream()), "primx_latent_denorm")
     return srt, z
+
+
+# ----------------------------------------------------------------------------- DINOv2 conditioner pieces
+def vit_tokens(patches: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, reg: Optional[torch.Tensor]) -> torch.Tensor:
+    """patches [B, np, D], cls [D], pos [1+np, D], reg [R, D] or None (all fp32) -> tokens [B, 1+R+np, D] fp32
+    (dinov2/models/vision_transformer.py:218-236)."""
+    B, npatch, D = patches.shape
+    R = 0 if reg is None else reg.shape[0]
+    out = torch.empty(B, 1 + R + npatch, D, dtype=torch.float32, device=patches.device)
+    check(_lib.load().primx_vit_tokens(_dev(patches, "patches", torch.float32), _dev(cls, "cls", torch.float32),
+                                       _dev(pos, "pos", torch.float32),
+                                       _dev(reg, "reg", torch.float32) if reg is not None else None, out.data_ptr(), B,
+                                       npatch, R, D, _stream()), "primx_vit_tokens")
+    return out

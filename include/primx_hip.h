@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 9
+#define PRIMX_ABI_VERSION 10
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -43,6 +43,7 @@ extern "C" {
 /* activation codes for primx_linear */
 #define PRIMX_ACT_NONE 0
 #define PRIMX_ACT_GELU_TANH 1
+#define PRIMX_ACT_GELU_ERF 2  /* nn.GELU() exact form (DINOv2 Mlp) */
 
 /* head-layout kinds for primx_linear_heads / primx_pack_heads */
 #define PRIMX_HEADS_ROWS 0 /* [B, H, n_pad, DP]  token-major rows, head dim zero-padded to DP   */
@@ -79,6 +80,11 @@ int primx_timestep_embedding(const int64_t* t, const float* freqs, float* emb, i
 /* PointEmbed features of the DiTAdditivePosEmb variant (models/dit_crossattn.py:80-108, 283-285): for token t with
  * point p = x[t*row_stride + 1 .. 3] writes feat[t*feat_stride + :] = [sin(p_d * freqs[k]) (d-major, 3F), cos(...) (3F), p (3)]
  * (freqs[k] = 2^k * pi, the non-zero entries of the reference's block-diagonal `basis` buffer). */
+/* ViT token assembly of the DINOv2 conditioner (dinov2/models/vision_transformer.py:218-236): fp32
+ * out[b, 0] = cls + pos[0];  out[b, 1 + r] = reg[r] (r < R, no positional term);  out[b, 1 + R + i] = patches[b, i] + pos[1 + i]. */
+int primx_vit_tokens(const float* patches, const float* cls, const float* pos, const float* reg, float* out, int B, int np,
+                     int R, int D, void* stream);
+
 int primx_point_features(const float* x, int64_t row_stride, const float* freqs, float* feat, int64_t feat_stride, int T,
                          int F, void* stream);
 

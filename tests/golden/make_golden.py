@@ -110,6 +110,42 @@ def gen_dit_addpos(dit_mod):
                         keys=np.array(sorted(sd.keys())))
 
 
+DINO_CFG = dict(img_size=56, patch_size=14, embed_dim=96, depth=2, num_heads=3, mlp_ratio=4, init_values=1.0,
+                num_register_tokens=4, interpolate_antialias=True, interpolate_offset=0.0, block_chunks=0)
+
+
+def dino_state_dict(reference_sd):
+    """Synthetic DINOv2 weights: LayerScale gammas O(1) like the released checkpoints (init 1.0, trained), tokens and the
+    positional table ~ N(0, 0.5), everything else as synth.state_dict_like."""
+    sd = synth.state_dict_like(SEED, reference_sd)
+    for k in reference_sd:
+        if k.endswith(".gamma"):
+            sd[k] = synth.tensor(SEED, k, tuple(reference_sd[k].shape), 0.3, 1.0)
+        elif k in ("cls_token", "pos_embed", "register_tokens"):
+            sd[k] = synth.tensor(SEED, k, tuple(reference_sd[k].shape), 0.5)
+    return sd
+
+
+def gen_dinov2():
+    """The vendored DINOv2 of the reference (models/conditioner/dinov2), small configuration, two image sizes: the
+    training resolution (positional table used as is) and a larger one (bicubic resampling of the table)."""
+    import importlib
+    vt = importlib.import_module("models.conditioner.dinov2.models.vision_transformer")
+    model = vt.DinoVisionTransformer(**DINO_CFG).eval()
+    sd = dino_state_dict(model.state_dict())
+    model.load_state_dict(sd, strict=True)
+    out = {"keys": np.array(sorted(sd.keys())), "seed": np.int64(SEED)}
+    with torch.no_grad():
+        for tag, size in (("native", 56), ("resampled", 84)):
+            x = synth.tensor(SEED, f"dino.x.{size}", (2, 3, size, size))
+            ret = model(x, is_training=True)
+            out[f"{tag}_cls"] = ret["x_norm_clstoken"].numpy()
+            out[f"{tag}_reg"] = ret["x_norm_regtokens"].numpy()
+            out[f"{tag}_patch"] = ret["x_norm_patchtokens"].numpy()
+            out[f"{tag}_prenorm"] = ret["x_prenorm"].numpy()
+    np.savez_compressed(os.path.join(HERE, "dinov2.npz"), **out)
+
+
 def gen_attention(att_mod):
     out = {}
     with torch.no_grad():
@@ -147,6 +183,7 @@ def main():
     gen_dit(dit_mod, diffusion_pkg)
     gen_attention(att_mod)
     gen_dit_addpos(dit_mod)
+    gen_dinov2()
     gen_vae(vae_mod)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
