@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 10
+#define PRIMX_ABI_VERSION 11
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -228,6 +228,17 @@ int primx_vae_output(const void* in, float* out, int P, int V, int C, int denorm
  * Replaces inference.py:328-332 / app.py:119-123. */
 int primx_latent_denorm(const float* x, const float* mean, const float* stdv, float nf, float* srt, float* z,
                         int64_t rows, int C, int n_srt, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * PrimSDF field query (models/primsdf.py:52-109; inference.py:106-116, 180-193)
+ * -------------------------------------------------------------------------------------------- */
+
+/* pts [n, 3] fp32 query points; srt [P, 4] = (scale, x, y, z) per primitive (`srt_param`); feat [P, C * S^3]
+ * (`feat_param`, channel-major [C][z][y][x]); lin [S] = torch.linspace(-1, 1, S) (the local grid of the nearest-voxel
+ * fallback); out [n, C] = [sdf, clip(tex, 0, 1) x 3, clip(mat, 0, 1) x 2].  eval_fill != 0 applies the inference-time
+ * fill of points no primitive covers (primsdf.py:78-100). */
+int primx_primsdf_query(const float* pts, const float* srt, const float* feat, const float* lin, float* out, int n, int P,
+                        int S, int C, int eval_fill, void* stream);
 
 #ifdef __cplusplus
 }

@@ -146,6 +146,41 @@ def gen_dinov2():
     np.savez_compressed(os.path.join(HERE, "dinov2.npz"), **out)
 
 
+PRIMSDF_CFG = dict(num_prims=48, dim_feat=6, prim_shape=8)
+
+
+def primsdf_params():
+    """Fitted-primitive-like parameters: centres in [-0.7, 0.7]^3, half-extents 0.15..0.4 (overlapping, yet leaving part
+    of [-1, 1]^3 uncovered so that the nearest-voxel fill is exercised), SDF payload of both signs, tex / mat partly
+    outside [0, 1] (clipping)."""
+    P, S = PRIMSDF_CFG["num_prims"], PRIMSDF_CFG["prim_shape"]
+    srt = torch.cat([0.15 + 0.25 * synth.tensor(SEED, "psdf.scale", (P, 1)).abs().clamp(max=1.0),
+                     0.7 * torch.tanh(synth.tensor(SEED, "psdf.pos", (P, 3)))], dim=1)
+    feat = synth.tensor(SEED, "psdf.feat", (P, 6 * S ** 3), 0.6, 0.3)
+    pts = 2.0 * torch.rand(4000, 3, generator=torch.Generator().manual_seed(SEED)) - 1.0
+    return srt, feat, pts
+
+
+def gen_primsdf():
+    """models/primsdf.py:PrimSDF.forward in eval and train mode (trimesh, imported at module top and unused by forward,
+    is stubbed)."""
+    import importlib
+    import types
+    sys.modules.setdefault("trimesh", types.ModuleType("trimesh"))
+    mod = importlib.import_module("models.primsdf")
+    m = mod.PrimSDF(**PRIMSDF_CFG)
+    srt, feat, pts = primsdf_params()
+    m.srt_param.data, m.feat_param.data = srt.clone(), feat.clone()
+    out = {"seed": np.int64(SEED)}
+    with torch.no_grad():
+        for tag in ("eval", "train"):
+            m.train(tag == "train")
+            pr = m(pts)
+            out[f"{tag}_sdf"], out[f"{tag}_tex"], out[f"{tag}_mat"] = pr["sdf"].numpy(), pr["tex"].numpy(), pr["mat"].numpy()
+        out["covered"] = (m.prim_weight(pts).sum(1) > 0).numpy()
+    np.savez_compressed(os.path.join(HERE, "primsdf.npz"), **out)
+
+
 def gen_attention(att_mod):
     out = {}
     with torch.no_grad():
@@ -184,6 +219,7 @@ def main():
     gen_attention(att_mod)
     gen_dit_addpos(dit_mod)
     gen_dinov2()
+    gen_primsdf()
     gen_vae(vae_mod)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

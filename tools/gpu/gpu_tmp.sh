@@ -1,2 +1,2 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_hip_dinov2.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -12
+timeout 900 python -m pytest tests/test_primsdf.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -6
