@@ -46,3 +46,34 @@ def latents_to_primitives(samples: torch.Tensor, vae, latent_mean: Optional[Sequ
     dec = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
     feat = dec.reshape(B, N, -1)
     return torch.cat([srt, feat], dim=-1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# On-disk formats of the hot path: the two checkpoints the CLI loads and the `denoised.pt`
+# it writes between sampling and mesh extraction.
+def load_checkpoints(model=None, vae=None, dit_checkpoint_path: Optional[str] = None,
+                     vae_checkpoint_path: Optional[str] = None) -> None:
+    """`model.load_state_dict(torch.load(p)['ema'])` / `vae.load_state_dict(torch.load(p)['model_state_dict'])`, strict,
+    as inference.py:257-262 does (fp16 `.pt` files load into the fp32 parameters; the packed 16-bit copies the kernels
+    read are rebuilt lazily on the first forward)."""
+    if model is not None and dit_checkpoint_path:
+        model.load_state_dict(torch.load(dit_checkpoint_path, map_location="cpu")["ema"], strict=True)
+    if vae is not None and vae_checkpoint_path:
+        vae.load_state_dict(torch.load(vae_checkpoint_path, map_location="cpu")["model_state_dict"], strict=True)
+
+
+def save_denoised(path: str, recon_param: torch.Tensor, index: int = 0) -> None:
+    """`{'model_state_dict': {'srt_param': [N, 4], 'feat_param': [N, 6 * 8^3]}}` of sample `index` (inference.py:351-352):
+    the file PrimSDF (mesh extraction) and the viewer load."""
+    p = recon_param[index].detach().cpu()
+    torch.save({"model_state_dict": {"srt_param": p[:, :4].contiguous(), "feat_param": p[:, 4:].contiguous()}}, path)
+
+
+def primsdf_from_denoised(path: str, device=None):
+    """A `PrimSDF` holding the primitives of a `denoised.pt` (what the GLB export builds before querying the field)."""
+    from .primsdf import PrimSDF
+    sd = torch.load(path, map_location="cpu")["model_state_dict"]
+    n, s3 = sd["srt_param"].shape[0], sd["feat_param"].shape[1] // 6
+    m = PrimSDF(num_prims=n, dim_feat=6, prim_shape=round(s3 ** (1.0 / 3.0)))
+    m.load_state_dict(sd, strict=True)
+    return m.to(device).eval() if device is not None else m.eval()

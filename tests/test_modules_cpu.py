@@ -76,3 +76,26 @@ def test_compat_shim_resolves_reference_class_names():
             ) % (ROOT, os.path.join(ROOT, "compat"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_denoised_pt_round_trip(tmp_path):
+    """The on-disk format between sampling and mesh extraction (inference.py:351-352) and the strict checkpoint loaders."""
+    import torch
+    from topia_xl_amd import pipeline
+    recon = torch.randn(2, 16, 4 + 6 * 512)
+    p = tmp_path / "denoised.pt"
+    pipeline.save_denoised(str(p), recon, index=1)
+    blob = torch.load(str(p))
+    assert set(blob) == {"model_state_dict"} and set(blob["model_state_dict"]) == {"srt_param", "feat_param"}
+    assert torch.equal(blob["model_state_dict"]["srt_param"], recon[1, :, :4])
+    m = pipeline.primsdf_from_denoised(str(p))
+    assert m.num_prims == 16 and m.prim_shape == 8 and torch.equal(m.feat_param.data, recon[1, :, 4:])
+    import topia_xl_amd as pkg
+    dit = pkg.DiT(seq_length=8, in_channels=4, condition_channels=8, hidden_size=64, depth=1, num_heads=2,
+                  cond_drop_prob=0.1, attn_proj_bias=True)
+    ck = tmp_path / "dit.pt"
+    torch.save({"ema": {k: v.half() for k, v in dit.state_dict().items()}}, str(ck))     # fp16 file, like the release
+    dit2 = pkg.DiT(seq_length=8, in_channels=4, condition_channels=8, hidden_size=64, depth=1, num_heads=2,
+                   cond_drop_prob=0.1, attn_proj_bias=True)
+    pipeline.load_checkpoints(model=dit2, dit_checkpoint_path=str(ck))
+    assert all(torch.equal(a.half(), b.half()) for a, b in zip(dit.state_dict().values(), dit2.state_dict().values()))
