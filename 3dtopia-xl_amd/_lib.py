@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PRIMX_LIB") or os.path.join(_HERE, "csrc", "libprimx_
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
 HEADS_ROWS, HEADS_VT, HEADS_KROWS = 0, 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -26,6 +26,8 @@ SIGNATURES = {
     "primx_padded_head_dim": [_i],
     "primx_layernorm_modulate": [_p, _p, _p, _l, _p, _i, _i, _i, _i, _f, _p],
     "primx_timestep_embedding": [_p, _p, _p, _i, _i, _p],
+    "primx_compute_raydirs": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _p],
+    "primx_raymarch": [_p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p],
     "primx_primsdf_query": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "primx_vit_tokens": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "primx_point_features": [_p, _l, _p, _p, _l, _i, _i, _p],

@@ -13,7 +13,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["rowops.hip", "gemm.hip", "attention.hip", "vae.hip", "primsdf.hip"]
+SOURCES = ["rowops.hip", "gemm.hip", "attention.hip", "vae.hip", "primsdf.hip", "raymarch.hip"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "primx_hip.h")]
 LIB = os.path.join(HERE, "libprimx_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

@@ -1,0 +1,99 @@
+"""Forward volumetric ray marcher - SURVEY.md section 8(f) row N2 (dva/ray_marcher.py:RayMarcher and the CUDA extension
+behind it).  `RayMarcher` keeps the reference's constructor and `forward(prim_rgba, prim_pos, prim_rot, prim_scale, K, RT)`
+-> {"rgba_image": [B, 4, H, W], "pixel_coords"}; the two kernels are `primx_compute_raydirs` and `primx_raymarch`
+(csrc/raymarch.hip).  Inference only: no backward pass, no training-time random ray subsampling."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+
+
+def convert_camera_parameters(Rt: torch.Tensor, K: torch.Tensor):
+    """dva/ray_marcher.py:22-30 (two tiny batched matrix products on the host-side tensors: plumbing)."""
+    R = Rt[:, :3, :3]
+    t = -R.permute(0, 2, 1).bmm(Rt[:, :3, 3].unsqueeze(2)).squeeze(2)
+    return dict(campos=t, camrot=R, focal=K[:, :2, :2], princpt=K[:, :2, 2])
+
+
+def compute_raydirs(viewpos, viewrot, focal, princpt, pixelcoords, volradius):
+    N, H, W = pixelcoords.shape[0], pixelcoords.shape[1], pixelcoords.shape[2]
+    dev = viewpos.device
+    raypos = torch.empty(N, H, W, 3, dtype=torch.float32, device=dev)
+    raydir = torch.empty_like(raypos)
+    tminmax = torch.empty(N, H, W, 2, dtype=torch.float32, device=dev)
+    # the dense fp32 copies must stay referenced until the launch is enqueued: a temporary dropped earlier returns its
+    # block to the caching allocator, and the NEXT temporary's copy kernel would overwrite it ahead of our kernel
+    keep = [t.float().contiguous() for t in (viewpos, viewrot, focal, princpt, pixelcoords)]
+    ptrs = [ops._dev(t, name, torch.float32) for t, name in zip(keep, ("viewpos", "viewrot", "focal", "princpt", "pixelcoords"))]
+    _lib.check(_lib.load().primx_compute_raydirs(*ptrs, float(volradius), raypos.data_ptr(), raydir.data_ptr(),
+                                                 tminmax.data_ptr(), N, H, W, ops._stream()), "primx_compute_raydirs")
+    del keep
+    return raypos, raydir, tminmax
+
+
+def mvpraymarch(raypos, raydir, stepsize, tminmax, primtransf, template, fadescale=8.0, fadeexp=8.0):
+    """template: [N, K, TD, TH, TW, 4] channels-last RGBA; primtransf = (pos [N,K,3], rot [N,K,3,3], scale [N,K,3])."""
+    primpos, primrot, primscale = (t.float().contiguous() for t in primtransf)
+    template = template.float().contiguous()
+    N, H, W = raypos.shape[:3]
+    K, TD, TH, TW = template.shape[1:5]
+    if template.shape[-1] != 4:
+        raise RuntimeError("mvpraymarch: the template must be channels-last RGBA")
+    out = torch.empty(N, H, W, 4, dtype=torch.float32, device=raypos.device)
+    _lib.check(_lib.load().primx_raymarch(
+        ops._dev(raypos, "raypos", torch.float32), ops._dev(raydir, "raydir", torch.float32),
+        ops._dev(tminmax, "tminmax", torch.float32), float(stepsize), ops._dev(primpos, "primpos", torch.float32),
+        ops._dev(primrot, "primrot", torch.float32), ops._dev(primscale, "primscale", torch.float32),
+        ops._dev(template, "template", torch.float32), out.data_ptr(), N, H, W, K, TD, TH, TW, float(fadescale),
+        float(fadeexp), ops._stream()), "primx_raymarch")
+    return out
+
+
+class RayMarcher(nn.Module):
+    def __init__(self, image_height, image_width, volradius, fadescale=8.0, fadeexp=8.0, dt=1.0, ray_subsample_factor=1,
+                 accum=2, termthresh=0.99, blocksize=None, with_t_img=True, chlast=False, assets=None):
+        super().__init__()
+        self.image_height, self.image_width = image_height, image_width
+        self.volradius, self.dt = volradius, dt
+        self.fadescale, self.fadeexp = fadescale, fadeexp
+        self.accum, self.termthresh = accum, termthresh          # carried; the forward path uses additive accumulation
+        self.ray_subsample_factor = ray_subsample_factor
+        self.__dict__["_coords"] = {}
+
+    def resize(self, h: int, w: int):
+        self.image_height, self.image_width = h, w
+
+    def _pixel_coords(self, B: int, factor: int, device) -> torch.Tensor:
+        key = (self.image_height, self.image_width, factor, str(device))
+        c = self._coords.get(key)
+        if c is None:
+            ys, xs = torch.meshgrid(torch.arange(self.image_height, dtype=torch.float32, device=device),
+                                    torch.arange(self.image_width, dtype=torch.float32, device=device), indexing="ij")
+            c = torch.stack([xs, ys], dim=-1)
+            if factor > 1:   # resize_pixel_coords (ray_marcher.py:57-76)
+                sw, sh = self.image_width // factor, self.image_height // factor
+                x0 = y0 = factor // 2
+                c = c[y0:y0 + factor * sh:factor, x0:x0 + factor * sw:factor, :]
+            self.__dict__["_coords"] = {key: c.contiguous()}
+        return c[None].expand(B, -1, -1, -1).contiguous()
+
+    def forward(self, prim_rgba, prim_pos, prim_rot, prim_scale, K, RT, ray_subsample_factor: Optional[int] = None):
+        if self.training:
+            raise NotImplementedError("the accelerated ray marcher is forward / inference only: call .eval()")
+        if not prim_rgba.is_cuda:
+            raise RuntimeError("RayMarcher.forward needs HIP device tensors; there is no CPU path")
+        B = prim_rgba.shape[0]
+        cam = convert_camera_parameters(RT.float(), K.float())
+        factor = self.ray_subsample_factor if ray_subsample_factor is None else ray_subsample_factor
+        pixel_coords = self._pixel_coords(B, factor, prim_rgba.device)
+        focal = torch.diagonal(cam["focal"], dim1=1, dim2=2).contiguous()
+        raypos, raydir, tminmax = compute_raydirs(cam["campos"], cam["camrot"], focal, cam["princpt"], pixel_coords,
+                                                  self.volradius)
+        rgba = mvpraymarch(raypos, raydir, self.dt / self.volradius, tminmax,
+                           (prim_pos / self.volradius, prim_rot, prim_scale),
+                           prim_rgba.permute(0, 1, 3, 4, 5, 2), self.fadescale, self.fadeexp)
+        return {"rgba_image": rgba.permute(0, 3, 1, 2), "pixel_coords": pixel_coords}

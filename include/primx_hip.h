@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 11
+#define PRIMX_ABI_VERSION 12
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -239,6 +239,24 @@ int primx_latent_denorm(const float* x, const float* mean, const float* stdv, fl
  * fill of points no primitive covers (primsdf.py:78-100). */
 int primx_primsdf_query(const float* pts, const float* srt, const float* feat, const float* lin, float* out, int n, int P,
                         int S, int C, int eval_fill, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Primitive ray marcher, forward (dva/ray_marcher.py:142-229; dva/mvp/extensions/{utils,mvpraymarch})
+ * -------------------------------------------------------------------------------------------- */
+
+/* viewpos [N,3], viewrot [N,3,3], focal [N,2], princpt [N,2], pixelcoords [N,H,W,2] or NULL (then (w, h)) ->
+ * raypos / raydir [N,H,W,3], tminmax [N,H,W,2] (slab test against the [-1,1]^3 volume, positions / volradius).
+ * Replaces compute_raydirs (utils/utils_kernel.cu:15-56). */
+int primx_compute_raydirs(const float* viewpos, const float* viewrot, const float* focal, const float* princpt,
+                          const float* pixelcoords, float volradius, float* raypos, float* raydir, float* tminmax, int N,
+                          int H, int W, void* stream);
+
+/* primpos [N,K,3], primrot [N,K,3,3], primscale [N,K,3] (inverse half extents), tplate [N,K,TD,TH,TW,4] channels-last
+ * RGBA -> rayrgba [N,H,W,4].  Replaces mvpraymarch(..., algo=0, chlast=True, warp=None, usebvh="fixedorder") forward
+ * (mvpraymarch/mvpraymarch_subset_kernel.h:9-93 with PrimTransfSRT, PrimSamplerTW<false>, PrimAccumAdditive). */
+int primx_raymarch(const float* raypos, const float* raydir, const float* tminmax, float stepsize, const float* primpos,
+                   const float* primrot, const float* primscale, const float* tplate, float* rayrgba, int N, int H, int W,
+                   int K, int TD, int TH, int TW, float fadescale, float fadeexp, void* stream);
 
 #ifdef __cplusplus
 }
