@@ -24,6 +24,7 @@
 namespace {
 
 constexpr int MAXHIT = 512;   // the reference's maxhitboxes
+constexpr int CHUNK = 96;     // marching steps per sub-list rebuild
 
 struct F3 { float x, y, z; };
 __device__ __forceinline__ F3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256) void raymarch_kernel(const float* __restrict__
                                                       float4* __restrict__ rayrgba, int N, int H, int W, int K, int TD, int TH,
                                                       int TW, float fadescale, float fadeexp) {
     __shared__ int hits[4][MAXHIT];
+    __shared__ int subs[4][MAXHIT];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = blockIdx.z;
@@ -111,6 +113,8 @@ __global__ __launch_bounds__(256) void raymarch_kernel(const float* __restrict__
     __builtin_amdgcn_wave_barrier();
 
     // ---- march
+    const F3 ro = rp;                       // ray origin (t = 0) for the per-chunk interval tests
+    int* sub = subs[wave];
     float t = tmin0;
     rp = {rp.x + rd.x * tmin0, rp.y + rd.y * tmin0, rp.z + rd.z * tmin0};
     const int incs = (int)floorf((rtmin - t) / stepsize);
@@ -119,42 +123,77 @@ __global__ __launch_bounds__(256) void raymarch_kernel(const float* __restrict__
     float4 acc = {0.f, 0.f, 0.f, 0.f};
     bool sat = false;
     const int sD = TW * TH, sH = TW;
+    // The shipped step is 1e-4 of the volume: a ray takes ~10^4 steps while a primitive spans a few hundred of them.
+    // Every CHUNK steps the tile's hit list is filtered down to the primitives whose (per-ray) slab interval overlaps the
+    // chunk for ANY ray of the wave, with a two-step safety margin; inside the chunk only those are transformed and
+    // tested.  The filter is conservative, and a listed primitive the sample is not inside fails `in` exactly as before,
+    // so the image is the one the unfiltered loop produces (132 -> 100 ms per 518^2 view of 2048 primitives).
     while (!__all(t > rtmax + 1e-5f || sat)) {
+        const float t_end = t + (float)CHUNK * stepsize;
+        const bool live = !(t > rtmax + 1e-5f || sat);
+        int nsub = 0;
         for (int ks = 0; ks < num; ++ks) {
             const int k = list[ks];
             const float* pr = prot + k * 9;
-            const F3 xm = {rp.x - ppos[k * 3], rp.y - ppos[k * 3 + 1], rp.z - ppos[k * 3 + 2]};
-            const float yx = (pr[0] * xm.x + pr[3] * xm.y + pr[6] * xm.z) * pscl[k * 3];
-            const float yy = (pr[1] * xm.x + pr[4] * xm.y + pr[7] * xm.z) * pscl[k * 3 + 1];
-            const float yz = (pr[2] * xm.x + pr[5] * xm.y + pr[8] * xm.z) * pscl[k * 3 + 2];
-            const bool in = yx > -1.f && yx < 1.f && yy > -1.f && yy < 1.f && yz > -1.f && yz < 1.f;
-            if (in && !sat && t < rtmax + 1e-5f) {
-                const float fade = __expf(-fadescale * (__powf(fabsf(yx), fadeexp) + __powf(fabsf(yy), fadeexp) +
-                                                        __powf(fabsf(yz), fadeexp)));
-                const float gx = (yx + 1.f) * 0.5f * (float)(TW - 1), gy = (yy + 1.f) * 0.5f * (float)(TH - 1),
-                            gz = (yz + 1.f) * 0.5f * (float)(TD - 1);
-                const int x0 = (int)floorf(gx), y0 = (int)floorf(gy), z0 = (int)floorf(gz);
-                const float fx = gx - (float)x0, fy = gy - (float)y0, fz = gz - (float)z0;
-                const float4* v = tpl + (int64_t)k * TD * sD;
-                float4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int xi = x0 + (c & 1), yi = y0 + ((c >> 1) & 1), zi = z0 + (c >> 2);
-                    if (xi >= 0 && xi < TW && yi >= 0 && yi < TH && zi >= 0 && zi < TD) {
-                        const float wgt = ((c & 1) ? fx : 1.f - fx) * (((c >> 1) & 1) ? fy : 1.f - fy) * ((c >> 2) ? fz : 1.f - fz);
-                        const float4 q = v[zi * sD + yi * sH + xi];
-                        s.x += q.x * wgt; s.y += q.y * wgt; s.z += q.z * wgt; s.w += q.w * wgt;
-                    }
-                }
-                const float alpha = s.w * fade;
-                const float newalpha = acc.w + alpha * stepsize;
-                const float contrib = fminf(newalpha, 1.f) - acc.w;
-                acc.x += s.x * contrib; acc.y += s.y * contrib; acc.z += s.z * contrib; acc.w += contrib;
-                if (newalpha >= 1.f) sat = true;
+            const F3 xm = {ro.x - ppos[k * 3], ro.y - ppos[k * 3 + 1], ro.z - ppos[k * 3 + 2]};
+            const float sx = pscl[k * 3], sy = pscl[k * 3 + 1], sz = pscl[k * 3 + 2];
+            const F3 r0 = {(pr[0] * xm.x + pr[3] * xm.y + pr[6] * xm.z) * sx, (pr[1] * xm.x + pr[4] * xm.y + pr[7] * xm.z) * sy,
+                           (pr[2] * xm.x + pr[5] * xm.y + pr[8] * xm.z) * sz};
+            const F3 r1 = {(pr[0] * rd.x + pr[3] * rd.y + pr[6] * rd.z) * sx, (pr[1] * rd.x + pr[4] * rd.y + pr[7] * rd.z) * sy,
+                           (pr[2] * rd.x + pr[5] * rd.y + pr[8] * rd.z) * sz};
+            const float ix = 1.0f / r1.x, iy = 1.0f / r1.y, iz = 1.0f / r1.z;
+            const float ax = (-1.f - r0.x) * ix, bx = (1.f - r0.x) * ix;
+            const float ay = (-1.f - r0.y) * iy, by = (1.f - r0.y) * iy;
+            const float az = (-1.f - r0.z) * iz, bz = (1.f - r0.z) * iz;
+            const float trmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+            const float trmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            // NaNs (ray parallel to a slab it touches) compare false everywhere: keep such a primitive
+            const bool skip = (trmax < t - 2.f * stepsize) || (trmin > t_end + 2.f * stepsize) || (trmin > trmax + 4.f * stepsize);
+            if (__any(live && !skip)) {
+                if (lane == 0) sub[nsub] = k;
+                ++nsub;
             }
         }
-        t += stepsize;
-        rp = {rp.x + rd.x * stepsize, rp.y + rd.y * stepsize, rp.z + rd.z * stepsize};
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        for (int step = 0; step < CHUNK; ++step) {
+            if (__all(t > rtmax + 1e-5f || sat)) break;
+            for (int ks = 0; ks < nsub; ++ks) {
+                const int k = sub[ks];
+                const float* pr = prot + k * 9;
+                const F3 xm = {rp.x - ppos[k * 3], rp.y - ppos[k * 3 + 1], rp.z - ppos[k * 3 + 2]};
+                const float yx = (pr[0] * xm.x + pr[3] * xm.y + pr[6] * xm.z) * pscl[k * 3];
+                const float yy = (pr[1] * xm.x + pr[4] * xm.y + pr[7] * xm.z) * pscl[k * 3 + 1];
+                const float yz = (pr[2] * xm.x + pr[5] * xm.y + pr[8] * xm.z) * pscl[k * 3 + 2];
+                const bool in = yx > -1.f && yx < 1.f && yy > -1.f && yy < 1.f && yz > -1.f && yz < 1.f;
+                if (in && !sat && t < rtmax + 1e-5f) {
+                    const float fade = __expf(-fadescale * (__powf(fabsf(yx), fadeexp) + __powf(fabsf(yy), fadeexp) +
+                                                            __powf(fabsf(yz), fadeexp)));
+                    const float gx = (yx + 1.f) * 0.5f * (float)(TW - 1), gy = (yy + 1.f) * 0.5f * (float)(TH - 1),
+                                gz = (yz + 1.f) * 0.5f * (float)(TD - 1);
+                    const int x0 = (int)floorf(gx), y0 = (int)floorf(gy), z0 = (int)floorf(gz);
+                    const float fx = gx - (float)x0, fy = gy - (float)y0, fz = gz - (float)z0;
+                    const float4* v = tpl + (int64_t)k * TD * sD;
+                    float4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int xi = x0 + (c & 1), yi = y0 + ((c >> 1) & 1), zi = z0 + (c >> 2);
+                        if (xi >= 0 && xi < TW && yi >= 0 && yi < TH && zi >= 0 && zi < TD) {
+                            const float wgt = ((c & 1) ? fx : 1.f - fx) * (((c >> 1) & 1) ? fy : 1.f - fy) * ((c >> 2) ? fz : 1.f - fz);
+                            const float4 q = v[zi * sD + yi * sH + xi];
+                            s.x += q.x * wgt; s.y += q.y * wgt; s.z += q.z * wgt; s.w += q.w * wgt;
+                        }
+                    }
+                    const float alpha = s.w * fade;
+                    const float newalpha = acc.w + alpha * stepsize;
+                    const float contrib = fminf(newalpha, 1.f) - acc.w;
+                    acc.x += s.x * contrib; acc.y += s.y * contrib; acc.z += s.z * contrib; acc.w += contrib;
+                    if (newalpha >= 1.f) sat = true;
+                }
+            }
+            t += stepsize;
+            rp = {rp.x + rd.x * stepsize, rp.y + rd.y * stepsize, rp.z + rd.z * stepsize};
+        }
     }
     if (valid) rayrgba[pix] = acc;
 }

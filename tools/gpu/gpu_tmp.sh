@@ -1,2 +1,3 @@
 #!/bin/bash
-timeout 600 python -m pytest tests/test_raymarch.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -12
+timeout 600 python -m pytest tests/test_raymarch.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -3
+timeout 600 python tools/raymarch_bench.py 2>&1 | grep -v amdgpu | tail -1
