@@ -47,7 +47,10 @@ constexpr int QPAD = 128;   // granularity of nq_pad (the Q operand buffers)
 constexpr int NW = 8;       // waves per workgroup: all of them share every K / V^T tile the workgroup stages
 constexpr int BQ = 32 * NW; // query rows per workgroup
 constexpr int BKV = 64;     // keys per tile
-constexpr int NSTAGE = 3;   // LDS ring depth
+#ifndef PRIMX_ATTN_NSTAGE
+#define PRIMX_ATTN_NSTAGE 3
+#endif
+constexpr int NSTAGE = PRIMX_ATTN_NSTAGE;   // LDS ring depth (3..6 fit one workgroup per CU)
 constexpr int WAITCNT_LGKM0 = 0xC07F;   // s_waitcnt simm16 on gfx9: vmcnt = 63 (no wait), expcnt = 7 (no wait), lgkmcnt = 0
 
 template <typename V8>
@@ -218,10 +221,11 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
 #define PRIMX_ATTN_WAITB()                                                                                         \
     do {                                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                     /* nothing of the next segment moves above ... */     \
-        __builtin_amdgcn_s_waitcnt((NSLOT & 15) | 0x70 | ((NSLOT >> 4) << 14)); /* vmcnt(NSLOT) lgkmcnt(0) */      \
+        __builtin_amdgcn_s_waitcnt((NFLY & 15) | 0x70 | ((NFLY >> 4) << 14)); /* vmcnt(NFLY) lgkmcnt(0) */         \
         asm volatile("s_barrier" ::: "memory");                                                                    \
         __builtin_amdgcn_sched_barrier(0);                     /* ... and nothing of this one sinks below */        \
     } while (0)
+    constexpr int NFLY = NSLOT * (NSTAGE - 2);   // DMAs of the pairs newer than the one the next light segment reads
     unsigned long long pt = 0, pl = 0, pm = 0, pw = 0, pn = 0, pl_dma = 0, pl_rd = 0;
     auto stamp = [&](unsigned long long& acc) {
         if (PROF) {
@@ -284,8 +288,8 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
 
     // ---- prologue: K(0) parks in the last stage, pairs 0 and 1 are issued; S(0) = K(0) Q^T
     if (!grp) issue_run(0, NSTAGE - 1);
-    issue_pair(0, 0);
-    issue_pair(1, 1);
+#pragma unroll
+    for (int pr = 0; pr < NSTAGE - 1; ++pr) issue_pair(pr, pr);
     f32x16 sA[2], sB[2];
     PRIMX_ATTN_WAITB();                   // K(0) and pair 0 landed
     {
