@@ -77,3 +77,30 @@ def primsdf_from_denoised(path: str, device=None):
     m = PrimSDF(num_prims=n, dim_feat=6, prim_shape=round(s3 ** (1.0 / 3.0)))
     m.load_state_dict(sd, strict=True)
     return m.to(device).eval() if device is not None else m.eval()
+
+
+def primitives_to_marcher_inputs(recon_param: torch.Tensor, volradius: float, sdf2alpha_var: float = 0.005):
+    """recon_param [B, N, 4 + 6 S^3] -> (prim_rgba [B,N,4,S,S,S] in 0..255, prim_pos, prim_rot, prim_scale) exactly as the
+    preview renderer prepares them (dva/visualize.py:215-239): alpha = 255 exp(-(sdf / 0.005)^2), rgb = 255 tex, identity
+    rotations, inverse scales.  Elementwise tensor preparation around the marcher (plumbing)."""
+    B, N, C = recon_param.shape
+    S = round(((C - 4) / 6) ** (1.0 / 3.0))
+    s3 = S ** 3
+    geo = recon_param[:, :, 4:4 + s3]
+    tex = recon_param[:, :, 4 + s3:4 + 4 * s3]
+    alpha = torch.exp(-(geo / sdf2alpha_var) ** 2).reshape(B, N, 1, S, S, S) * 255
+    rgb = tex.reshape(B, N, 3, S, S, S) * 255
+    pos = recon_param[:, :, 1:4].reshape(B, N, 3) * volradius
+    rot = torch.eye(3, device=recon_param.device, dtype=recon_param.dtype)[None, None].repeat(B, N, 1, 1)
+    scale = 1.0 / recon_param[:, :, 0:1].reshape(B, N, 1).repeat(1, 1, 3)
+    return torch.cat([rgb, alpha], dim=2), pos, rot, scale
+
+
+def preview_camera(volradius: float, height: int, width: int, device):
+    """The fixed preview camera of dva/visualize.py:240-285 (looking down -z from 5 volume radii, 1024-pixel intrinsics
+    rescaled to the image size)."""
+    Rt = torch.tensor([[[1.0, 0.0, 0.0, 0.0], [0.0, -1.0, 0.0, 0.0], [0.0, 0.0, -1.0, 5.0 * volradius]]], device=device)
+    K = torch.tensor([[[2084.9526697685183, 0.0, 512.0], [0.0, 2084.9526697685183, 512.0], [0.0, 0.0, 1.0]]], device=device)
+    K[:, 0:1, :] *= height / 1024.0
+    K[:, 1:2, :] *= width / 1024.0
+    return K, Rt

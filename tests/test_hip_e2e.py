@@ -1,0 +1,19 @@
+"""The whole data flow of inference.py:312-352 at smoke size (examples/generate.py --small): every stage runs on the HIP
+path and hands the next one tensors of the reference's shapes."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_generate_small():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "generate.py"), "--small", "--steps", "5", "--res", "48",
+                        "--lattice", "24"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert "tokens (1, 17, 96)" in last and "samples (1, 64, 68)" in last and "recon_param (1, 64, 3076)" in last
+    assert "sdf grid (24, 24, 24)" in last and "preview (1, 4, 48, 48)" in last

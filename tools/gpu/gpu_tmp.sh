@@ -1,4 +1,3 @@
 #!/bin/bash
-L=$PWD/3dtopia-xl_amd/csrc
-PRIMX_LIB=$L/libprimx_s5.so timeout 600 python -m pytest tests/test_hip_attention.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -2
-for v in s3 s4 s5 s3 s4 s5; do echo "--- $v"; PRIMX_LIB=$L/libprimx_$v.so REPS=50 timeout 120 python tools/attn_bench.py 2>&1 | grep -v amdgpu | tail -4; done
+timeout 600 python -m pytest tests/test_hip_e2e.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -8
+timeout 900 python examples/generate.py 2>&1 | grep -v amdgpu | tail -9
