@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void raymarch_kernel(const float* __restrict__
         const bool live = !(t > rtmax + 1e-5f || sat);
         int nsub = 0;
         for (int ks = 0; ks < num; ++ks) {
-            const int k = list[ks];
+            const int k = __builtin_amdgcn_readfirstlane(list[ks]);   // wave-uniform: the primitive record comes through scalar loads
             const float* pr = prot + k * 9;
             const F3 xm = {ro.x - ppos[k * 3], ro.y - ppos[k * 3 + 1], ro.z - ppos[k * 3 + 2]};
             const float sx = pscl[k * 3], sy = pscl[k * 3 + 1], sz = pscl[k * 3 + 2];
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void raymarch_kernel(const float* __restrict__
         for (int step = 0; step < CHUNK; ++step) {
             if (__all(t > rtmax + 1e-5f || sat)) break;
             for (int ks = 0; ks < nsub; ++ks) {
-                const int k = sub[ks];
+                const int k = __builtin_amdgcn_readfirstlane(sub[ks]);
                 const float* pr = prot + k * 9;
                 const F3 xm = {rp.x - ppos[k * 3], rp.y - ppos[k * 3 + 1], rp.z - ppos[k * 3 + 2]};
                 const float yx = (pr[0] * xm.x + pr[3] * xm.y + pr[6] * xm.z) * pscl[k * 3];
