@@ -50,6 +50,9 @@ constexpr int BKV = 64;     // keys per tile
 #ifndef PRIMX_ATTN_NSTAGE
 #define PRIMX_ATTN_NSTAGE 3
 #endif
+#ifndef PRIMX_ATTN_PRIO
+#define PRIMX_ATTN_PRIO 1   // 1: s_setprio 1 around every matrix segment (same-box: 58.1 vs 59.5 us); 2: static prio for group 1 (no gain); 0: off
+#endif
 constexpr int NSTAGE = PRIMX_ATTN_NSTAGE;   // LDS ring depth (3..6 fit one workgroup per CU)
 constexpr int WAITCNT_LGKM0 = 0xC07F;   // s_waitcnt simm16 on gfx9: vmcnt = 63 (no wait), expcnt = 7 (no wait), lgkmcnt = 0
 
@@ -272,6 +275,9 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     auto seg_matrix = [&](int st, int t_next, const f32x16 (&sc)[2], f32x16 (&sn)[2], const V8 (&kf)[2][KSTEPS],
                           const V8 (&vf0)[DTILES][2]) {
         if (idle) return;
+#if PRIMX_ATTN_PRIO == 1
+        __builtin_amdgcn_s_setprio(1);   // the matrix segment outranks its partner's light segment at the issue arbiter
+#endif
         const float mc = m_run * c;
         float psum = 0.f;
         V8 vf1[DTILES][2], pb0[2], pb1[2];
@@ -284,6 +290,9 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
         fence_lds();
         pv(vf1, pb1);
         if (KMASK) l_run += psum;
+#if PRIMX_ATTN_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     // ---- prologue: K(0) parks in the last stage, pairs 0 and 1 are issued; S(0) = K(0) Q^T
@@ -299,6 +308,9 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
         asm volatile("s_barrier" ::: "memory");   // group 0's L(0) refills this stage: everyone's K(0) reads are home first
         qk(kf0, 0, sA);                   // S(0)
     }
+#if PRIMX_ATTN_PRIO == 2
+    if (grp) __builtin_amdgcn_s_setprio(1);
+#endif
     if (PROF) pt = __builtin_readcyclecounter();
     // ---- main loop.  Group 0 runs  L B M B,  group 1 runs  B L B M  per step: the same number of barriers, group 1 half
     // a step late.  Ring safety (NSTAGE = 3): pair j+2 goes to the stage of pair j-1, whose K part was last read in
