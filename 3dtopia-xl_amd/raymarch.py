@@ -13,10 +13,12 @@ from . import _lib, ops
 
 
 def convert_camera_parameters(Rt: torch.Tensor, K: torch.Tensor):
-    """dva/ray_marcher.py:22-30 (two tiny batched matrix products on the host-side tensors: plumbing)."""
-    R = Rt[:, :3, :3]
-    t = -R.permute(0, 2, 1).bmm(Rt[:, :3, 3].unsqueeze(2)).squeeze(2)
-    return dict(campos=t, camrot=R, focal=K[:, :2, :2], princpt=K[:, :2, 2])
+    """World-to-camera [R | t] and pinhole K -> the quantities the ray generator consumes (dva/ray_marcher.py:22-30):
+    camera centre c = -R^T t, the rotation itself, the 2 x 2 focal block and the principal point.  (Two tiny batched
+    products on a handful of floats: plumbing.)"""
+    rot = Rt[:, :3, :3]
+    centre = -torch.einsum("nji,nj->ni", rot, Rt[:, :3, 3])
+    return {"campos": centre, "camrot": rot, "focal": K[:, :2, :2], "princpt": K[:, :2, 2]}
 
 
 def compute_raydirs(viewpos, viewrot, focal, princpt, pixelcoords, volradius):

@@ -24,9 +24,10 @@ Tensor = torch.Tensor
 
 
 def convert_camera(Rt: Tensor, K: Tensor):
-    R = Rt[:, :3, :3]
-    t = -R.permute(0, 2, 1).bmm(Rt[:, :3, 3].unsqueeze(2)).squeeze(2)
-    return t, R, torch.diagonal(K[:, :2, :2], dim1=1, dim2=2).contiguous(), K[:, :2, 2]
+    """(camera centre -R^T t, R, diag focal, principal point)   dva/ray_marcher.py:22-30 + 195."""
+    rot = Rt[:, :3, :3]
+    centre = -(rot.transpose(1, 2) @ Rt[:, :3, 3:4])[..., 0]
+    return centre, rot, torch.stack([K[:, 0, 0], K[:, 1, 1]], dim=-1), K[:, :2, 2]
 
 
 def compute_raydirs(viewpos, viewrot, focal, princpt, pixelcoords, volradius):
