@@ -129,3 +129,27 @@ def test_linear_residual(ops, dtype):
     assert rel_l2(got, (ref + res.double()) * 0.5 ** 0.5) < TOL[dtype]
     got = ops.linear_residual(A.to(DEV), W.to(DEV), b.to(DEV), None, 1.0)
     assert rel_l2(got, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K", [(700, 128), (3000, 64), (520, 1152)])
+def test_big_tile_edges(ops, dtype, M, K):
+    """256 x 288 kernel (>= 224 workgroups): a ragged last M tile, fewer k-slices than ring stages, GELU (erf and tanh),
+    bias-less, and the gate-residual epilogue with batch boundaries inside a tile."""
+    N = 288 * (224 * 256 // max(256, (M + 255) // 256 * 256) + 40)      # enough column tiles for the big-tile rule
+    N = min(N, 288 * 96)
+    assert ((M + 255) // 256) * (N // 288) >= 224
+    A, W, b, ref = _mk(21, M, N, K, dtype)
+    r = lambda t: t.to(dtype).double()
+    got = ops.linear(A.to(DEV), W.to(DEV), b.to(DEV))
+    assert rel_l2(got, ref) < TOL[dtype], rel_l2(got, ref)
+    got = ops.linear(A.to(DEV), W.to(DEV), None, act=2)                                   # exact GELU
+    assert rel_l2(got, r(F.gelu(r(ref - b.double()).float()))) < 2 * TOL[dtype]
+    rows = 100                                                                            # 7 / 30 / 5.2 batch entries
+    Bn = (M + rows - 1) // rows
+    gate = synth.tensor(21, "gate", (Bn, N), 0.5).to(dtype)
+    x = synth.tensor(21, "x", (M, N))
+    want = x.double() + r(gate.double().repeat_interleave(rows, 0)[:M] * r(ref))
+    xd = x.to(DEV)
+    ops.linear_gate_residual(A.to(DEV), W.to(DEV), b.to(DEV), gate.to(DEV), xd, rows)
+    assert rel_l2(xd - x.to(DEV), want - x.double()) < 2 * TOL[dtype]
