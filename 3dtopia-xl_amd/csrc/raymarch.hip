@@ -19,14 +19,23 @@
 // primitive record is wave-uniform, so it comes through scalar loads) and build the tile's hit list in LDS with a ballot
 // - 2048 primitives x 270 k rays is ~1 ms of VALU, less than the tree build + traversal it replaces; the list order is the
 // index order the reference's "fixedorder" tree produces, so saturation happens at the same sample.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
+// PRIMX_RAYMARCH_STATS=1: per-wave counters [waves, sum num, marching waves, chunks, sum nsub, steps, record evaluations]
+__device__ unsigned long long g_rm_stats[12];
+
 constexpr int MAXHIT = 512;   // the reference's maxhitboxes
 constexpr int CHUNK = 96;     // marching steps per sub-list rebuild
+constexpr int NREC = 64;      // primitives per wave and chunk with an LDS record (16 floats) and per-ray entry / exit steps
 
 struct F3 { float x, y, z; };
+__device__ __forceinline__ float fast_pow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 __device__ __forceinline__ F3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
 
 __global__ __launch_bounds__(256) void raydirs_kernel(const float* __restrict__ viewpos, const float* __restrict__ viewrot,
@@ -63,9 +72,11 @@ __global__ __launch_bounds__(256) void raymarch_kernel(const float* __restrict__
                                                       const float* __restrict__ primpos, const float* __restrict__ primrot,
                                                       const float* __restrict__ primscale, const float4* __restrict__ tplate,
                                                       float4* __restrict__ rayrgba, int N, int H, int W, int K, int TD, int TH,
-                                                      int TW, float fadescale, float fadeexp) {
+                                                      int TW, float fadescale, float fadeexp, int stats) {
     __shared__ int hits[4][MAXHIT];
     __shared__ int subs[4][MAXHIT];
+    __shared__ float4 recs[4][NREC][4];   // (pos.xyz, r00) (r01 r02 r10 r11) (r12 r20 r21 r22) (scale.xyz, -)
+    __shared__ unsigned short span[4][NREC][64];   // per ray: first | last << 8 step of the chunk the ray can be inside
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = blockIdx.z;
@@ -81,6 +92,7 @@ __global__ __launch_bounds__(256) void raymarch_kernel(const float* __restrict__
     const float* pscl = primscale + (int64_t)n * K * 3;
     const float4* tpl = tplate + (int64_t)n * K * TD * TH * TW;
 
+    const unsigned long long c_start = stats ? __builtin_readcyclecounter() : 0;
     // ---- hit list of the tile (index order) + this ray's own [rtmin, rtmax]
     int* list = hits[wave];
     int num = 0;
@@ -112,6 +124,8 @@ __global__ __launch_bounds__(256) void raymarch_kernel(const float* __restrict__
     __builtin_amdgcn_s_waitcnt(0xC07F);   // the list (written by lane 0) is read by the whole wave below
     __builtin_amdgcn_wave_barrier();
 
+    const unsigned long long c_hit = stats ? __builtin_readcyclecounter() : 0;
+    unsigned long long c_rebuild = 0, c_t0 = 0;
     // ---- march
     const F3 ro = rp;                       // ray origin (t = 0) for the per-chunk interval tests
     int* sub = subs[wave];
@@ -127,8 +141,10 @@ __global__ __launch_bounds__(256) void raymarch_kernel(const float* __restrict__
     // Every CHUNK steps the tile's hit list is filtered down to the primitives whose (per-ray) slab interval overlaps the
     // chunk for ANY ray of the wave, with a two-step safety margin; inside the chunk only those are transformed and
     // tested.  The filter is conservative, and a listed primitive the sample is not inside fails `in` exactly as before,
-    // so the image is the one the unfiltered loop produces (132 -> 100 ms per 518^2 view of 2048 primitives).
+    // so the image is the one the unfiltered loop produces.
+    unsigned long long st_chunks = 0, st_nsub = 0, st_steps = 0, st_eval = 0;
     while (!__all(t > rtmax + 1e-5f || sat)) {
+        if (stats) c_t0 = __builtin_readcyclecounter();
         const float t_end = t + (float)CHUNK * stepsize;
         const bool live = !(t > rtmax + 1e-5f || sat);
         int nsub = 0;
@@ -151,38 +167,87 @@ __global__ __launch_bounds__(256) void raymarch_kernel(const float* __restrict__
             const bool skip = (trmax < t - 2.f * stepsize) || (trmin > t_end + 2.f * stepsize) || (trmin > trmax + 4.f * stepsize);
             if (__any(live && !skip)) {
                 if (lane == 0) sub[nsub] = k;
+                if (nsub < NREC) {
+                    // conservative step window of THIS ray inside primitive k during the chunk (two steps of margin each side;
+                    // anything that does not compare cleanly - NaN, infinities - becomes "always")
+                    float e0 = floorf((trmin - t) / stepsize) - 2.f, e1 = ceilf((trmax - t) / stepsize) + 2.f;
+                    unsigned short w = 0x00ff;                                   // first 255 > last 0: never
+                    if (live && !skip) {
+                        const int i0 = (e0 >= 0.f && e0 <= 255.f) ? (int)e0 : (e0 > 255.f ? 255 : 0);
+                        const int i1 = (e1 >= 0.f && e1 <= 255.f) ? (int)e1 : (e1 < 0.f ? 0 : 255);
+                        w = (unsigned short)(i0 | (i1 << 8));
+                        if (!(trmin <= trmax)) w = 0xff00;                       // unordered: evaluate every step
+                    }
+                    span[wave][nsub][lane] = w;
+                }
                 ++nsub;
             }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
+        // The records of the chunk's cached primitives go to LDS once.  Per step a ray only compares the step index with
+        // its window (2 bytes per ray per primitive, lane-linear LDS read); the record is fetched (LDS broadcast) and the
+        // exact inside test / sample run only when some ray of the wave is within its window.
+        st_chunks += 1; st_nsub += nsub;
+        if (stats) c_rebuild += __builtin_readcyclecounter() - c_t0;
+        const int ncache = min(nsub, NREC);
+        float* recf = reinterpret_cast<float*>(recs[wave]);
+        for (int i = lane; i < ncache * 16; i += 64) {
+            const int k = sub[i >> 4], j = i & 15;
+            float v = 0.f;
+            if (j < 3) v = ppos[k * 3 + j];
+            else if (j < 12) v = prot[k * 9 + j - 3];
+            else if (j < 15) v = pscl[k * 3 + j - 12];
+            recf[i] = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        __builtin_amdgcn_wave_barrier();
         for (int step = 0; step < CHUNK; ++step) {
             if (__all(t > rtmax + 1e-5f || sat)) break;
+            st_steps += 1;
             for (int ks = 0; ks < nsub; ++ks) {
+                float4 c0, c1, c2, c3;
+                if (ks < NREC) {
+                    const unsigned w = span[wave][ks][lane];
+                    const bool maybe = step >= (int)(w & 255u) && step <= (int)(w >> 8);
+                    if (!__any(maybe)) continue;          // nobody near this primitive at this step: 6 instructions
+                    c0 = recs[wave][ks][0]; c1 = recs[wave][ks][1]; c2 = recs[wave][ks][2]; c3 = recs[wave][ks][3];
+                } else {   // beyond the cache (rare): straight from memory, every step
+                    const int k = __builtin_amdgcn_readfirstlane(sub[ks]);
+                    const float* pr_ = prot + k * 9;
+                    c0 = {ppos[k * 3], ppos[k * 3 + 1], ppos[k * 3 + 2], pr_[0]};
+                    c1 = {pr_[1], pr_[2], pr_[3], pr_[4]};
+                    c2 = {pr_[5], pr_[6], pr_[7], pr_[8]};
+                    c3 = {pscl[k * 3], pscl[k * 3 + 1], pscl[k * 3 + 2], 0.f};
+                }
                 const int k = __builtin_amdgcn_readfirstlane(sub[ks]);
-                const float* pr = prot + k * 9;
-                const F3 xm = {rp.x - ppos[k * 3], rp.y - ppos[k * 3 + 1], rp.z - ppos[k * 3 + 2]};
-                const float yx = (pr[0] * xm.x + pr[3] * xm.y + pr[6] * xm.z) * pscl[k * 3];
-                const float yy = (pr[1] * xm.x + pr[4] * xm.y + pr[7] * xm.z) * pscl[k * 3 + 1];
-                const float yz = (pr[2] * xm.x + pr[5] * xm.y + pr[8] * xm.z) * pscl[k * 3 + 2];
+                st_eval += 1;
+                const float pr[9] = {c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w};
+                const F3 xm = {rp.x - c0.x, rp.y - c0.y, rp.z - c0.z};
+                const float yx = (pr[0] * xm.x + pr[3] * xm.y + pr[6] * xm.z) * c3.x;
+                const float yy = (pr[1] * xm.x + pr[4] * xm.y + pr[7] * xm.z) * c3.y;
+                const float yz = (pr[2] * xm.x + pr[5] * xm.y + pr[8] * xm.z) * c3.z;
                 const bool in = yx > -1.f && yx < 1.f && yy > -1.f && yy < 1.f && yz > -1.f && yz < 1.f;
                 if (in && !sat && t < rtmax + 1e-5f) {
-                    const float fade = __expf(-fadescale * (__powf(fabsf(yx), fadeexp) + __powf(fabsf(yy), fadeexp) +
-                                                            __powf(fabsf(yz), fadeexp)));
+                    // the reference's __powf / __expf are CUDA's fast forms 2^(y log2 x) and 2^(x log2 e); HIP's __powf is
+                    // the full-precision routine (~200 instructions - measured: 1900 VALU instructions per marching step)
+                    const float fade = fast_exp(-fadescale * (fast_pow(fabsf(yx), fadeexp) + fast_pow(fabsf(yy), fadeexp) +
+                                                              fast_pow(fabsf(yz), fadeexp)));
                     const float gx = (yx + 1.f) * 0.5f * (float)(TW - 1), gy = (yy + 1.f) * 0.5f * (float)(TH - 1),
                                 gz = (yz + 1.f) * 0.5f * (float)(TD - 1);
-                    const int x0 = (int)floorf(gx), y0 = (int)floorf(gy), z0 = (int)floorf(gz);
+                    const int x0 = min(max((int)floorf(gx), 0), TW - 2), y0 = min(max((int)floorf(gy), 0), TH - 2),
+                              z0 = min(max((int)floorf(gz), 0), TD - 2);   // (no-op clamps: memory safety only)
                     const float fx = gx - (float)x0, fy = gy - (float)y0, fz = gz - (float)z0;
                     const float4* v = tpl + (int64_t)k * TD * sD;
                     float4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         const int xi = x0 + (c & 1), yi = y0 + ((c >> 1) & 1), zi = z0 + (c >> 2);
-                        if (xi >= 0 && xi < TW && yi >= 0 && yi < TH && zi >= 0 && zi < TD) {
-                            const float wgt = ((c & 1) ? fx : 1.f - fx) * (((c >> 1) & 1) ? fy : 1.f - fy) * ((c >> 2) ? fz : 1.f - fz);
-                            const float4 q = v[zi * sD + yi * sH + xi];
-                            s.x += q.x * wgt; s.y += q.y * wgt; s.z += q.z * wgt; s.w += q.w * wgt;
-                        }
+                        // |y| < 1 strictly => 0 <= x0 <= TW - 2 (and likewise y0, z0): all eight corners are inside the grid,
+                        // the reference's zero-padding branch (utils.h:473-500) cannot trigger here
+                        const float wgt = ((c & 1) ? fx : 1.f - fx) * (((c >> 1) & 1) ? fy : 1.f - fy) * ((c >> 2) ? fz : 1.f - fz);
+                        const float4 q = (stats == 2) ? float4{0.5f, 0.5f, 0.5f, 5.f} : v[zi * sD + yi * sH + xi];
+                        s.x += q.x * wgt; s.y += q.y * wgt; s.z += q.z * wgt; s.w += q.w * wgt;
                     }
                     const float alpha = s.w * fade;
                     const float newalpha = acc.w + alpha * stepsize;
@@ -196,6 +261,14 @@ __global__ __launch_bounds__(256) void raymarch_kernel(const float* __restrict__
         }
     }
     if (valid) rayrgba[pix] = acc;
+    if (stats && lane == 0) {
+        atomicAdd(&g_rm_stats[0], 1ull); atomicAdd(&g_rm_stats[1], (unsigned long long)num);
+        atomicAdd(&g_rm_stats[2], st_chunks ? 1ull : 0ull); atomicAdd(&g_rm_stats[3], st_chunks); atomicAdd(&g_rm_stats[4], st_nsub);
+        atomicAdd(&g_rm_stats[5], st_steps); atomicAdd(&g_rm_stats[6], st_eval);
+        const unsigned long long c_end = __builtin_readcyclecounter();
+        atomicAdd(&g_rm_stats[7], c_hit - c_start); atomicAdd(&g_rm_stats[8], c_rebuild); atomicAdd(&g_rm_stats[9], c_end - c_hit - c_rebuild);
+        atomicMax(&g_rm_stats[10], c_end - c_start);
+    }
 }
 
 }  // namespace
@@ -220,9 +293,21 @@ extern "C" int primx_raymarch(const float* raypos, const float* raydir, const fl
                   "primx_raymarch: null pointer");
     PRIMX_REQUIRE(N > 0 && H > 0 && W > 0 && K > 0 && TD > 1 && TH > 1 && TW > 1 && stepsize > 0.f,
                   "primx_raymarch: empty problem / non-positive step");
+    static const int stats = [] { const char* e = getenv("PRIMX_RAYMARCH_STATS"); return e ? atoi(e) : 0; }();   // 2: no template fetch
+    unsigned long long z[12] = {0}, r[12];
+    if (stats) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rm_stats), z, sizeof(z));
     hipLaunchKernelGGL(raymarch_kernel, dim3((W + 15) / 16, (H + 15) / 16, N), dim3(256), 0, (hipStream_t)stream, raypos,
                        raydir, tminmax, stepsize, primpos, primrot, primscale, (const float4*)tplate, (float4*)rayrgba, N, H, W,
-                       K, TD, TH, TW, fadescale, fadeexp);
+                       K, TD, TH, TW, fadescale, fadeexp, stats);
+    if (stats) {
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        (void)hipMemcpyFromSymbol(r, HIP_SYMBOL(g_rm_stats), sizeof(r));
+        const double w = r[0] ? (double)r[0] : 1.0, mw = r[2] ? (double)r[2] : 1.0;
+        fprintf(stderr, "raymarch stats: %llu waves, hit list %.1f per wave; %llu marching waves: %.1f chunks, %.1f listed per chunk, "
+                        "%.0f steps, %.1f record evaluations per step; cycles per wave: hit list %.0f, rebuilds %.0f (per marching wave), "
+                        "marching %.0f (per marching wave), slowest wave %llu\n", r[0], r[1] / w, r[2], r[3] / mw, r[4] / (r[3] ? (double)r[3] : 1.0),
+                r[5] / mw, r[6] / (r[5] ? (double)r[5] : 1.0), r[7] / w, r[8] / mw, r[9] / mw, r[10]);
+    }
     PRIMX_CHECK_LAUNCH("primx_raymarch");
     return PRIMX_OK;
 }
