@@ -50,6 +50,9 @@ constexpr int BKV = 64;     // keys per tile
 #ifndef PRIMX_ATTN_NSTAGE
 #define PRIMX_ATTN_NSTAGE 3
 #endif
+#ifndef PRIMX_ATTN_ALLREADS_L
+#define PRIMX_ATTN_ALLREADS_L 1   // 1: the second V^T half is read in the light segment too (matrix segment without LDS reads; same box 58.5 -> 56.9 us)
+#endif
 #ifndef PRIMX_ATTN_PRIO
 #define PRIMX_ATTN_PRIO 1   // 1: s_setprio 1 around every matrix segment (same-box: 58.1 vs 59.5 us); 2: static prio for group 1 (no gain); 0: off
 #endif
@@ -241,12 +244,16 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     // LIGHT segment of step j on stage `st` = {K(j+1), V(j)}: DMA of pair j+2 into `st_refill` (last read, by either
     // group, before the barrier this segment started behind), fragment reads for QK^T(j+1) and the first half of PV(j),
     // row max of S(j) and the (rare) rescale of O.
-    auto seg_light = [&](int st, int st_refill, int jp, const f32x16 (&sc)[2], V8 (&kf)[2][KSTEPS], V8 (&vf0)[DTILES][2]) {
+    auto seg_light = [&](int st, int st_refill, int jp, const f32x16 (&sc)[2], V8 (&kf)[2][KSTEPS], V8 (&vf0)[DTILES][2],
+                         V8 (&vf1)[DTILES][2]) {
         if (idle) return;
         issue_pair(jp, st_refill);
         if (PROF) { __builtin_amdgcn_sched_barrier(0); stamp(pl_dma); }
         read_k(st, kf);
         read_v(st, 0, vf0);
+#if PRIMX_ATTN_ALLREADS_L
+        read_v(st, 1, vf1);
+#endif
         if (PROF) { __builtin_amdgcn_sched_barrier(0); stamp(pl_rd); }
         float mx = sc[0][0];
 #pragma unroll
@@ -273,15 +280,17 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     // MFMAs are in registers on entry; the second V^T half is read under the QK^T MFMAs.
     // (Moving the first exponentials into the light segment was measured: the matrix segment did not get shorter.)
     auto seg_matrix = [&](int st, int t_next, const f32x16 (&sc)[2], f32x16 (&sn)[2], const V8 (&kf)[2][KSTEPS],
-                          const V8 (&vf0)[DTILES][2]) {
+                          const V8 (&vf0)[DTILES][2], V8 (&vf1)[DTILES][2]) {
         if (idle) return;
 #if PRIMX_ATTN_PRIO == 1
         __builtin_amdgcn_s_setprio(1);   // the matrix segment outranks its partner's light segment at the issue arbiter
 #endif
         const float mc = m_run * c;
         float psum = 0.f;
-        V8 vf1[DTILES][2], pb0[2], pb1[2];
+        V8 pb0[2], pb1[2];
+#if !PRIMX_ATTN_ALLREADS_L
         read_v(st, 1, vf1);
+#endif
         qk(kf, t_next, sn);
         probs(sc[0], mc, psum, pb0);
         __builtin_amdgcn_sched_barrier(0);
@@ -318,25 +327,25 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     // segment (group 0 issues K pieces in its L(j), group 1 V^T pieces in its L(j)); pair j is complete before the
     // barrier in front of group 0's L(j) because every wave waits vmcnt(NSLOT) before EVERY barrier.
     int st = 0, st_free = NSTAGE - 1;
-    V8 kf[2][KSTEPS], vf0[DTILES][2];
+    V8 kf[2][KSTEPS], vf0[DTILES][2], vf1[DTILES][2];
     int j = 0;
     for (; j + 1 < ntiles; j += 2) {
         if (grp) { PRIMX_ATTN_WAITB(); stamp(pw); }
-        seg_light(st, st_free, j + NSTAGE - 1, sA, kf, vf0);
+        seg_light(st, st_free, j + NSTAGE - 1, sA, kf, vf0, vf1);
         stamp(pl);
         PRIMX_ATTN_WAITB();
         stamp(pw);
-        seg_matrix(st, j + 1, sA, sB, kf, vf0);      // softmax + PV of tile j, QK^T of tile j+1
+        seg_matrix(st, j + 1, sA, sB, kf, vf0, vf1);      // softmax + PV of tile j, QK^T of tile j+1
         stamp(pm);
         if (!grp) { PRIMX_ATTN_WAITB(); stamp(pw); }
         st_free = st;
         st = (st == NSTAGE - 1) ? 0 : st + 1;
         if (grp) { PRIMX_ATTN_WAITB(); stamp(pw); }
-        seg_light(st, st_free, j + NSTAGE, sB, kf, vf0);
+        seg_light(st, st_free, j + NSTAGE, sB, kf, vf0, vf1);
         stamp(pl);
         PRIMX_ATTN_WAITB();
         stamp(pw);
-        seg_matrix(st, min(j + 2, ntiles - 1), sB, sA, kf, vf0);
+        seg_matrix(st, min(j + 2, ntiles - 1), sB, sA, kf, vf0, vf1);
         stamp(pm);
         if (!grp) { PRIMX_ATTN_WAITB(); stamp(pw); }
         st_free = st;
@@ -345,9 +354,9 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     }
     if (j < ntiles) {                     // odd tile count (the DMAs are clamped and redundant: uniform vmcnt bookkeeping)
         if (grp) PRIMX_ATTN_WAITB();
-        seg_light(st, st_free, j + NSTAGE - 1, sA, kf, vf0);
+        seg_light(st, st_free, j + NSTAGE - 1, sA, kf, vf0, vf1);
         PRIMX_ATTN_WAITB();
-        seg_matrix(st, ntiles - 1, sA, sB, kf, vf0);
+        seg_matrix(st, ntiles - 1, sA, sB, kf, vf0, vf1);
         if (!grp) PRIMX_ATTN_WAITB();
     }
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): drain the clamped tail DMAs before the workgroup retires
