@@ -48,7 +48,8 @@ def test_timestep_embedding_and_mlp(ops):
     assert rel_l2(got, F.silu(F.linear(ref, W, b))) < 1e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(4096, 1152, 68), (2, 384, 256), (130, 70, 12)])
+@pytest.mark.parametrize("M,N,K", [(4096, 1152, 68), (2, 384, 256), (130, 70, 12),
+                                   (8, 1152, 1152), (1, 70, 12), (5, 333, 260), (9, 70, 260)])   # M <= 8: wave-per-column path
 def test_linear_f32(ops, M, N, K):
     import torch.nn.functional as F
     x, W, b = synth.tensor(3, "x", (M, K)), synth.tensor(3, "W", (N, K), K ** -0.5), synth.tensor(3, "b", (N,))
