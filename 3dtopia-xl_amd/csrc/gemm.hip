@@ -26,6 +26,7 @@
 // over channels-last [P, S^3, Cin] activations: k = tap * Cin + ci, row m = (p, voxel); out-of-volume taps
 // and any K tail read a 16-byte zero block instead of branching.
 #include <stdio.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -1106,7 +1107,13 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
     constexpr int STAGE = ROWS * KS;         // halves per stage
     constexpr int NINST = ROWS / 16;         // 34 wave-instructions (16 rows each) per stage
     constexpr int NSLOT = (NINST + 7) / 8;   // 5 (waves 0,1) / 4
-    __shared__ __attribute__((aligned(16))) S smem[NST * STAGE];
+    // EPI_HEADS stages the rounded 16-bit tile in LDS after the main loop (row-major [256][304] for the token-major
+    // layouts, transposed [288][272] for PRIMX_HEADS_VT); the strides put the 16 fragment rows of a wave 8 banks apart
+    constexpr int RS_ROWS = BN + 16, RS_VT = BM + 16;
+    constexpr int STG = (EPI == EPI_HEADS) ? ((BM * RS_ROWS > BN * RS_VT) ? BM * RS_ROWS : BN * RS_VT) : 0;
+    constexpr int LDS_HALVES = (NST * STAGE > STG) ? NST * STAGE : STG;
+    static_assert(LDS_HALVES * 2 <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1160,6 +1167,16 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
 #pragma unroll
         for (int j = 0; j < NPF; ++j) b_n[j] = *reinterpret_cast<const V8*>(base0 + w_off + j * 16 * KS);
     }
+    // Tile-uniform epilogue form of EPI_HEADS: a column tile of a PRIMX_HEADS_VT segment wants 4 consecutive TOKENS per
+    // lane, i.e. the plain operand order (accumulator = C); everything else swaps the operands (accumulator = C^T, 4
+    // consecutive columns per lane).  The main loop exists once per order; the choice is made once per workgroup.
+    bool vt_tile = false;
+    if (EPI == EPI_HEADS) {
+        const int seg = (n0 / (p.heads * p.dh)) % p.n_seg;
+        vt_tile = (seg == 0 ? p.kind[0] : seg == 1 ? p.kind[1] : p.kind[2]) == PRIMX_HEADS_VT;
+    }
+    auto main_loop = [&](auto swapped) {
+    constexpr bool SW = decltype(swapped)::value;
     int st = 0;
     for (int ks = 0; ks < nks; ++ks) {
         // slice ks+2 may stay in flight (4..5 DMAs per wave): <= 4 outstanding means slices ks and ks+1 have landed;
@@ -1182,7 +1199,8 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
         for (int j = 0; j < NI; ++j) {
             if (j < NSLOT) issue_one(ks_fill, st_fill, j);
 #pragma unroll
-            for (int i = 0; i < MI; ++i) acc[i][j] = T16<DT>::mfma16(b[j], a[i], acc[i][j]);
+            for (int i = 0; i < MI; ++i)
+                acc[i][j] = SW ? T16<DT>::mfma16(b[j], a[i], acc[i][j]) : T16<DT>::mfma16(a[i], b[j], acc[i][j]);
             if (j == NPF) {   // the prefetched registers are free now: fetch slice ks+1's (clamped reads past the end are unused)
 #pragma unroll
                 for (int i = 0; i < MI; ++i) a_n[i] = *reinterpret_cast<const V8*>(base_n + a_off + i * 16 * KS);
@@ -1192,10 +1210,100 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
         }
         st = st_next;
     }
+    };
+    if (EPI == EPI_HEADS && vt_tile) main_loop(std::false_type{});
+    else main_loop(std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (clamped tail DMAs)
 
-    // ---- epilogue from registers: acc[i][j][r] = C[m0 + wm*64 + i*16 + lr][n0 + wn*144 + j*16 + 4*lg + r]
     using V4e = typename T16<DT>::V4;
+    if (EPI == EPI_HEADS) {
+        // ---- heads epilogue through LDS (host guarantees: per % 288 == 0, 288 % dh == 0, dh % 8 == 0,
+        // rows_per_batch % 256 == 0, so the tile lies in ONE (repetition, segment, batch entry) and covers whole heads).
+        // Phase 1 parks bias + rounding (+ scale0) results as 16-bit values; phase 2 walks the tile in DESTINATION order
+        // with 16-byte accesses and almost no live registers (the register-resident scatter spilled at this tile size).
+        const int per = p.heads * p.dh;
+        const int seg_all = n0 / per, rep_i = seg_all / p.n_seg, seg = seg_all - rep_i * p.n_seg;
+        const int hh0 = (n0 - seg_all * per) / p.dh;
+        const int bb = m0 / p.rows_per_batch, tok0 = m0 - bb * p.rows_per_batch;
+        const int kind = seg == 0 ? p.kind[0] : seg == 1 ? p.kind[1] : p.kind[2];
+        S* dst = (seg == 0 ? p.dst[0] : seg == 1 ? p.dst[1] : p.dst[2]) +
+                 rep_i * (seg == 0 ? p.rep_stride[0] : seg == 1 ? p.rep_stride[1] : p.rep_stride[2]);
+        const float sc = (seg == 0) ? p.scale0 : 1.0f;
+        __syncthreads();   // every wave is done with the operand stages
+        if (!vt_tile) {
+            // acc[i][j][r] = C[wm*64 + i*16 + lr][wn*144 + j*16 + 4*lg + r]
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                V4e bv = V4e{};
+                if (p.bias) bv = *reinterpret_cast<const V4e*>(p.bias + n0 + wn * 144 + j * 16 + 4 * lg);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    V4e o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float y = rnd16<DT>(acc[i][j][r] + (float)bv[r]);
+                        if (sc != 1.0f) y = rnd16<DT>(sc * y);
+                        o[r] = (S)y;
+                    }
+                    *reinterpret_cast<V4e*>(smem + (wm * 64 + i * 16 + lr) * RS_ROWS + wn * 144 + j * 16 + 4 * lg) = o;
+                }
+            }
+            __syncthreads();
+            const int rs = heads_row_stride(kind, p.DP);
+#pragma unroll 6
+            for (int it = 0; it < (BM * (BN / 8)) / 512; ++it) {      // 9216 (row, 8-column) units / 512 threads = 18
+                const int u = tid + 512 * it;
+                const int row = u / (BN / 8), c = u - row * (BN / 8);
+                int d = 8 * c, hl = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (d >= p.dh) { d -= p.dh; ++hl; }
+                const V8 v = *reinterpret_cast<const V8*>(smem + row * RS_ROWS + 8 * c);
+                if (m0 + row < p.M)
+                    *reinterpret_cast<V8*>(dst + (((int64_t)bb * p.heads + hh0 + hl) * p.n_pad + tok0 + row) * rs + d) = v;
+            }
+        } else {
+            // acc[i][j][r] = C[wm*64 + i*16 + 4*lg + r][wn*144 + j*16 + lr]  ->  staged transposed [column][token]
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const float bj = p.bias ? (float)p.bias[n0 + wn * 144 + j * 16 + lr] : 0.f;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    V4e o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float y = rnd16<DT>(acc[i][j][r] + bj);
+                        if (sc != 1.0f) y = rnd16<DT>(sc * y);
+                        o[r] = (S)y;
+                    }
+                    *reinterpret_cast<V4e*>(smem + (wn * 144 + j * 16 + lr) * RS_VT + wm * 64 + i * 16 + 4 * lg) = o;
+                }
+            }
+            __syncthreads();
+#pragma unroll 3
+            for (int it = 0; it < (BN * (BM / 16)) / 512; ++it) {     // 4608 (column, 16-token) units / 512 threads = 9
+                const int u = tid + 512 * it;
+                const int col = u >> 4, g = u & 15;
+                int d = col, hl = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (d >= p.dh) { d -= p.dh; ++hl; }
+                const V8 lo = *reinterpret_cast<const V8*>(smem + col * RS_VT + 16 * g);
+                const V8 hi = *reinterpret_cast<const V8*>(smem + col * RS_VT + 16 * g + 8);
+                // vt_key_pos: the 4-key quads of a group of 16 are stored in the order {0, 2, 1, 3}
+                const V8 o0 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const V8 o1 = {lo[4], lo[5], lo[6], lo[7], hi[4], hi[5], hi[6], hi[7]};
+                S* rowp = dst + (((int64_t)bb * p.heads + hh0 + hl) * p.DP + d) * p.n_pad + tok0 + 16 * g;
+                if (m0 + 16 * g < p.M) {
+                    *reinterpret_cast<V8*>(rowp) = o0;
+                    *reinterpret_cast<V8*>(rowp + 8) = o1;
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- epilogue from registers: acc[i][j][r] = C[m0 + wm*64 + i*16 + lr][n0 + wn*144 + j*16 + 4*lg + r]
     const int nb = n0 + wn * 144 + 4 * lg;
     V4e bpre[NI];
 #pragma unroll
@@ -1257,6 +1365,11 @@ static const bool g_big_q = [] {   // PRIMX_GEMM_BIGQ=0: 256x288 kernel with the
     return !(e && e[0] == '0');
 }();
 
+static const int g_big_heads_min = [] {   // fewest 256x288 workgroups for which the heads epilogue takes the big tile
+    const char* e = getenv("PRIMX_GEMM_BIGHEADS_MIN");
+    return e ? atoi(e) : 160;
+}();
+
 static const int g_gemm_prof_mode = [] {   // PRIMX_GEMM_PROF=1: synchronous launches + timeline print; 2: without MFMAs and
     const char* e = getenv("PRIMX_GEMM_PROF");   // fragment reads (DMA-only bound probe); 3: without MFMAs
     return e ? atoi(e) : 0;
@@ -1311,8 +1424,16 @@ int launch(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
     // 256x288 tile: only where same-box A/B showed a win - the dense-output epilogues with enough workgroups to fill
     // the chip (fc1 at T = 4096: exactly 256; every large-batch GEMM).  The heads epilogue stays on the 128x144 kernel
     // (qkv would be 192 workgroups = 75 % of the CUs, and the scatter epilogue spilled at this tile's register budget).
-    const bool use_big = !g_no_big && a.N % 288 == 0 && ((a.M + 255) / 256) * (a.N / 288) >= 224 &&
-                         (EPI == EPI_LINEAR || EPI == EPI_RES || EPI == EPI_GATE_RESIDUAL);
+    bool use_big = !g_no_big && a.N % 288 == 0 && ((a.M + 255) / 256) * (a.N / 288) >= 224 &&
+                   (EPI == EPI_LINEAR || EPI == EPI_RES || EPI == EPI_GATE_RESIDUAL);
+    // Heads epilogue on the 256x288 tile (LDS-staged scatter, gemm288q only): tiles must cover whole heads of one
+    // segment and one batch entry.  It already pays at 192 workgroups (qkv at T = 4096: 75 % of the CUs, one round
+    // instead of three rounds of 128x144 tiles); PRIMX_GEMM_BIGHEADS_MIN moves the threshold (0 = never).
+    if (EPI == EPI_HEADS && !g_no_big && g_big_q && !g_gemm_prof_on && g_big_heads_min > 0 && a.heads > 0) {
+        const int per = a.heads * a.dh;
+        use_big = a.N % 288 == 0 && per % 288 == 0 && 288 % a.dh == 0 && a.dh % 8 == 0 && a.rows_per_batch % 256 == 0 &&
+                  (a.M / 256) * (a.N / 288) >= g_big_heads_min;
+    }
 #define PRIMX_GEMM_LAUNCH(KT)                                                                                         \
     do {                                                                                                              \
         if (a.N <= 32) {                                                                                              \

@@ -46,12 +46,19 @@ def _stream() -> int:
 PROFILE = None
 
 
-def _gemm_tag(epi: int, M: int, N: int, K: int, dtype) -> str:
+def _gemm_tag(epi: int, M: int, N: int, K: int, dtype, heads=None) -> str:
     """Name of the kernel instantiation the C side selects (csrc/gemm.hip launch()), spelled as rocprofv3 prints
     it, so bench.py's per-kernel numbers can be matched against profiles/*kernel_trace_summary.txt."""
     dt = dtype_code(dtype)
     if N <= 32:
         return f"gemm_kernel<{dt}, {epi}, 32, 4, 1, 1, 1, 0, {int(K % 64 != 0)}>"
+    if epi == 2 and heads is not None and K % 64 == 0 and os.environ.get("PRIMX_GEMM_PROF") is None \
+            and os.environ.get("PRIMX_GEMM_BIGQ", "1") != "0" and os.environ.get("PRIMX_GEMM_NOBIG") != "1":
+        H, dh, rows = heads       # heads epilogue on the 256x288 tile (csrc/gemm.hip launch(): whole heads, one batch entry)
+        wg_min = int(os.environ.get("PRIMX_GEMM_BIGHEADS_MIN", "160"))
+        if wg_min > 0 and N % 288 == 0 and (H * dh) % 288 == 0 and 288 % dh == 0 and dh % 8 == 0 and rows % 256 == 0 \
+                and (M // 256) * (N // 288) >= wg_min:
+            return f"gemm288q_dma_kernel<{dt}, {epi}>"
     if epi != 2 and N % 288 == 0 and K % 64 == 0 and ((M + 255) // 256) * (N // 288) >= 224:
         q = "" if os.environ.get("PRIMX_GEMM_BIGQ", "1") == "0" or os.environ.get("PRIMX_GEMM_PROF") == "1" else "q"
         return f"gemm288{q}_dma_kernel<{dt}, {epi}>"
@@ -194,7 +201,7 @@ def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     n_seg = len(kinds)
     kind_arr = (C.c_int * n_seg)(*kinds)
     dst_arr = (C.c_void_p * n_seg)(*[_dev(d, "dst", A.dtype) for d in dsts])
-    _timed(_gemm_tag(2, M, N, K, A.dtype), 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_heads(
+    _timed(_gemm_tag(2, M, N, K, A.dtype, (heads, dh, rows_per_batch)), 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_heads(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None, M, N, K,
         rows_per_batch, heads, dh, n_seg, kind_arr, dst_arr, n_rep, rep_batches, n_pad, scale0, dtype_code(A.dtype),
         _stream()),

@@ -75,7 +75,8 @@ def test_linear_gate_residual(ops, dtype):
 
 
 @pytest.mark.parametrize("B,n,H,dh,K,n_rep", [(2, 70, 4, 72, 64, 3), (1, 1370, 16, 72, 768, 2),
-                                             (2, 1370, 16, 72, 768, 5)])   # the last one takes the 256x288 tile
+                                             (2, 1370, 16, 72, 768, 5),
+                                             (2, 2048, 16, 72, 64, 2)])   # the last one takes the 256x288 tile (256 workgroups)
 def test_linear_heads_repeated(ops, B, n, H, dh, K, n_rep):
     """to_k / to_v of several blocks batched in one GEMM (N = n_rep * 2 * D): repetition r fills batch entries
     [r*B, (r+1)*B) of the K (padded row stride) and V^T destinations."""
@@ -98,7 +99,8 @@ def test_linear_heads_repeated(ops, B, n, H, dh, K, n_rep):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("B,n,H,dh,K", [(2, 256, 16, 72, 1152), (3, 70, 4, 72, 64), (1, 1370, 16, 72, 768),
-                                       (2, 64, 8, 32, 256), (1, 1, 6, 64, 128)])
+                                       (2, 64, 8, 32, 256), (1, 1, 6, 64, 128),
+                                       (2, 2048, 16, 72, 256), (1, 4096, 16, 72, 128)])   # 256x288 tile, LDS-staged scatter
 def test_linear_heads_layouts(ops, dtype, B, n, H, dh, K):
     """qkv projection written straight into the attention layouts == Linear + reshape + unbind."""
     from topia_xl_amd._lib import HEADS_KROWS, HEADS_ROWS, HEADS_VT

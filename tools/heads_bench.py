@@ -29,3 +29,5 @@ run("k_only", 2740, 1370, 768, [HEADS_ROWS], 28)
 run("v_only", 2740, 1370, 768, [HEADS_VT], 28)
 run("kk_all", 2740, 1370, 768, [HEADS_KROWS, HEADS_KROWS], 28)
 run("qkk", 4096, 2048, 1152, [HEADS_ROWS, HEADS_KROWS, HEADS_KROWS], 1)
+run("qkv_b4", 16384, 2048, 1152, [HEADS_ROWS, HEADS_KROWS, HEADS_VT], 1)
+run("to_q_b4", 16384, 2048, 1152, [HEADS_ROWS], 1)
