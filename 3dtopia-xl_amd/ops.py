@@ -146,8 +146,11 @@ def silu_cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return out
 
 
-def cast16(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+def cast16(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    elif out.dtype != dtype or out.numel() != x.numel() or not out.is_contiguous():
+        raise RuntimeError("cast16: out must be a contiguous tensor of the target dtype with x.numel() elements")
     check(_lib.load().primx_cast16(_dev(x, "x", torch.float32), out.data_ptr(), dtype_code(dtype), x.numel(),
                                    _stream()), "primx_cast16")
     return out

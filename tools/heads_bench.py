@@ -31,3 +31,4 @@ run("kk_all", 2740, 1370, 768, [HEADS_KROWS, HEADS_KROWS], 28)
 run("qkk", 4096, 2048, 1152, [HEADS_ROWS, HEADS_KROWS, HEADS_KROWS], 1)
 run("qkv_b4", 16384, 2048, 1152, [HEADS_ROWS, HEADS_KROWS, HEADS_VT], 1)
 run("to_q_b4", 16384, 2048, 1152, [HEADS_ROWS], 1)
+run("kv_pad", 3072, 1536, 768, [HEADS_KROWS, HEADS_VT], 28)   # 1370 conditioning rows padded to 1536 (dit.py)
