@@ -1464,12 +1464,73 @@ int ilog2_exact(int v) {
     return (1 << l) == v ? l : -1;
 }
 
+// Few-row Linear (M <= 4: the adaLN modulation of every block from the B_e timestep embeddings, one 669 MB weight
+// stream per forward at DiT-XL).  HBM-bound: a wave owns 4 output columns, streams their W rows with 16-byte loads and
+// keeps M x 4 fp32 partial sums; A (a few KB) comes from L1.  The MFMA tiles spent 180 us on it (256-row tiles with 2
+// valid rows: 1.26 GB through the L2 -> LDS path); PRIMX_GEMM_NOGEMV=1 goes back to them.
+constexpr int GEMV_ROWS = 4, GEMV_COLS = 4;
+template <int DT>
+__global__ __launch_bounds__(256) void gemv16_kernel(const typename T16<DT>::S* __restrict__ A,
+                                                     const typename T16<DT>::S* __restrict__ W,
+                                                     const typename T16<DT>::S* __restrict__ bias,
+                                                     typename T16<DT>::S* __restrict__ out, int M, int N, int K) {
+    using S = typename T16<DT>::S;
+    using V8 = typename T16<DT>::V8;
+    using V4 = typename T16<DT>::V4;
+    const int lane = threadIdx.x & 63;
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GEMV_COLS;
+    if (n0 >= N) return;
+    float acc[GEMV_ROWS][GEMV_COLS] = {};
+    for (int kc = lane; kc < K / 8; kc += 64) {
+        V8 w[GEMV_COLS];
+#pragma unroll
+        for (int c = 0; c < GEMV_COLS; ++c)   // streamed once per forward: non-temporal
+            w[c] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(W + (int64_t)(n0 + c) * K + kc * 8));
+#pragma unroll
+        for (int m = 0; m < GEMV_ROWS; ++m) {
+            if (m < M) {
+                const V8 a = *reinterpret_cast<const V8*>(A + (int64_t)m * K + kc * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float af = (float)a[e];
+#pragma unroll
+                    for (int c = 0; c < GEMV_COLS; ++c) acc[m][c] = fmaf(af, (float)w[c][e], acc[m][c]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < GEMV_ROWS; ++m) {
+        if (m >= M) break;
+        V4 o;
+#pragma unroll
+        for (int c = 0; c < GEMV_COLS; ++c) o[c] = (S)(wave_sum(acc[m][c]) + (bias ? (float)bias[n0 + c] : 0.f));
+        if (lane == 0) *reinterpret_cast<V4*>(out + (int64_t)m * N + n0) = o;
+    }
+}
+
+static const bool g_no_gemv = [] {
+    const char* e = getenv("PRIMX_GEMM_NOGEMV");
+    return e && e[0] == '1';
+}();
+
 }  // namespace
 
 extern "C" int primx_linear(const void* A, const void* W, const void* bias, void* out, int M, int N, int K, int dtype,
                             int act, float out_scale, void* stream) {
     PRIMX_REQUIRE(out, "primx_linear: null output");
     PRIMX_REQUIRE(act == PRIMX_ACT_NONE || act == PRIMX_ACT_GELU_TANH || act == PRIMX_ACT_GELU_ERF, "primx_linear: bad activation code");
+    if (M > 0 && M <= GEMV_ROWS && N % GEMV_COLS == 0 && K > 0 && K % 8 == 0 && act == PRIMX_ACT_NONE &&
+        out_scale == 1.0f && !g_no_gemv) {
+        PRIMX_REQUIRE(A && W, "primx_linear: null operand");
+        PRIMX_DISPATCH_16(dtype, "primx_linear", {
+            using S = typename T16<DT>::S;
+            hipLaunchKernelGGL((gemv16_kernel<DT>), dim3((N / GEMV_COLS + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                               (const S*)A, (const S*)W, (const S*)bias, (S*)out, M, N, K);
+            PRIMX_CHECK_LAUNCH("primx_linear");
+            return PRIMX_OK;
+        });
+    }
     PRIMX_DISPATCH_16(dtype, "primx_linear", {
         using S = typename T16<DT>::S;
         GemmArgs<DT> a = {};

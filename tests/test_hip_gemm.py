@@ -30,7 +30,8 @@ def _mk(seed, M, N, K, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (4096, 1152, 1152), (2, 2304, 384), (300, 136, 1152),
-                                   (1370, 200, 768), (129, 129, 4608)])
+                                   (1370, 200, 768), (129, 129, 4608),
+                                   (1, 1152, 1152), (3, 20740, 264), (4, 4612, 1152), (5, 4612, 128)])   # M <= 4: streaming GEMV
 def test_linear_plain(ops, dtype, M, N, K):
     A, W, b, ref = _mk(11, M, N, K, dtype)
     got = ops.linear(A.to(DEV), W.to(DEV), b.to(DEV))

@@ -10,7 +10,7 @@ dev = "cuda:0"
 dt = torch.float16
 reps = int(os.environ.get("REPS", "20"))
 shapes = [("proj", 4096, 1152, 1152), ("fc2", 4096, 1152, 4608), ("qkv", 4096, 3456, 1152), ("fc1", 4096, 4608, 1152),
-          ("kv", 2740, 2304, 768), ("big_proj", 32768, 1152, 1152), ("big_fc1", 32768, 4608, 1152), ("n128", 4096, 1024, 1152)]
+          ("kv", 2740, 2304, 768), ("big_proj", 32768, 1152, 1152), ("big_fc1", 32768, 4608, 1152), ("n128", 4096, 1024, 1152), ("adaLN", 2, 28 * 9 * 1152 + 2 * 1152, 1152)]
 only = os.environ.get("ONLY")
 for name, M, N, K in shapes:
     if only and name not in only.split(","):
