@@ -236,6 +236,24 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs<DT>& p, const ColIn
 // `bv`: the four bias values of columns n..n+3, loaded by the caller BEFORE its store loop (a load issued between
 // the stores cannot be hoisted by the compiler - the output may alias it - and each one then costs a full memory
 // round trip: 9 x ~775 cycles per tile, PRIMX_GEMM_PROF).
+// EPI_LINEAR arithmetic of four consecutive columns: bias, rounding, activation, scale - each rounded to the 16-bit
+// type like the separate autocast ops of the reference.
+template <int DT>
+__device__ __forceinline__ typename T16<DT>::V4 linear_out4(const GemmArgs<DT>& p, const f32x4 a,
+                                                            const typename T16<DT>::V4 bv) {
+    using S = typename T16<DT>::S;
+    typename T16<DT>::V4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float y = rnd16<DT>(a[j] + (p.bias ? (float)bv[j] : 0.f));
+        if (p.act == PRIMX_ACT_GELU_TANH) y = rnd16<DT>(gelu_tanh_f(y));
+        else if (p.act == PRIMX_ACT_GELU_ERF) y = rnd16<DT>(gelu_erf_f(y));
+        if (p.out_scale != 1.0f) y = rnd16<DT>(p.out_scale * y);
+        o[j] = (S)y;
+    }
+    return o;
+}
+
 template <int DT, int EPI>
 __device__ __forceinline__ void epilogue_row4(const GemmArgs<DT>& p, int m, int n, const f32x4 a,
                                               const typename T16<DT>::V4 bv) {
@@ -247,16 +265,7 @@ __device__ __forceinline__ void epilogue_row4(const GemmArgs<DT>& p, int m, int 
         for (int j = 0; j < 4; ++j) b[j] = (float)bv[j];
     }
     if (EPI == EPI_LINEAR) {
-        V4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float y = rnd16<DT>(a[j] + b[j]);
-            if (p.act == PRIMX_ACT_GELU_TANH) y = rnd16<DT>(gelu_tanh_f(y));
-            else if (p.act == PRIMX_ACT_GELU_ERF) y = rnd16<DT>(gelu_erf_f(y));
-            if (p.out_scale != 1.0f) y = rnd16<DT>(p.out_scale * y);
-            o[j] = (S)y;
-        }
-        *reinterpret_cast<V4*>(p.out + (int64_t)m * p.N + n) = o;
+        *reinterpret_cast<V4*>(p.out + (int64_t)m * p.N + n) = linear_out4<DT>(p, a, bv);
     } else if (EPI == EPI_RES) {
         float r[4] = {0.f, 0.f, 0.f, 0.f};
         if (p.res) {
@@ -1098,6 +1107,8 @@ __global__ __launch_bounds__(512, 2) void gemm288_dma_kernel(const GemmArgs<DT> 
 // 256-byte bank window, the XOR separates rows 0-7 from 8-15 which the groups pair with chunk c and c+1).
 template <int DT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT> p) {
+    unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pc2 = 0;   // PRIMX_GEMM_PROF=1 timeline (see g_gemm_prof)
+    if (p.prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
     typedef __attribute__((address_space(1))) const void GV;
@@ -1110,7 +1121,8 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
     // EPI_HEADS stages the rounded 16-bit tile in LDS after the main loop (row-major [256][304] for the token-major
     // layouts, transposed [288][272] for PRIMX_HEADS_VT); the strides put the 16 fragment rows of a wave 8 banks apart
     constexpr int RS_ROWS = BN + 16, RS_VT = BM + 16;
-    constexpr int STG = (EPI == EPI_HEADS) ? ((BM * RS_ROWS > BN * RS_VT) ? BM * RS_ROWS : BN * RS_VT) : 0;
+    constexpr int STG = (EPI == EPI_HEADS) ? ((BM * RS_ROWS > BN * RS_VT) ? BM * RS_ROWS : BN * RS_VT)
+                        : (EPI == EPI_LINEAR) ? BM * RS_ROWS : 0;
     constexpr int LDS_HALVES = (NST * STAGE > STG) ? NST * STAGE : STG;
     static_assert(LDS_HALVES * 2 <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES];
@@ -1160,6 +1172,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
     constexpr int NPF = 3;
     V8 a_n[MI], b_n[NPF];
     asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");     // slice 0 landed
+    if (p.prof) pc1 = __builtin_readcyclecounter();
     {
         const S* base0 = smem;
 #pragma unroll
@@ -1214,6 +1227,18 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
     if (EPI == EPI_HEADS && vt_tile) main_loop(std::false_type{});
     else main_loop(std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (clamped tail DMAs)
+    if (p.prof) pc2 = __builtin_readcyclecounter();
+    auto prof_end = [&]() {
+        if (p.prof) {
+            __builtin_amdgcn_s_waitcnt(0);   // the epilogue's stores have been issued AND acknowledged
+            const unsigned long long pc3 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0) {
+                atomicMin(&g_gemm_prof[0], pr0); atomicMax(&g_gemm_prof[1], pr1);
+                atomicAdd(&g_gemm_prof[2], pc1 - pc0); atomicAdd(&g_gemm_prof[3], pc2 - pc1);
+                atomicAdd(&g_gemm_prof[4], pc3 - pc2); atomicAdd(&g_gemm_prof[5], 1ull); atomicAdd(&g_gemm_prof[6], pr0);
+            }
+        }
+    };
 
     using V4e = typename T16<DT>::V4;
     if (EPI == EPI_HEADS) {
@@ -1300,6 +1325,36 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
                 }
             }
         }
+        prof_end();
+        return;
+    }
+
+    if (EPI == EPI_LINEAR) {
+        // ---- dense 16-bit output through LDS: the register form below stores 8 bytes per lane in 32-byte runs (16 rows per
+        // wave-instruction) and measured 33k cycles per tile at fc1 (PRIMX_GEMM_PROF), a third of the kernel; parked
+        // row-major in LDS the tile leaves as 16-byte stores, 576 contiguous bytes per row.
+        V4e bpre[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            bpre[j] = V4e{};
+            if (p.bias) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + n0 + wn * 144 + j * 16 + 4 * lg);
+        }
+        __syncthreads();   // every wave is done with the operand stages
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                *reinterpret_cast<V4e*>(smem + (wm * 64 + i * 16 + lr) * RS_ROWS + wn * 144 + j * 16 + 4 * lg) =
+                    linear_out4<DT>(p, acc[i][j], bpre[j]);
+        __syncthreads();
+#pragma unroll 6
+        for (int it = 0; it < (BM * (BN / 8)) / 512; ++it) {      // 9216 (row, 8-column) units / 512 threads = 18
+            const int u = tid + 512 * it;
+            const int row = u / (BN / 8), c = u - row * (BN / 8);
+            const V8 v = *reinterpret_cast<const V8*>(smem + row * RS_ROWS + 8 * c);
+            if (m0 + row < p.M) *reinterpret_cast<V8*>(p.out + (int64_t)(m0 + row) * p.N + n0 + 8 * c) = v;
+        }
+        prof_end();
         return;
     }
 
@@ -1339,6 +1394,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
                 if (ok) epilogue_row4<DT, EPI>(p, m, nb + j * 16, acc[i][j], bpre[j]);
         }
     }
+    prof_end();
 }
 
 // PRIMX_GEMM_REGSTAGE=1 selects the register-staged T144 kernel instead of the LDS-DMA one (A/B measurements)
@@ -1380,7 +1436,7 @@ template <int DT, int EPI, int BIG = 0>
 void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     const dim3 grid(BIG ? ((a.M + 255) / 256) * (a.N / 288) : mt * (a.N / 144));
     auto go = [&](const GemmArgs<DT>& x) {
-        if (BIG && g_big_q && !g_gemm_prof_on && x.K % 32 == 0) hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
+        if (BIG && g_big_q && x.K % 32 == 0) hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
         else if (BIG) hipLaunchKernelGGL((gemm288_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
         else if (g_reg_epi) hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI, 1>), grid, dim3(512), 0, st, x);
         else hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI, 0>), grid, dim3(512), 0, st, x);
@@ -1405,10 +1461,10 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     const double n = r[5] ? (double)r[5] : 1.0;
     fprintf(stderr, "%s<%d,%d> M=%d N=%d K=%d: %llu workgroups, events %.1f us, first start -> last end %.1f us, mean start offset "
                     "%.1f us; per workgroup (core cycles): entry->tile0 %.0f | main loop %.0f | epilogue %.0f (LDS staging %.0f, read+store issue %.0f)\n",
-            BIG ? "gemm288_dma" : "gemm144_dma", DT, EPI, a.M, a.N, a.K,
+            BIG ? (g_big_q ? "gemm288q_dma" : "gemm288_dma") : "gemm144_dma", DT, EPI, a.M, a.N, a.K,
             r[5], ms * 1e3, (r[1] - r[0]) * 0.01, (r[6] / n - (double)r[0]) * 0.01, r[2] / n, r[3] / n, r[4] / n, (r[7] >> 32) / n,
             (r[7] & 0xffffffffull) / n);
-    if (BIG)
+    if (BIG && !g_big_q)
         fprintf(stderr, "   per k-tile (wave 0 of each workgroup, core cycles): wait DMA + barrier %.0f | reads + 72 MFMAs %.0f | lgkm + barrier %.0f | DMA issue %.0f\n",
                 r[8] / n, r[9] / n, r[10] / n, r[11] / n);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
@@ -1426,10 +1482,11 @@ int launch(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
     // (qkv would be 192 workgroups = 75 % of the CUs, and the scatter epilogue spilled at this tile's register budget).
     bool use_big = !g_no_big && a.N % 288 == 0 && ((a.M + 255) / 256) * (a.N / 288) >= 224 &&
                    (EPI == EPI_LINEAR || EPI == EPI_RES || EPI == EPI_GATE_RESIDUAL);
+    if (EPI == EPI_LINEAR && g_big_q && (reinterpret_cast<uintptr_t>(a.out) & 15) != 0) use_big = false;  // its 16-byte stores
     // Heads epilogue on the 256x288 tile (LDS-staged scatter, gemm288q only): tiles must cover whole heads of one
     // segment and one batch entry.  It already pays at 192 workgroups (qkv at T = 4096: 75 % of the CUs, one round
     // instead of three rounds of 128x144 tiles); PRIMX_GEMM_BIGHEADS_MIN moves the threshold (0 = never).
-    if (EPI == EPI_HEADS && !g_no_big && g_big_q && !g_gemm_prof_on && g_big_heads_min > 0 && a.heads > 0) {
+    if (EPI == EPI_HEADS && !g_no_big && g_big_q && g_big_heads_min > 0 && a.heads > 0) {
         const int per = a.heads * a.dh;
         use_big = a.N % 288 == 0 && per % 288 == 0 && 288 % a.dh == 0 && a.dh % 8 == 0 && a.rows_per_batch % 256 == 0 &&
                   (a.M / 256) * (a.N / 288) >= g_big_heads_min;

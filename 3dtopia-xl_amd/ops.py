@@ -52,7 +52,7 @@ def _gemm_tag(epi: int, M: int, N: int, K: int, dtype, heads=None) -> str:
     dt = dtype_code(dtype)
     if N <= 32:
         return f"gemm_kernel<{dt}, {epi}, 32, 4, 1, 1, 1, 0, {int(K % 64 != 0)}>"
-    if epi == 2 and heads is not None and K % 64 == 0 and os.environ.get("PRIMX_GEMM_PROF") is None \
+    if epi == 2 and heads is not None and K % 64 == 0 \
             and os.environ.get("PRIMX_GEMM_BIGQ", "1") != "0" and os.environ.get("PRIMX_GEMM_NOBIG") != "1":
         H, dh, rows = heads       # heads epilogue on the 256x288 tile (csrc/gemm.hip launch(): whole heads, one batch entry)
         wg_min = int(os.environ.get("PRIMX_GEMM_BIGHEADS_MIN", "160"))
@@ -60,7 +60,7 @@ def _gemm_tag(epi: int, M: int, N: int, K: int, dtype, heads=None) -> str:
                 and (M // 256) * (N // 288) >= wg_min:
             return f"gemm288q_dma_kernel<{dt}, {epi}>"
     if epi != 2 and N % 288 == 0 and K % 64 == 0 and ((M + 255) // 256) * (N // 288) >= 224:
-        q = "" if os.environ.get("PRIMX_GEMM_BIGQ", "1") == "0" or os.environ.get("PRIMX_GEMM_PROF") == "1" else "q"
+        q = "" if os.environ.get("PRIMX_GEMM_BIGQ", "1") == "0" else "q"
         return f"gemm288{q}_dma_kernel<{dt}, {epi}>"
     if N % 144 == 0:
         regepi = int(os.environ.get("PRIMX_GEMM_REGEPI", "0") == "1")

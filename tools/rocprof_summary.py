@@ -29,6 +29,33 @@ def main():
     for name, gx, gy, n, a, vg, ag, lds in rows:
         print(f"{n:7d} {a/1e3:10.2f} {str(gx//256)+'x'+str(gy):>14} {vg:5d} {ag:5d} {lds:7d}  {short(name, 80)}", file=out)
 
+    # ---- idle time between consecutive kernels (same queue, dependent launches): where the step time that is in no kernel goes
+    try:
+        ks = db.execute('select name, start, "end" from kernels order by start').fetchall()
+    except sqlite3.Error as e:  # older rocpd schemas
+        print(f"\n# (no gap analysis: {e})", file=out)
+        return
+    if len(ks) < 2:
+        return
+    gaps = [(ks[i + 1][1] - ks[i][2], ks[i][0], ks[i + 1][0]) for i in range(len(ks) - 1)]
+    small = [g for g in gaps if 0 <= g[0] < 50_000]           # < 50 us: back-to-back launches (larger = host-side pauses)
+    span = ks[-1][2] - ks[0][1]
+    print(f"\n# gaps between consecutive kernels: {len(gaps)} boundaries over {span/1e3:.0f} us of trace; "
+          f"{len(small)} back-to-back (< 50 us) with {sum(g[0] for g in small)/1e3:.1f} us idle in total "
+          f"(mean {sum(g[0] for g in small)/max(1, len(small))/1e3:.2f} us), {sum(1 for g in gaps if g[0] < 0)} overlapping", file=out)
+    edges = [0, 1000, 2000, 3000, 4000, 6000, 10000, 50000]
+    hist = [sum(1 for g in small if lo <= g[0] < hi) for lo, hi in zip(edges[:-1], edges[1:])]
+    print("# histogram (us): " + "  ".join(f"[{lo/1e3:g},{hi/1e3:g}) {n}" for lo, hi, n in zip(edges[:-1], edges[1:], hist)), file=out)
+    by_pred = {}
+    for g, pred, _ in small:
+        k = short(pred, 60)
+        t = by_pred.setdefault(k, [0, 0])
+        t[0] += 1
+        t[1] += g
+    print("# idle after each kernel (back-to-back boundaries): count, mean us", file=out)
+    for k, (n, t) in sorted(by_pred.items(), key=lambda kv: -kv[1][1])[:12]:
+        print(f"{n:7d} {t/n/1e3:8.2f}  {k}", file=out)
+
 
 if __name__ == "__main__":
     main()
