@@ -1121,8 +1121,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
     // EPI_HEADS stages the rounded 16-bit tile in LDS after the main loop (row-major [256][304] for the token-major
     // layouts, transposed [288][272] for PRIMX_HEADS_VT); the strides put the 16 fragment rows of a wave 8 banks apart
     constexpr int RS_ROWS = BN + 16, RS_VT = BM + 16;
-    constexpr int STG = (EPI == EPI_HEADS) ? ((BM * RS_ROWS > BN * RS_VT) ? BM * RS_ROWS : BN * RS_VT)
-                        : (EPI == EPI_LINEAR) ? BM * RS_ROWS : 0;
+    constexpr int STG = (EPI == EPI_HEADS) ? ((BM * RS_ROWS > BN * RS_VT) ? BM * RS_ROWS : BN * RS_VT) : 0;
     constexpr int LDS_HALVES = (NST * STAGE > STG) ? NST * STAGE : STG;
     static_assert(LDS_HALVES * 2 <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES];
@@ -1329,35 +1328,9 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
         return;
     }
 
-    if (EPI == EPI_LINEAR) {
-        // ---- dense 16-bit output through LDS: the register form below stores 8 bytes per lane in 32-byte runs (16 rows per
-        // wave-instruction) and measured 33k cycles per tile at fc1 (PRIMX_GEMM_PROF), a third of the kernel; parked
-        // row-major in LDS the tile leaves as 16-byte stores, 576 contiguous bytes per row.
-        V4e bpre[NI];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            bpre[j] = V4e{};
-            if (p.bias) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + n0 + wn * 144 + j * 16 + 4 * lg);
-        }
-        __syncthreads();   // every wave is done with the operand stages
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                *reinterpret_cast<V4e*>(smem + (wm * 64 + i * 16 + lr) * RS_ROWS + wn * 144 + j * 16 + 4 * lg) =
-                    linear_out4<DT>(p, acc[i][j], bpre[j]);
-        __syncthreads();
-#pragma unroll 6
-        for (int it = 0; it < (BM * (BN / 8)) / 512; ++it) {      // 9216 (row, 8-column) units / 512 threads = 18
-            const int u = tid + 512 * it;
-            const int row = u / (BN / 8), c = u - row * (BN / 8);
-            const V8 v = *reinterpret_cast<const V8*>(smem + row * RS_ROWS + 8 * c);
-            if (m0 + row < p.M) *reinterpret_cast<V8*>(p.out + (int64_t)(m0 + row) * p.N + n0 + 8 * c) = v;
-        }
-        prof_end();
-        return;
-    }
-
+    // (EPI_LINEAR through the same LDS staging as EPI_HEADS - 16-byte stores, 576 contiguous bytes per row - measured
+    // WORSE than the register form below at fc1: epilogue 33.4k -> 40.1k cycles per tile.  The 33k are the 37.7 MB write
+    // burst of 256 workgroups finishing together (2.1 TB/s), not store issue.)
     // ---- epilogue from registers: acc[i][j][r] = C[m0 + wm*64 + i*16 + lr][n0 + wn*144 + j*16 + 4*lg + r]
     const int nb = n0 + wn * 144 + 4 * lg;
     V4e bpre[NI];
@@ -1482,7 +1455,6 @@ int launch(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
     // (qkv would be 192 workgroups = 75 % of the CUs, and the scatter epilogue spilled at this tile's register budget).
     bool use_big = !g_no_big && a.N % 288 == 0 && ((a.M + 255) / 256) * (a.N / 288) >= 224 &&
                    (EPI == EPI_LINEAR || EPI == EPI_RES || EPI == EPI_GATE_RESIDUAL);
-    if (EPI == EPI_LINEAR && g_big_q && (reinterpret_cast<uintptr_t>(a.out) & 15) != 0) use_big = false;  // its 16-byte stores
     // Heads epilogue on the 256x288 tile (LDS-staged scatter, gemm288q only): tiles must cover whole heads of one
     // segment and one batch entry.  It already pays at 192 workgroups (qkv at T = 4096: 75 % of the CUs, one round
     // instead of three rounds of 128x144 tiles); PRIMX_GEMM_BIGHEADS_MIN moves the threshold (0 = never).
