@@ -82,6 +82,32 @@ struct GemmArgs {
     int cout;      // EPI_CONVT: N = 8 * cout
 };
 
+// Activation of the EPI_LINEAR epilogue.  `p.act` is uniform, but both branches are pure arithmetic, so hipcc if-converts
+// them: every element then paid for the tanh form AND the erf polynomial (~40 VALU instructions instead of ~12; the fc1
+// epilogue was 31k of the kernel's 91k cycles, PRIMX_GEMM_PROF).  The empty volatile asm makes each side
+// non-speculatable, which forces real (scalar, uniform) branches.
+#define PRIMX_APPLY_ACT(y)                                   \
+    do {                                                     \
+        if (p.act == PRIMX_ACT_GELU_TANH) {                  \
+            asm volatile("" ::: "memory");                   \
+            y = rnd16<DT>(gelu_tanh_f(y));                   \
+        } else if (p.act == PRIMX_ACT_GELU_ERF) {            \
+            asm volatile("" ::: "memory");                   \
+            y = rnd16<DT>(gelu_erf_f(y));                    \
+        }                                                    \
+    } while (0)
+
+// Output stores of the epilogues.  PRIMX_NT_STORES: non-temporal (streaming) policy - experiment on whether the
+// end-of-kernel write-back of dirty L2 lines is what the epilogues wait for.
+template <typename T>
+__device__ __forceinline__ void out_store(T* ptr, const T v) {
+#ifdef PRIMX_NT_STORES
+    __builtin_nontemporal_store(v, ptr);
+#else
+    *ptr = v;
+#endif
+}
+
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // bijective "contiguous chunk per XCD" remap (cdna_hip_programming.md T1)
     const int q = nwg >> 3, r = nwg & 7;
@@ -148,8 +174,7 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs<DT>& p, const ColIn
             const int m = mq + j;
             if (m >= p.M) continue;
             float y = rnd16<DT>(a[j] + c.bias);
-            if (p.act == PRIMX_ACT_GELU_TANH) y = rnd16<DT>(gelu_tanh_f(y));
-            else if (p.act == PRIMX_ACT_GELU_ERF) y = rnd16<DT>(gelu_erf_f(y));
+            PRIMX_APPLY_ACT(y);
             if (p.out_scale != 1.0f) y = rnd16<DT>(p.out_scale * y);
             p.out[(int64_t)m * p.N + n] = (S)y;
         }
@@ -243,13 +268,22 @@ __device__ __forceinline__ typename T16<DT>::V4 linear_out4(const GemmArgs<DT>& 
                                                             const typename T16<DT>::V4 bv) {
     using S = typename T16<DT>::S;
     typename T16<DT>::V4 o;
+    float y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = rnd16<DT>(a[j] + (p.bias ? (float)bv[j] : 0.f));
+    if (p.act == PRIMX_ACT_GELU_TANH) {          // one uniform branch per four elements (see PRIMX_APPLY_ACT)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = rnd16<DT>(gelu_tanh_f(y[j]));
+    } else if (p.act == PRIMX_ACT_GELU_ERF) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = rnd16<DT>(gelu_erf_f(y[j]));
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float y = rnd16<DT>(a[j] + (p.bias ? (float)bv[j] : 0.f));
-        if (p.act == PRIMX_ACT_GELU_TANH) y = rnd16<DT>(gelu_tanh_f(y));
-        else if (p.act == PRIMX_ACT_GELU_ERF) y = rnd16<DT>(gelu_erf_f(y));
-        if (p.out_scale != 1.0f) y = rnd16<DT>(p.out_scale * y);
-        o[j] = (S)y;
+        if (p.out_scale != 1.0f) y[j] = rnd16<DT>(p.out_scale * y[j]);
+        o[j] = (S)y[j];
     }
     return o;
 }
@@ -265,7 +299,7 @@ __device__ __forceinline__ void epilogue_row4(const GemmArgs<DT>& p, int m, int 
         for (int j = 0; j < 4; ++j) b[j] = (float)bv[j];
     }
     if (EPI == EPI_LINEAR) {
-        *reinterpret_cast<V4*>(p.out + (int64_t)m * p.N + n) = linear_out4<DT>(p, a, bv);
+        out_store(reinterpret_cast<V4*>(p.out + (int64_t)m * p.N + n), linear_out4<DT>(p, a, bv));
     } else if (EPI == EPI_RES) {
         float r[4] = {0.f, 0.f, 0.f, 0.f};
         if (p.res) {
@@ -896,7 +930,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
                     if (h_seg == 0 && p.scale0 != 1.0f) y = rnd16<DT>(p.scale0 * y);
                     o[j] = (S)y;
                 }
-                *reinterpret_cast<V4*>(h_dst + (((int64_t)bb * p.heads + hh) * p.n_pad + tok) * h_rs + d) = o;
+                out_store(reinterpret_cast<V4*>(h_dst + (((int64_t)bb * p.heads + hh) * p.n_pad + tok) * h_rs + d), o);
             } else if (EPI == EPI_GATE_RESIDUAL) {
                 using V4 = typename T16<DT>::V4;
                 const int m = m0 + row, n = n0 + 4 * c4;
@@ -905,7 +939,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     xv[j] = xv[j] + rnd16<DT>((float)gv[j] * rnd16<DT>(v0[j] + v1[j] + (p.bias ? (float)bv[j] : 0.f)));
-                *reinterpret_cast<f32x4*>(p.x + (int64_t)m * p.N + n) = xv;
+                out_store(reinterpret_cast<f32x4*>(p.x + (int64_t)m * p.N + n), xv);
             } else {
                 epilogue_row4<DT, EPI>(p, m0 + row, n0 + 4 * c4, v0 + v1, bpre[i]);
             }
@@ -1074,7 +1108,7 @@ __global__ __launch_bounds__(512, 2) void gemm288_dma_kernel(const GemmArgs<DT> 
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     xv[j][r] += rnd16<DT>((float)gv[j][r] * rnd16<DT>(acc[i][j][r] + (p.bias ? (float)bpre[j][r] : 0.f)));
-                if (ok) *reinterpret_cast<f32x4*>(xrow + j * 16) = xv[j];
+                if (ok) out_store(reinterpret_cast<f32x4*>(xrow + j * 16), xv[j]);
             }
         } else {
 #pragma unroll
@@ -1284,7 +1318,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
                     if (d >= p.dh) { d -= p.dh; ++hl; }
                 const V8 v = *reinterpret_cast<const V8*>(smem + row * RS_ROWS + 8 * c);
                 if (m0 + row < p.M)
-                    *reinterpret_cast<V8*>(dst + (((int64_t)bb * p.heads + hh0 + hl) * p.n_pad + tok0 + row) * rs + d) = v;
+                    out_store(reinterpret_cast<V8*>(dst + (((int64_t)bb * p.heads + hh0 + hl) * p.n_pad + tok0 + row) * rs + d), v);
             }
         } else {
             // acc[i][j][r] = C[wm*64 + i*16 + 4*lg + r][wn*144 + j*16 + lr]  ->  staged transposed [column][token]
@@ -1319,8 +1353,8 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
                 const V8 o1 = {lo[4], lo[5], lo[6], lo[7], hi[4], hi[5], hi[6], hi[7]};
                 S* rowp = dst + (((int64_t)bb * p.heads + hh0 + hl) * p.DP + d) * p.n_pad + tok0 + 16 * g;
                 if (m0 + 16 * g < p.M) {
-                    *reinterpret_cast<V8*>(rowp) = o0;
-                    *reinterpret_cast<V8*>(rowp + 8) = o1;
+                    out_store(reinterpret_cast<V8*>(rowp), o0);
+                    out_store(reinterpret_cast<V8*>(rowp + 8), o1);
                 }
             }
         }
@@ -1359,7 +1393,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     xv[j][r] += rnd16<DT>((float)gv[j][r] * rnd16<DT>(acc[i][j][r] + (p.bias ? (float)bpre[j][r] : 0.f)));
-                if (ok) *reinterpret_cast<f32x4*>(xrow + j * 16) = xv[j];
+                if (ok) out_store(reinterpret_cast<f32x4*>(xrow + j * 16), xv[j]);
             }
         } else {
 #pragma unroll
