@@ -8,4 +8,6 @@ timeout 900 python bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/final -o trace -- python bench.py --no-cpu-baseline --steps 25 > gpurun_out/final/bench_trace.json 2> gpurun_out/final/bench_trace.err
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/final -o fetch -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 --no-kernel-events > /dev/null 2> gpurun_out/final/fetch.err
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/final -o write -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 --no-kernel-events > /dev/null 2> gpurun_out/final/write.err
-ls gpurun_out/final | head -30
+for db in gpurun_out/final/*.db; do python tools/rocprof_summary.py $db gpurun_out/final/kernel_trace_summary.txt; done
+tail -22 gpurun_out/final/kernel_trace_summary.txt | cut -c1-200
+ls -la gpurun_out/final | head -30
