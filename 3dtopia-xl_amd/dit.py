@@ -216,7 +216,7 @@ class DiT(nn.Module):
         Be, L, Dc = y.shape
         if Lk == L:
             return ops.cast16(y.reshape(Be * L, Dc).float().contiguous(), dtype)
-        key = ("y16", Be, Lk, Dc, dtype, str(y.device))
+        key = ("y16", Be, L, Lk, Dc, dtype, str(y.device))
         buf = self._heads_ws.get(key)
         if buf is None:
             buf = torch.zeros(Be, Lk, Dc, dtype=dtype, device=y.device)
