@@ -1494,7 +1494,8 @@ int launch(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
     // instead of three rounds of 128x144 tiles); PRIMX_GEMM_BIGHEADS_MIN moves the threshold (0 = never).
     if (EPI == EPI_HEADS && !g_no_big && g_big_q && g_big_heads_min > 0 && a.heads > 0) {
         const int per = a.heads * a.dh;
-        use_big = a.N % 288 == 0 && per % 288 == 0 && 288 % a.dh == 0 && a.dh % 8 == 0 && a.rows_per_batch % 256 == 0 &&
+        // (dh >= 32: the epilogue finds the head of a column with at most 8 compare-subtract steps, 288 / dh <= 9 heads per tile)
+        use_big = a.N % 288 == 0 && per % 288 == 0 && 288 % a.dh == 0 && a.dh % 8 == 0 && a.dh >= 32 && a.rows_per_batch % 256 == 0 &&
                   (a.M / 256) * (a.N / 288) >= g_big_heads_min;
     }
 #define PRIMX_GEMM_LAUNCH(KT)                                                                                         \

@@ -56,7 +56,7 @@ def _gemm_tag(epi: int, M: int, N: int, K: int, dtype, heads=None) -> str:
             and os.environ.get("PRIMX_GEMM_BIGQ", "1") != "0" and os.environ.get("PRIMX_GEMM_NOBIG") != "1":
         H, dh, rows = heads       # heads epilogue on the 256x288 tile (csrc/gemm.hip launch(): whole heads, one batch entry)
         wg_min = int(os.environ.get("PRIMX_GEMM_BIGHEADS_MIN", "160"))
-        if wg_min > 0 and N % 288 == 0 and (H * dh) % 288 == 0 and 288 % dh == 0 and dh % 8 == 0 and rows % 256 == 0 \
+        if wg_min > 0 and N % 288 == 0 and (H * dh) % 288 == 0 and 288 % dh == 0 and dh % 8 == 0 and dh >= 32 and rows % 256 == 0 \
                 and (M // 256) * (N // 288) >= wg_min:
             return f"gemm288q_dma_kernel<{dt}, {epi}>"
     if epi != 2 and N % 288 == 0 and K % 64 == 0 and ((M + 255) // 256) * (N // 288) >= 224:
