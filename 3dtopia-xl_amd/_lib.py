@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PRIMX_LIB") or os.path.join(_HERE, "csrc", "libprimx_
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
 HEADS_ROWS, HEADS_VT, HEADS_KROWS = 0, 1, 2
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -48,6 +48,10 @@ SIGNATURES = {
     "primx_convtranspose_k2s2": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "primx_vae_output": [_p, _p, _i, _i, _i, _i, _f, _i, _p],
     "primx_latent_denorm": [_p, _p, _p, _f, _p, _p, _l, _i, _i, _p],
+    "primx_gemm_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _l, _i, _p],
+    "primx_attention_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_l), C.POINTER(_l), C.POINTER(_l), _f, _p],
+    "primx_layernorm_modulate_f32": [_p, _p, _p, _l, _p, _i, _i, _i, _f, _p],
+    "primx_silu_f32": [_p, _p, _l, _p],
 }
 _RESTYPES = {"primx_last_error": C.c_char_p}
 
@@ -69,6 +73,16 @@ def load(path: Optional[str] = None) -> C.CDLL:
             f"{path} not found: the HIP library is not built. Run `python __graft_entry__.py` "
             "(build()) first - there is no PyTorch/CPU fallback for this path."
         )
+    if path == LIB_PATH and not os.environ.get("PRIMX_LIB") and not os.environ.get("PRIMX_SKIP_FRESH_CHECK"):
+        # the binary must have been built from exactly the sources next to it (content hashes, csrc/build.py): a
+        # stale shipped .so is an error, never silently benchmarked
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("primx_build", os.path.join(_HERE, "csrc", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if not mod.check_fresh():
+            raise RuntimeError(f"{path} does not match the sources in {os.path.dirname(path)} (build_manifest.json): "
+                               "run `python __graft_entry__.py` (build()) to rebuild it")
     # make sure the HIP runtime PyTorch uses is the one already mapped (same SONAME libamdhip64.so.7)
     try:
         import torch  # noqa: F401

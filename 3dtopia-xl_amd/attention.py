@@ -65,6 +65,7 @@ class MemEffAttention(_PackedMixin, nn.Module):
         return {"w_qkv": _c16(self.qkv.weight, dtype), "b_qkv": _c16(self.qkv.bias, dtype),
                 "w_proj": _c16(self.proj.weight, dtype), "b_proj": _c16(self.proj.bias, dtype)}
 
+    @ops.on_input_device
     def forward(self, x: torch.Tensor, attn_bias=None) -> torch.Tensor:
         if attn_bias is not None:
             raise NotImplementedError("attn_bias is not used on the 3DTopia-XL path")
@@ -116,6 +117,7 @@ class MemEffCrossAttention(_PackedMixin, nn.Module):
             "w_proj": _c16(self.proj.weight, dtype), "b_proj": _c16(self.proj.bias, dtype),
         }
 
+    @ops.on_input_device
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, attn_bias=None) -> torch.Tensor:
         if attn_bias is not None:
             raise NotImplementedError("attn_bias is not used on the 3DTopia-XL path")

@@ -518,14 +518,11 @@ __global__ void diffusion_step_kernel(const float* __restrict__ x, const void* _
             float logvar;
             if (var_type >= 2) {
                 const float vv = OutLoad<TO>::ld(model_out, r * c_out + C + c);
-                if (var_type == 3) {  // learned range: frac * max_log + (1 - frac) * min_log
-                    const float fr = OutLoad<TO>::frac(vv);
-                    const float u0 = fr * max_log;
-                    const float u1 = OutLoad<TO>::one_minus(fr) * min_log;
-                    logvar = u0 + u1;
-                } else {
-                    logvar = vv;
-                }
+                // LEARNED and LEARNED_RANGE alike (gaussian_diffusion.py:285-293): frac * max_log + (1 - frac) * min_log
+                const float fr = OutLoad<TO>::frac(vv);
+                const float u0 = fr * max_log;
+                const float u1 = OutLoad<TO>::one_minus(fr) * min_log;
+                logvar = u0 + u1;
             } else {
                 logvar = fixed_logvar;
             }

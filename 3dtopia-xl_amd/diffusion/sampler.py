@@ -42,7 +42,7 @@ from .schedule import (
 
 COEF_STRIDE = 16  # floats per step in the device coefficient table (see include/primx_hip.h)
 
-# column indices of the coefficient table - keep in sync with csrc/diffusion_step.hip
+# column indices of the coefficient table - keep in sync with csrc/rowops.hip (diffusion_step_kernel)
 C_SQRT_ACP, C_SQRT_1M_ACP, C_SQRT_RECIP_ACP, C_SQRT_RECIPM1_ACP = 0, 1, 2, 3
 C_POST_MEAN1, C_POST_MEAN2, C_MIN_LOG, C_MAX_LOG, C_FIXED_LOGVAR = 4, 5, 6, 7, 8
 C_DDIM_X0, C_DDIM_EPS, C_DDIM_SIGMA, C_NONZERO, C_FIXED_VAR = 9, 10, 11, 12, 13
@@ -128,14 +128,21 @@ class GaussianDiffusion(DiffusionTables):
         return st
 
     # ------------------------------------------------------------------ one step
-    def _step(self, kind: str, model: Callable, x: torch.Tensor, i: int, *, clip_denoised: bool,
-              model_kwargs: Optional[dict], eta: float, coef: torch.Tensor, tmap: torch.Tensor):
+    def _step(self, kind: str, model: Callable, x: torch.Tensor, i: int, **kw):
         from .. import ops  # deferred: importing the sampler must not need the HIP library
+        with ops.device_of(x):   # launches go to the current device's stream: make x's device current for the step
+            return self._step_on_device(kind, model, x, i, **kw)
+
+    def _step_on_device(self, kind: str, model: Callable, x: torch.Tensor, i: int, *, clip_denoised: bool,
+                        model_kwargs: Optional[dict], eta: float, coef: torch.Tensor, tmap: torch.Tensor):
+        from .. import ops
 
         if x.dim() != 3:
             raise AssertionError("x must be (B, n_tokens, C)")
         B, nt, C = x.shape
-        t_model = tmap[i].expand(B)  # (B,) int64 view, no allocation, no H2D  (respace.py:124-129)
+        # (B,) int64 timesteps of the ORIGINAL process (respace.py:124-129): a row of the per-loop [n, B] table (contiguous,
+        # so nothing downstream has to copy it), or a broadcast view for the single-step API.  No allocation, no H2D.
+        t_model = tmap[i] if tmap.dim() == 2 else tmap[i].expand(B)
         model_output = model(x, t_model, **(model_kwargs or {}))
         if isinstance(model_output, tuple):
             model_output = model_output[0]
@@ -174,6 +181,7 @@ class GaussianDiffusion(DiffusionTables):
             )
         img = img.float().contiguous()
         coef, tmap = self._device_state(img.device, eta)
+        tmap = tmap[:, None].expand(-1, img.shape[0]).contiguous()      # [n_steps, B], built once per loop
         indices = range(self.num_timesteps - 1, -1, -1)
         if progress:
             from tqdm.auto import tqdm

@@ -154,6 +154,7 @@ class DinoVisionTransformer(nn.Module):
         return tab
 
     # ------------------------------------------------------------------ forward
+    @ops.on_input_device
     def forward_features(self, x: torch.Tensor, masks=None, mod=None, precision_dtype: torch.dtype = torch.float16):
         """x: [B, 3, H, W] preprocessed image (fp32) -> the reference's dict (vision_transformer.py:266-283)."""
         if masks is not None or mod is not None:

@@ -17,9 +17,11 @@ Same constructor kwargs, same ``state_dict`` keys (515 tensors for the shipped c
   LayerNorm, 16-bit Linear/attention outputs, 16-bit modulation vectors, 16-bit CFG combine), see
   DESIGN.md "Numerics".
 
-Only the autocast path is accelerated (``enable_amp=True`` with fp16 or bf16); the fp32
-(``enable_amp=False``) variant raises NotImplementedError - gfx950 has no TF32 and exact-fp32 MFMA
-runs at 1/16 rate (out of scope for this round).
+Two numeric routes, selected exactly as the reference selects them (dit_crossattn.py:184,197):
+``enable_amp=True`` with fp16 / bf16 -> the autocast topology on the 16-bit MFMA path (production, everything above);
+``enable_amp=False`` (the signature default) or ``precision_dtype=float32`` -> exact fp32 on the fp32 matrix instruction
+(csrc/fp32.hip: gfx950 has no TF32, so this is at least the reference's own fp32 / TF32 precision, at 1/16 of the
+16-bit MFMA rate).
 """
 from __future__ import annotations
 
@@ -134,6 +136,12 @@ class DiT(nn.Module):
         self.initialize_weights()
         self._pack: Dict = {}
         self._heads_ws: Dict = {}
+        self._cond: Optional[Dict] = None
+        # Opt-in exact-algebra shortcut: to_k(y) / to_v(y) do not depend on the timestep
+        # (models/attention.py:106-107), so with this flag the K / V projections of all blocks are computed once per
+        # conditioning tensor and reused across DDIM steps.  Off by default: a step then executes the reference's full
+        # algorithmic FLOPs (bench.py reports both when the flag is on).
+        self.reuse_cond_kv = False
 
     # ------------------------------------------------------------------ init (dit_crossattn.py:153-182)
     def initialize_weights(self):
@@ -156,10 +164,12 @@ class DiT(nn.Module):
     def repack(self) -> None:
         self._pack = {}
         self._heads_ws = {}
+        self._cond = None
 
     def _apply(self, fn, *a, **k):
         self.__dict__["_pack"] = {}
         self.__dict__["_heads_ws"] = {}
+        self.__dict__["_cond"] = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
@@ -205,40 +215,80 @@ class DiT(nn.Module):
         key = (tag, B, n, kind, dtype, str(device), pad_to)
         buf = self._heads_ws.get(key)
         if buf is None:
+            if len(self._heads_ws) >= 16:   # shapes changed (another batch / token count): drop the old workspaces
+                self._heads_ws = {}
+                self._cond = None           # its K / V cache pointed into them
             buf = ops.alloc_heads(B, self.num_heads, n, self.hidden_size // self.num_heads, kind, dtype, device, pad_to,
                                   role=tag[0].lower())  # "q" / "k": operand-level key-padding mask (ops.alloc_heads)
             self._heads_ws[key] = buf
         return buf
 
-    def _cond16(self, y: torch.Tensor, Lk: int, dtype) -> torch.Tensor:
-        """The autocast cast of the conditioning tokens in front of to_k / to_v (attention.py:106-107) -> [Be * Lk, Dc];
-        rows L..Lk-1 of every batch entry are zero (persistent workspace, only the valid rows are rewritten)."""
-        Be, L, Dc = y.shape
-        if Lk == L:
-            return ops.cast16(y.reshape(Be * L, Dc).float().contiguous(), dtype)
-        key = ("y16", Be, L, Lk, Dc, dtype, str(y.device))
-        buf = self._heads_ws.get(key)
-        if buf is None:
-            buf = torch.zeros(Be, Lk, Dc, dtype=dtype, device=y.device)
-            self._heads_ws[key] = buf
+    # ------------------------------------------------------------------ conditioning (step-invariant inputs)
+    def _cond_state(self, y: torch.Tensor, null_half: bool, dt) -> Dict:
+        """16-bit image of the conditioning tokens as the K / V projection reads them, cached per conditioning tensor.
+
+        What the reference does every step - `cat([y, y_null])` (dit_crossattn.py:207-208) and the autocast cast in
+        front of to_k / to_v (attention.py:106-107) - depends only on `y`, so it is done once per `y` and reused while
+        the caller keeps passing the same tensor (same storage, shape, strides and in-place version; the cache holds a
+        reference to `y`, so its storage cannot be recycled for another tensor behind our back).  This is a cast of an
+        INPUT, not skipped arithmetic.  The step-invariant K / V projections themselves are reused only when
+        `self.reuse_cond_kv` is set (exact algebra; off by default so that a step executes
+        the reference's full algorithmic FLOPs)."""
+        B, L, Dc = y.shape
+        Be = 2 * B if null_half else B
+        st = self._cond
+        if st is not None:
+            k = st["y"]
+            if (k.data_ptr() == y.data_ptr() and k.shape == y.shape and k.stride() == y.stride() and k.dtype == y.dtype
+                    and st["ver"] == y._version and st["dt"] == dt and st["null_half"] == null_half):
+                return st
+        # Conditioning rows per batch entry as the K / V projection sees them: padded with zero rows to a multiple of 256
+        # when that costs <= 12.5 % (1370 -> 1536), so that GEMM tiles never straddle batch entries and the projection
+        # takes the 256x288 tile (csrc/gemm.hip launch()).  The pad rows produce K = bias_k / V = bias_v entries beyond
+        # the L valid keys: the attention kernel never visits tiles past L, and inside the last tile they carry the
+        # operand-level key mask (ops.alloc_heads), i.e. probability exactly 0.
+        Lk = L
+        if (ops.round_up(L, 256) - L) * 8 <= L:
+            Lk = ops.round_up(L, 256)
+        buf = torch.zeros(Be, Lk, Dc, dtype=dt, device=y.device)
         yf = y.float().contiguous()
-        for b in range(Be):
-            ops.cast16(yf[b], dtype, out=buf[b, :L])
-        return buf.view(Be * Lk, Dc)
+        for b in range(B):
+            ops.cast16(yf[b], dt, out=buf[b, :L])
+        if null_half:   # y_null = null_cond_embedding.expand_as(y)  (dit_crossattn.py:207): one row, broadcast once
+            null16 = ops.cast16(self.null_cond_embedding.detach().float().contiguous().to(y.device), dt)
+            buf[B:, :L] = null16
+        st = {"y": y, "ver": y._version, "dt": dt, "null_half": null_half, "Lk": Lk, "y16": buf.view(Be * Lk, Dc),
+              "kv_valid": False}
+        self._cond = st
+        return st
 
     # ------------------------------------------------------------------ forward
+    @ops.on_input_device
     def forward(self, x, t, y, precision_dtype=torch.float32, enable_amp=False):
-        """x: (B, N, C) fp32; t: (B,) int; y: (B, L, Dc) fp32 -> (B, N, out_channels) in ``precision_dtype``."""
+        """x: (B, N, C) fp32; t: (B,) int; y: (B, L, Dc) fp32 -> (B, N, out_channels).
+
+        `enable_amp=True` with fp16 / bf16: the autocast topology on the 16-bit MFMA path, output in `precision_dtype`.
+        `enable_amp=False` (the signature default; `precision: tf32` of the CLI, inference.py:239-247) or
+        `precision_dtype=float32`: exact fp32 on the fp32 matrix instruction (csrc/fp32.hip), fp32 output."""
+        self._check_inputs(x)
+        if not enable_amp or precision_dtype == torch.float32:
+            return self._forward_fp32(x, t, y)
+        if precision_dtype not in (torch.float16, torch.bfloat16):
+            raise NotImplementedError(f"autocast dtype {precision_dtype} is not supported (fp16 / bf16 / fp32)")
+        return self._forward16(x, t, y, precision_dtype, null_half=False)
+
+    def _check_inputs(self, x):
         if self.training:
             raise NotImplementedError("the accelerated DiT is inference-only: call .eval()")
-        if not enable_amp or precision_dtype not in (torch.float16, torch.bfloat16):
-            raise NotImplementedError(
-                "only the autocast path (enable_amp=True, precision_dtype fp16/bf16) is accelerated; "
-                "the fp32 / TF32 variant is not implemented on gfx950 (see DESIGN.md)")
         if not x.is_cuda:
             raise RuntimeError("DiT.forward needs HIP device tensors; there is no CPU path")
-        dt = precision_dtype
-        Be, N, Cin = x.shape
+
+    def _forward16(self, x, t, y, dt, null_half: bool):
+        """The 16-bit autocast path.  `null_half`: classifier-free guidance - the effective batch is [x; x] with the
+        second half conditioned on the null embedding (dit_crossattn.py:204-209), assembled here without materialising
+        the concatenations: tokens are embedded into both halves of the residual stream, t is embedded once."""
+        B, N, Cin = x.shape
+        Be = 2 * B if null_half else B
         L, Dc = y.shape[1], y.shape[2]
         D, H = self.hidden_size, self.num_heads
         dh = D // H
@@ -246,19 +296,19 @@ class DiT(nn.Module):
         pk = self.packed(dt)
         dev = x.device
 
-        h = self._embed_tokens(x.reshape(T, Cin).float().contiguous())
-        t_emb = self.t_embedder(t)
+        xf = x.reshape(B * N, Cin).float().contiguous()
+        h = torch.empty(T, D, dtype=torch.float32, device=dev)
+        self._embed_tokens(xf, h[:B * N])
+        t_emb = self.t_embedder(t)                               # [B, D]
+        st16 = torch.empty(Be, D, dtype=dt, device=dev)
+        ops.silu_cast(t_emb, dt, out=st16[:B])
+        if null_half:
+            self._embed_tokens(xf, h[B * N:])
+            ops.silu_cast(t_emb, dt, out=st16[B:])
         # adaLN for every block + final layer: SiLU -> one streaming GEMM (dit_crossattn.py:40-43,54,69-75)
-        mod = ops.linear(ops.silu_cast(t_emb, dt), pk["w_ada"], pk["b_ada"])  # [Be, depth*9D + 2D]
-        # Conditioning rows per batch entry as the K / V projection sees them: padded with zero rows to a multiple of 256
-        # when that costs <= 12.5 % (1370 -> 1536), so that GEMM tiles never straddle batch entries and the projection
-        # takes the 256x288 tile (csrc/gemm.hip launch(): 637 -> ~400 us per forward).  The pad rows produce K = bias_k /
-        # V = bias_v entries beyond the L valid keys: the attention kernel never visits tiles past L, and inside the
-        # last tile they carry the operand-level key mask (ops.alloc_heads), i.e. probability exactly 0.
-        Lk = L
-        if (ops.round_up(L, 256) - L) * 8 <= L:
-            Lk = ops.round_up(L, 256)
-        y16 = self._cond16(y, Lk, dt)
+        mod = ops.linear(st16, pk["w_ada"], pk["b_ada"])         # [Be, depth*9D + 2D]
+        cs = self._cond_state(y, null_half, dt)
+        Lk, y16 = cs["Lk"], cs["y16"]
 
         nq_pad = ops.round_up(N, ops.BQ)
         Qc = self._heads("Qc", Be, N, HEADS_ROWS, dt, dev, ops.BQ)
@@ -268,9 +318,10 @@ class DiT(nn.Module):
         Vc = self._heads("Vc", self.depth * Be, L, HEADS_VT, dt, dev, kv_pad)
         Kc_blk = Kc.view(self.depth, Be, *Kc.shape[1:])
         Vc_blk = Vc.view(self.depth, Be, *Vc.shape[1:])
-        if self.depth:
+        if self.depth and not (self.reuse_cond_kv and cs["kv_valid"] and cs.get("kv_id") == (Kc.data_ptr(), Vc.data_ptr())):
             ops.linear_heads(y16, pk["w_kv_all"], pk["b_kv_all"], Lk, H, dh, [HEADS_KROWS, HEADS_VT], [Kc, Vc],
                              Kc.shape[2], n_rep=self.depth, rep_batches=Be)
+            cs["kv_valid"], cs["kv_id"] = True, (Kc.data_ptr(), Vc.data_ptr())
         Qs = self._heads("Qs", Be, N, HEADS_ROWS, dt, dev, ops.BQ)
         Ks = self._heads("Ks", Be, N, HEADS_KROWS, dt, dev, ops.BQ)
         Vs = self._heads("Vs", Be, N, HEADS_VT, dt, dev, ops.BQ)
@@ -304,18 +355,65 @@ class DiT(nn.Module):
         out = ops.linear(xn, pk["w_final"], pk["b_final"])
         return out.view(Be, N, self.out_channels)
 
-    def _embed_tokens(self, xf: torch.Tensor) -> torch.Tensor:
-        """[T, C] fp32 -> [T, D] fp32, outside autocast in the reference (dit_crossattn.py:191-192)."""
-        return ops.linear_f32(xf, self.x_embedder.weight.detach(), self.x_embedder.bias.detach())
+    def _forward_fp32(self, x, t, y):
+        """The reference with autocast off: every Linear, the attention core, LayerNorm, modulate, GELU and the gated
+        residuals in fp32 (dit_crossattn.py:184-202 with enable_amp=False).  Reads the fp32 parameters directly."""
+        Be, N, Cin = x.shape
+        L, Dc = y.shape[1], y.shape[2]
+        D, H = self.hidden_size, self.num_heads
+        dh = D // H
+        T = Be * N
+        dev = x.device
+        f = lambda p: p.detach()
+        h = torch.empty(T, D, dtype=torch.float32, device=dev)
+        self._embed_tokens(x.reshape(T, Cin).float().contiguous(), h)
+        st = ops.silu_f32(self.t_embedder(t))                                      # SiLU(t_emb), shared by every adaLN
+        y2 = y.float().contiguous().view(Be * L, Dc)
+        scale = dh ** -0.5
+        xn = torch.empty(T, D, dtype=torch.float32, device=dev)
+        for blk in self.blocks:
+            ada = blk.adaLN_modulation[1]
+            mod = ops.gemm_f32(st, f(ada.weight), f(ada.bias))                     # [Be, 9D]
+            ch = [mod[:, j * D:(j + 1) * D] for j in range(9)]
+            ca, sa, mlp = blk.crossattn, blk.attn, blk.mlp
+            bias = lambda lin: None if lin.bias is None else f(lin.bias)
+            # ---- cross-attention: q = scale * to_q(x) and the core scales by dh^-1/2 again (attention.py:105,109)
+            ops.layernorm_modulate_f32(h, ch[0], ch[1], N, self.LN_EPS, out=xn)
+            q = ops.gemm_f32(xn, f(ca.to_q.weight), bias(ca.to_q), out_scale=scale)
+            k = ops.gemm_f32(y2, f(ca.to_k.weight), bias(ca.to_k))
+            v = ops.gemm_f32(y2, f(ca.to_v.weight), bias(ca.to_v))
+            o = ops.attention_f32(q.view(Be, N, H, dh), k.view(Be, L, H, dh), v.view(Be, L, H, dh), scale)
+            ops.gemm_f32(o.view(T, D), f(ca.proj.weight), bias(ca.proj), out=h, gate=ch[2], rows_per_batch=N)
+            # ---- self-attention on the unbind() views of the fused qkv buffer (attention.py:49-54)
+            ops.layernorm_modulate_f32(h, ch[3], ch[4], N, self.LN_EPS, out=xn)
+            qkv = ops.gemm_f32(xn, f(sa.qkv.weight), bias(sa.qkv)).view(Be, N, 3, H, dh)
+            o = ops.attention_f32(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], scale)
+            ops.gemm_f32(o.view(T, D), f(sa.proj.weight), bias(sa.proj), out=h, gate=ch[5], rows_per_batch=N)
+            # ---- MLP
+            ops.layernorm_modulate_f32(h, ch[6], ch[7], N, self.LN_EPS, out=xn)
+            hid = ops.gemm_f32(xn, f(mlp.fc1.weight), f(mlp.fc1.bias), act=ACT_GELU_TANH)
+            ops.gemm_f32(hid, f(mlp.fc2.weight), f(mlp.fc2.bias), out=h, gate=ch[8], rows_per_batch=N)
+        fl = self.final_layer
+        mod = ops.gemm_f32(st, f(fl.adaLN_modulation[1].weight), f(fl.adaLN_modulation[1].bias))
+        ops.layernorm_modulate_f32(h, mod[:, :D], mod[:, D:2 * D], N, self.LN_EPS, out=xn)
+        out = ops.gemm_f32(xn, f(fl.linear.weight), f(fl.linear.bias))
+        return out.view(Be, N, self.out_channels)
 
+    def _embed_tokens(self, xf: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """[T, C] fp32 -> out [T, D] fp32, outside autocast in the reference (dit_crossattn.py:191-192)."""
+        return ops.linear_f32(xf, self.x_embedder.weight.detach(), self.x_embedder.bias.detach(), out=out)
+
+    @ops.on_input_device
     def forward_with_cfg(self, x, t, y, cfg_scale=0.0, precision_dtype=torch.float32, enable_amp=False):
         """Classifier-free guidance: one forward at 2B, combine on all channels, return the B-sized half
         (dit_crossattn.py:204-213)."""
-        combined = torch.cat([x, x], dim=0)
-        combined_t = torch.cat([t, t], dim=0)
-        y_null = self.null_cond_embedding.detach().to(y.dtype).expand_as(y)
-        combined_y = torch.cat([y, y_null], dim=0)
-        model_out = self.forward(combined, combined_t, combined_y, precision_dtype, enable_amp)
+        self._check_inputs(x)
+        if enable_amp and precision_dtype in (torch.float16, torch.bfloat16):
+            model_out = self._forward16(x, t, y, precision_dtype, null_half=True)
+        else:   # fp32 route: the reference's literal concatenations (dit_crossattn.py:205-208)
+            y_null = self.null_cond_embedding.detach().to(y.dtype).expand_as(y)
+            model_out = self.forward(torch.cat([x, x], dim=0), torch.cat([t, t], dim=0), torch.cat([y, y_null], dim=0),
+                                     precision_dtype, enable_amp)
         return ops.cfg_combine(model_out.contiguous(), float(cfg_scale))
 
 
@@ -346,14 +444,15 @@ class DiTAdditivePosEmb(DiT):
                          gradient_checkpointing=gradient_checkpointing)
         self.point_emb = PointEmbed(hidden_dim=48, dim=hidden_size)
 
-    def _embed_tokens(self, xf: torch.Tensor) -> torch.Tensor:
+    def _embed_tokens(self, xf: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         pe = self.point_emb
         n = pe.embedding_dim // 6
         feat = ops.point_features(xf, pe.basis[0, :n].contiguous())       # the non-zero entries of the block-diagonal basis
         w = pe.mlp.weight.detach()
         w = torch.nn.functional.pad(w, (0, feat.shape[1] - w.shape[1]))   # K padded like the features (zero column)
-        return (ops.linear_f32(xf, self.x_embedder.weight.detach(), self.x_embedder.bias.detach()) +
-                ops.linear_f32(feat, w.contiguous(), pe.mlp.bias.detach()))
+        out.copy_(ops.linear_f32(xf, self.x_embedder.weight.detach(), self.x_embedder.bias.detach()) +
+                  ops.linear_f32(feat, w.contiguous(), pe.mlp.bias.detach()))
+        return out
 
     def forward_with_cfg(self, *args, **kwargs):
         raise AttributeError("the reference's DiTAdditivePosEmb defines no forward_with_cfg (dit_crossattn.py:215-301)")

@@ -26,9 +26,14 @@ def dtype_code(dt: torch.dtype) -> int:
         raise TypeError(f"unsupported dtype {dt}") from None
 
 
+_launch_dev: Optional[int] = None  # device index of the operands of the launch being assembled (set by _dev)
+
+
 def _dev(t: torch.Tensor, name: str, dtype: Optional[torch.dtype] = None) -> int:
+    global _launch_dev
     if not t.is_cuda:
         raise RuntimeError(f"{name} must live on a HIP device (got {t.device}); there is no CPU path")
+    _launch_dev = t.device.index
     if not t.is_contiguous():
         raise RuntimeError(f"{name} must be contiguous")
     if dtype is not None and t.dtype != dtype:
@@ -37,7 +42,38 @@ def _dev(t: torch.Tensor, name: str, dtype: Optional[torch.dtype] = None) -> int
 
 
 def _stream() -> int:
+    """Launch stream = torch's current stream of the CURRENT device.  The C ABI carries no device index, so the operands
+    must live on the current device: a tensor on another GPU would be launched on the wrong device's stream (unordered
+    against the torch ops that produced it).  The module entry points (DiT.forward, VAE.decode, the sampler, ...) switch
+    to their input's device with ``device_of``; raw op calls on a non-current device fail loudly here."""
+    cur = torch.cuda.current_device()
+    if _launch_dev is not None and _launch_dev != cur:
+        raise RuntimeError(f"operands live on cuda:{_launch_dev} but the current device is cuda:{cur}: call "
+                           "torch.cuda.set_device(...) or wrap the call in `with torch.cuda.device(t.device)`")
     return torch.cuda.current_stream().cuda_stream
+
+
+def device_of(t: torch.Tensor):
+    """Context manager making ``t``'s HIP device current (no-op when it already is)."""
+    if not t.is_cuda:
+        raise RuntimeError(f"expected a HIP device tensor, got {t.device}; there is no CPU path")
+    return torch.cuda.device(t.device)
+
+
+def on_input_device(fn):
+    """Decorator for module entry points: run ``fn`` with the device of its first tensor argument current."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.Tensor):
+                if a.is_cuda and a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return wrapped
 
 
 # Optional per-launch timing of the MFMA kernels (bench.py's roofline leg): when PROFILE is a list, every
@@ -139,8 +175,11 @@ def point_features(x: torch.Tensor, freqs: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def silu_cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+def silu_cast(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    elif out.dtype != dtype or out.numel() != x.numel() or not out.is_contiguous():
+        raise RuntimeError("silu_cast: out must be a contiguous tensor of the target dtype with x.numel() elements")
     check(_lib.load().primx_silu_cast(_dev(x, "x", torch.float32), out.data_ptr(), dtype_code(dtype), x.numel(),
                                       _stream()), "primx_silu_cast")
     return out
@@ -156,10 +195,14 @@ def cast16(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = No
     return out
 
 
-def linear_f32(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], act_out: int = 0) -> torch.Tensor:
+def linear_f32(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], act_out: int = 0,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     M, K = x.shape
     N = W.shape[0]
-    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (M, N) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise RuntimeError("linear_f32: out must be a contiguous fp32 [M, N] tensor")
     check(_lib.load().primx_linear_f32(_dev(x, "x", torch.float32), _dev(W, "W", torch.float32),
                                        _dev(b, "b", torch.float32) if b is not None else None, out.data_ptr(),
                                        M, N, K, act_out, _stream()), "primx_linear_f32")
@@ -408,4 +451,66 @@ def vit_tokens(patches: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, reg:
                                        _dev(pos, "pos", torch.float32),
                                        _dev(reg, "reg", torch.float32) if reg is not None else None, out.data_ptr(), B,
                                        npatch, R, D, _stream()), "primx_vit_tokens")
+    return out
+
+
+# ----------------------------------------------------------------------------- the reference's fp32 (no-autocast) path
+def gemm_f32(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
+             act: int = ACT_NONE, out_scale: float = 1.0, gate: Optional[torch.Tensor] = None,
+             rows_per_batch: int = 0) -> torch.Tensor:
+    """fp32 nn.Linear on the fp32 matrix instruction.  gate is None: out = act(A W^T + bias) * out_scale; else the
+    in-place gated residual out[m] += gate[m // rows_per_batch] * (A W^T + bias)[m]  (csrc/fp32.hip)."""
+    M, K = A.shape
+    N = W.shape[0]
+    if W.shape[1] != K:
+        raise RuntimeError("gemm_f32: operand mismatch")
+    if gate is not None:
+        if out is None or gate.stride(-1) != 1 or gate.dtype != torch.float32 or not gate.is_cuda:
+            raise RuntimeError("gemm_f32: the gated form updates `out` in place and needs a last-dim-contiguous fp32 gate")
+    elif out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    _timed("gemm_f32_kernel", 2.0 * M * N * K, lambda: check(_lib.load().primx_gemm_f32(
+        _dev(A, "A", torch.float32), _dev(W, "W", torch.float32),
+        _dev(bias, "bias", torch.float32) if bias is not None else None, _dev(out, "out", torch.float32), M, N, K, act,
+        out_scale, gate.data_ptr() if gate is not None else None, gate.stride(0) if gate is not None else 0,
+        rows_per_batch, _stream()), "primx_gemm_f32"))
+    return out
+
+
+def attention_f32(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None) -> torch.Tensor:
+    """softmax(q k^T * scale) v for fp32 [B, M, H, dh] views with a contiguous last dim (any batch / token / head
+    strides) -> contiguous [B, Mq, H, dh]: the xFormers call of the reference with autocast off."""
+    B, Mq, H, dh = q.shape
+    Mk = k.shape[1]
+    if k.shape != (B, Mk, H, dh) or v.shape != (B, Mk, H, dh):
+        raise RuntimeError("attention_f32: q / k / v must be [B, M, H, dh] with equal B, H, dh")
+    for t, name in ((q, "q"), (k, "k"), (v, "v")):
+        if t.dtype != torch.float32 or not t.is_cuda or t.stride(3) != 1:
+            raise RuntimeError(f"attention_f32: {name} must be an fp32 HIP tensor with a contiguous last dim")
+    out = torch.empty(B, Mq, H, dh, dtype=torch.float32, device=q.device)
+    strides = [(C.c_int64 * 3)(t.stride(0), t.stride(1), t.stride(2)) for t in (q, k, v)]
+    _dev(out, "out", torch.float32)
+    _timed("attn_f32_kernel", 4.0 * B * H * Mq * Mk * dh, lambda: check(_lib.load().primx_attention_f32(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Mq, Mk, dh, strides[0], strides[1], strides[2],
+        dh ** -0.5 if scale is None else scale, _stream()), "primx_attention_f32"))
+    return out
+
+
+def layernorm_modulate_f32(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, rows_per_batch: int,
+                           eps: float = 1e-6, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    rows, D = x.shape
+    if shift.stride(-1) != 1 or scale.stride(-1) != 1 or shift.stride(0) != scale.stride(0) \
+            or shift.dtype != torch.float32 or scale.dtype != torch.float32:
+        raise RuntimeError("layernorm_modulate_f32: shift/scale must be fp32, last-dim contiguous, equal row strides")
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().primx_layernorm_modulate_f32(_dev(x, "x", torch.float32), shift.data_ptr(), scale.data_ptr(),
+                                                   shift.stride(0), _dev(out, "out", torch.float32), rows, rows_per_batch,
+                                                   D, eps, _stream()), "primx_layernorm_modulate_f32")
+    return out
+
+
+def silu_f32(x: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(x)
+    check(_lib.load().primx_silu_f32(_dev(x, "x", torch.float32), out.data_ptr(), x.numel(), _stream()), "primx_silu_f32")
     return out

@@ -20,6 +20,7 @@ import torch
 from . import ops
 
 
+@ops.on_input_device
 def latents_to_primitives(samples: torch.Tensor, vae, latent_mean: Optional[Sequence[float]] = None,
                           latent_std: Optional[Sequence[float]] = None, latent_nf: float = 1.0,
                           max_prims_per_call: int = 8 * 2048) -> torch.Tensor:

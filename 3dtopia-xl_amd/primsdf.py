@@ -70,6 +70,7 @@ class PrimSDF(nn.Module):
             self.dim_feat, 0 if self.training else 1, ops._stream()), "primx_primsdf_query")
         return out
 
+    @ops.on_input_device
     def forward(self, x: torch.Tensor):
         out = self.query(x)
         return {"sdf": out[:, 0:1], "tex": out[:, 1:4], "mat": out[:, 4:6]}

@@ -21,6 +21,7 @@ def convert_camera_parameters(Rt: torch.Tensor, K: torch.Tensor):
     return {"campos": centre, "camrot": rot, "focal": K[:, :2, :2], "princpt": K[:, :2, 2]}
 
 
+@ops.on_input_device
 def compute_raydirs(viewpos, viewrot, focal, princpt, pixelcoords, volradius):
     N, H, W = pixelcoords.shape[0], pixelcoords.shape[1], pixelcoords.shape[2]
     dev = viewpos.device
@@ -83,6 +84,7 @@ class RayMarcher(nn.Module):
             self.__dict__["_coords"] = {key: c.contiguous()}
         return c[None].expand(B, -1, -1, -1).contiguous()
 
+    @ops.on_input_device
     def forward(self, prim_rgba, prim_pos, prim_rot, prim_scale, K, RT, ray_subsample_factor: Optional[int] = None):
         if self.training:
             raise NotImplementedError("the accelerated ray marcher is forward / inference only: call .eval()")
@@ -99,3 +101,30 @@ class RayMarcher(nn.Module):
                            (prim_pos / self.volradius, prim_rot, prim_scale),
                            prim_rgba.permute(0, 1, 3, 4, 5, 2), self.fadescale, self.fadeexp)
         return {"rgba_image": rgba.permute(0, 3, 1, 2), "pixel_coords": pixel_coords}
+
+
+def generate_colored_boxes(template: torch.Tensor, prim_rot: torch.Tensor, alpha: float = 10000.0, seed: int = 123456):
+    """Debug templates for the bounding-box preview (dva/ray_marcher.py:232-279, used by dva/visualize.py:26): every
+    primitive becomes an opaque box of one random colour, shaded by the face its voxel is nearest to.  template:
+    [B, K, 4, S, S, S] -> same shape.  Elementwise preparation of a marcher input (plumbing, plain torch); colours follow
+    the reference's `np.random.seed(seed)` stream so previews look the same."""
+    import numpy as np
+
+    B, K, S = template.shape[0], template.shape[1], template.shape[-1]
+    dev = template.device
+    lin = torch.linspace(-1.0, 1.0, S, device=dev)
+    zz, yy, xx = torch.meshgrid(lin, lin, lin, indexing="ij")
+    ax, ay, az = xx.abs(), yy.abs(), zz.abs()
+    # outward unit normal of the dominant face(s), in the marcher's (x, -y, -z) convention; ties share the normal
+    n = torch.stack([torch.where((ax >= ay) & (ax >= az), xx.sign(), torch.zeros_like(xx)),
+                     -torch.where((ay >= ax) & (ay >= az), yy.sign(), torch.zeros_like(xx)),
+                     -torch.where((az >= ax) & (az >= ay), zz.sign(), torch.zeros_like(xx))], dim=-1)
+    n = n / n.pow(2).sum(-1, keepdim=True).sqrt()
+    light = torch.full((3,), -3.0, device=dev)
+    light = light / light.norm()
+    shade = 1.4 * (n * light).sum(-1).clamp(min=0.2)                                   # [S, S, S]
+    colours = torch.as_tensor(np.random.RandomState(seed).rand(K, 3) * 255.0, dtype=template.dtype, device=dev)
+    out = template.clone()
+    out[:, :, :3] = colours[None, :, :, None, None, None] * shade[None, None, None]
+    out[:, :, 3] = alpha
+    return out

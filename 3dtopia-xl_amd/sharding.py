@@ -105,6 +105,8 @@ class ShardedSampler:
 
     def __init__(self, model: torch.nn.Module, diffusion, device, sync_weights: bool = True):
         self.model, self.diffusion, self.device = model, diffusion, torch.device(device)
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)   # RCCL and the primx_* launches use the current device's streams
         self.rank, self.world = _world()
         self.weight_bytes = broadcast_module_(model, 0) if sync_weights else 0
 

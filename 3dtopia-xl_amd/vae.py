@@ -258,6 +258,7 @@ class VAE(nn.Module):
             out = ops.linear_residual(att.view(P * V, Cc), w["w_proj"], w["b_proj"], None, 1.0)
         return out.view(P, V, Cc)
 
+    @ops.on_input_device
     def decode(self, x: torch.Tensor, denormalize: bool = False) -> torch.Tensor:
         """x: (P, 1, S, S, S) fp32 latents -> (P, out_channels, 2S, 2S, 2S) fp32  (vae3d_dib.py:437-440).
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 12
+#define PRIMX_ABI_VERSION 13
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -257,6 +257,36 @@ int primx_compute_raydirs(const float* viewpos, const float* viewrot, const floa
 int primx_raymarch(const float* raypos, const float* raydir, const float* tminmax, float stepsize, const float* primpos,
                    const float* primrot, const float* primscale, const float* tplate, float* rayrgba, int N, int H, int W,
                    int K, int TD, int TH, int TW, float fadescale, float fadeexp, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * The reference's fp32 call path: DiT.forward(x, t, y) with the signature defaults precision_dtype=float32,
+ * enable_amp=False (models/dit_crossattn.py:184) and `precision: tf32` of the CLI (inference.py:239-247).
+ * gfx950 has no TF32: these run EXACT fp32 on v_mfma_f32_32x32x2_f32 (csrc/fp32.hip).
+ * -------------------------------------------------------------------------------------------- */
+
+/* nn.Linear in fp32 on the matrix cores.  gate == NULL: out[M, N] = act(A W^T + bias) * out_scale.
+ * gate != NULL: out[m, n] += gate[(m / rows_per_batch) * gate_stride + n] * (A W^T + bias)[m, n], in place -
+ * `x = x + gate.unsqueeze(1) * branch` (models/dit_crossattn.py:55-57).  A [M, K], W [N, K] row-major, K % 4 == 0,
+ * 16-byte aligned.  Replaces F.linear outside autocast: models/attention.py:37-39,83-87, models/utils.py:87-91,
+ * models/dit_crossattn.py:40-43,68-72. */
+int primx_gemm_f32(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int act,
+                   float out_scale, const float* gate, int64_t gate_stride, int rows_per_batch, void* stream);
+
+/* xformers.ops.memory_efficient_attention(q, k, v) semantics for fp32 operands given as strided [B, M, H, dh] views
+ * (element strides {batch, token, head}; last dim contiguous) - e.g. the unbind() views of the fused qkv buffer:
+ * out [B, Nq, H, dh] contiguous = softmax(q k^T * scale) v, fp32 online softmax.  dh <= 128.
+ * Replaces models/attention.py:54,109 when autocast is off. */
+int primx_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int H, int Nq, int Nkv,
+                        int dh, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, float scale,
+                        void* stream);
+
+/* out[r, :] = LN(x[r, :]) * (1 + scale[b, :]) + shift[b, :] in fp32 (no affine; b = r / rows_per_batch; shift/scale
+ * at element stride mod_stride between batch entries).  models/dit_crossattn.py:32-36,55-57,67,76 outside autocast. */
+int primx_layernorm_modulate_f32(const float* x, const float* shift, const float* scale, int64_t mod_stride, float* out,
+                                 int rows, int rows_per_batch, int D, float eps, void* stream);
+
+/* out = x * sigmoid(x), fp32: the nn.SiLU in front of every adaLN Linear (models/dit_crossattn.py:40-43,69-72). */
+int primx_silu_f32(const float* in, float* out, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -111,10 +111,12 @@ def test_ancestral_step(ops):
         mo = (synth.tensor(6, "mo", (2, 64, 136)) * 0.7).to(dt)
         for i in (24, 7, 0):
             ref = dref.ancestral_step(tab, i, x, mo, noise)
-            s, x0 = ops.diffusion_step(x.to(DEV), mo.to(DEV), coef, i, mean_type=2, var_type=3, ancestral=True,
-                                       clip_denoised=False, noise=noise.to(DEV))
-            assert torch.equal(x0.cpu(), ref["pred_xstart"])
-            assert max_abs(s, ref["sample"]) < 2e-6 * max(1.0, float(ref["sample"].abs().max()))  # expf ulp
+            # ModelVarType.LEARNED takes the same log-variance interpolation as LEARNED_RANGE (gaussian_diffusion.py:285-293)
+            for var_type in (3, 2):
+                s, x0 = ops.diffusion_step(x.to(DEV), mo.to(DEV), coef, i, mean_type=2, var_type=var_type, ancestral=True,
+                                           clip_denoised=False, noise=noise.to(DEV))
+                assert torch.equal(x0.cpu(), ref["pred_xstart"])
+                assert max_abs(s, ref["sample"]) < 2e-6 * max(1.0, float(ref["sample"].abs().max()))  # expf ulp
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

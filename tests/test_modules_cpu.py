@@ -54,8 +54,10 @@ def test_cpu_tensors_are_refused(pkg):
     x, t, y = torch.zeros(1, 64, 68), torch.zeros(1, dtype=torch.long), torch.zeros(1, 3, 96)
     with pytest.raises(RuntimeError, match="no CPU path"):
         m(x, t, y, torch.float16, True)
-    with pytest.raises(NotImplementedError):
-        m(x, t, y)                                 # fp32 / no-amp variant is not accelerated
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(x, t, y)                                 # the fp32 / no-amp signature default also runs on the HIP path only
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.forward_with_cfg(x, t, y, 6.0)
     vae = pkg.VAE(**VAE_CFG)
     with pytest.raises(RuntimeError, match="no CPU path"):
         vae.decode(torch.zeros(2, 1, 4, 4, 4))
@@ -63,19 +65,6 @@ def test_cpu_tensors_are_refused(pkg):
         pkg.memory_efficient_attention(torch.zeros(1, 4, 2, 32, dtype=torch.float16),
                                        torch.zeros(1, 4, 2, 32, dtype=torch.float16),
                                        torch.zeros(1, 4, 2, 32, dtype=torch.float16))
-
-
-def test_compat_shim_resolves_reference_class_names():
-    """compat/ mirrors the reference's import paths (configs/inference_dit.yml:32,53 class_name strings)."""
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r);"
-            "import importlib;"
-            "m = importlib.import_module('models.dit_crossattn'); v = importlib.import_module('models.vae3d_dib');"
-            "d = importlib.import_module('models.diffusion');"
-            "import topia_xl_amd as p;"
-            "assert m.DiT is p.DiT and v.VAE is p.VAE and d.create_diffusion is p.create_diffusion; print('ok')"
-            ) % (ROOT, os.path.join(ROOT, "compat"))
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
-    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
 
 
 def test_denoised_pt_round_trip(tmp_path):
