@@ -137,6 +137,7 @@ class DiT(nn.Module):
         self._pack: Dict = {}
         self._heads_ws: Dict = {}
         self._cond: Optional[Dict] = None
+        self._packed_only = False   # set on ranks that received the packed blob instead of the fp32 parameters
         # Opt-in exact-algebra shortcut: to_k(y) / to_v(y) do not depend on the timestep
         # (models/attention.py:106-107), so with this flag the K / V projections of all blocks are computed once per
         # conditioning tensor and reused across DDIM steps.  Off by default: a step then executes the reference's full
@@ -165,6 +166,7 @@ class DiT(nn.Module):
         self._pack = {}
         self._heads_ws = {}
         self._cond = None
+        self._packed_only = False
 
     def _apply(self, fn, *a, **k):
         self.__dict__["_pack"] = {}
@@ -176,39 +178,89 @@ class DiT(nn.Module):
         self.repack()
         return super().load_state_dict(*a, **k)
 
+    # The packed 16-bit weights live in ONE flat device buffer ("blob": 1.82 GB for DiT-XL) that the per-layer operands
+    # are views of: it is filled in place from the fp32 parameters (no concatenation temporaries), it is what a
+    # multi-GPU launch broadcasts over xGMI (sharding.broadcast_packed_, SURVEY.md section 8e), and a rank that
+    # received it needs no fp32 parameters at all for the 16-bit path.
+    _PACK_ALIGN = 128   # elements: every operand starts 256-byte aligned
+
+    def _pack_layout(self):
+        """[(name, block index or None, shape)] in blob order - derived from the hyper-parameters only."""
+        D, Dc, depth = self.hidden_size, self.condition_channels, self.depth
+        Hm = self.blocks[0].mlp.fc1.out_features if depth else 0
+        proj_bias = depth > 0 and self.blocks[0].attn.proj.bias is not None
+        items = []
+        for i in range(depth):
+            items += [("w_q", i, (D, D)), ("b_q", i, (D,)), ("w_cproj", i, (D, D)), ("b_cproj", i, (D,) if proj_bias else None),
+                      ("w_qkv", i, (3 * D, D)), ("b_qkv", i, (3 * D,)), ("w_proj", i, (D, D)),
+                      ("b_proj", i, (D,) if proj_bias else None), ("w_fc1", i, (Hm, D)), ("b_fc1", i, (Hm,)),
+                      ("w_fc2", i, (D, Hm)), ("b_fc2", i, (D,))]
+        # to_k / to_v of ALL blocks read the same conditioning tokens: one [depth*2D, Dc] matrix; ONE adaLN matrix
+        items += [("w_kv_all", None, (depth * 2 * D, Dc) if depth else None), ("b_kv_all", None, (depth * 2 * D,) if depth else None),
+                  ("w_ada", None, (depth * 9 * D + 2 * D, D)), ("b_ada", None, (depth * 9 * D + 2 * D,)),
+                  ("w_final", None, (self.out_channels, D)), ("b_final", None, (self.out_channels,))]
+        return items
+
+    def packed_alloc(self, dtype: torch.dtype, device=None) -> Dict:
+        """Allocate the blob and the operand views WITHOUT filling them (a non-source rank of a broadcast does this)."""
+        device = self.x_embedder.weight.device if device is None else torch.device(device)
+        layout = self._pack_layout()
+        al = self._PACK_ALIGN
+        total = sum(ops.round_up(math.prod(shp), al) for _, _, shp in layout if shp is not None)
+        flat = torch.zeros(total, dtype=dtype, device=device)      # alignment gaps stay zero: the blob is reproducible byte for byte
+        pk: Dict = {"blocks": [dict() for _ in range(self.depth)], "_flat": flat}
+        off = 0
+        for name, blk, shp in layout:
+            view = None
+            if shp is not None:
+                n = math.prod(shp)
+                view = flat[off:off + n].view(shp)
+                off += ops.round_up(n, al)
+            (pk if blk is None else pk["blocks"][blk])[name] = view
+        self._pack = {(dtype, device): pk}
+        self._cond = None
+        return pk
+
     def packed(self, dtype: torch.dtype) -> Dict:
         """One-time conversion of the fp32 parameters into the 16-bit operands the kernels stream:
         per block fused [to_k; to_v] and qkv matrices, and ONE adaLN matrix for all blocks + final."""
-        key = (dtype, self.x_embedder.weight.device)
+        dev = self.x_embedder.weight.device
+        key = (dtype, dev)
         if key in self._pack:
             return self._pack[key]
+        if self._packed_only:
+            raise RuntimeError(f"this rank holds only a broadcast packed blob, and not for ({dtype}, {dev})")
+        pk = self.packed_alloc(dtype, dev)
+        D = self.hidden_size
         with torch.no_grad():
-            blocks = []
-            for blk in self.blocks:
-                ca, sa, mlp = blk.crossattn, blk.attn, blk.mlp
-                blocks.append({
-                    "w_q": _c16(ca.to_q.weight, dtype), "b_q": _c16(ca.to_q.bias, dtype),
-                    "w_cproj": _c16(ca.proj.weight, dtype), "b_cproj": _c16(ca.proj.bias, dtype),
-                    "w_qkv": _c16(sa.qkv.weight, dtype), "b_qkv": _c16(sa.qkv.bias, dtype),
-                    "w_proj": _c16(sa.proj.weight, dtype), "b_proj": _c16(sa.proj.bias, dtype),
-                    "w_fc1": _c16(mlp.fc1.weight, dtype), "b_fc1": _c16(mlp.fc1.bias, dtype),
-                    "w_fc2": _c16(mlp.fc2.weight, dtype), "b_fc2": _c16(mlp.fc2.bias, dtype),
-                })
-            ada_w = [b.adaLN_modulation[1].weight for b in self.blocks] + [self.final_layer.adaLN_modulation[1].weight]
-            ada_b = [b.adaLN_modulation[1].bias for b in self.blocks] + [self.final_layer.adaLN_modulation[1].bias]
-            kv_w = [torch.cat([b.crossattn.to_k.weight, b.crossattn.to_v.weight], 0) for b in self.blocks]
-            kv_b = [torch.cat([b.crossattn.to_k.bias, b.crossattn.to_v.bias], 0) for b in self.blocks]
-            pk = {
-                "blocks": blocks,
-                # to_k / to_v of ALL blocks read the same conditioning tokens: one [depth*2D, Dc] matrix
-                "w_kv_all": _c16(torch.cat(kv_w, 0), dtype) if kv_w else None,
-                "b_kv_all": _c16(torch.cat(kv_b, 0), dtype) if kv_b else None,
-                "w_ada": _c16(torch.cat(ada_w, 0), dtype), "b_ada": _c16(torch.cat(ada_b, 0), dtype),
-                "w_final": _c16(self.final_layer.linear.weight, dtype),
-                "b_final": _c16(self.final_layer.linear.bias, dtype),
-            }
-        self._pack = {key: pk}
+            for i, blk in enumerate(self.blocks):
+                ca, sa, mlp, w = blk.crossattn, blk.attn, blk.mlp, pk["blocks"][i]
+                for name, lin in (("q", ca.to_q), ("cproj", ca.proj), ("qkv", sa.qkv), ("proj", sa.proj), ("fc1", mlp.fc1),
+                                  ("fc2", mlp.fc2)):
+                    w["w_" + name].copy_(lin.weight)                     # fp32 -> 16-bit cast in the copy
+                    if w["b_" + name] is not None:
+                        w["b_" + name].copy_(lin.bias)
+                pk["w_kv_all"][i * 2 * D:i * 2 * D + D].copy_(ca.to_k.weight)
+                pk["w_kv_all"][i * 2 * D + D:(i + 1) * 2 * D].copy_(ca.to_v.weight)
+                pk["b_kv_all"][i * 2 * D:i * 2 * D + D].copy_(ca.to_k.bias)
+                pk["b_kv_all"][i * 2 * D + D:(i + 1) * 2 * D].copy_(ca.to_v.bias)
+                pk["w_ada"][i * 9 * D:(i + 1) * 9 * D].copy_(blk.adaLN_modulation[1].weight)
+                pk["b_ada"][i * 9 * D:(i + 1) * 9 * D].copy_(blk.adaLN_modulation[1].bias)
+            base = self.depth * 9 * D
+            pk["w_ada"][base:].copy_(self.final_layer.adaLN_modulation[1].weight)
+            pk["b_ada"][base:].copy_(self.final_layer.adaLN_modulation[1].bias)
+            pk["w_final"].copy_(self.final_layer.linear.weight)
+            pk["b_final"].copy_(self.final_layer.linear.bias)
         return pk
+
+    def small_fp32_tensors(self):
+        """The fp32 parameters the 16-bit path reads directly (embedders outside autocast, dit_crossattn.py:191-192, and
+        the null conditioning row): what travels next to the packed blob in a broadcast."""
+        ts = [self.x_embedder.weight, self.x_embedder.bias, self.t_embedder.mlp[0].weight, self.t_embedder.mlp[0].bias,
+              self.t_embedder.mlp[2].weight, self.t_embedder.mlp[2].bias]
+        if self.cond_drop_prob > 0:
+            ts.append(self.null_cond_embedding)
+        return [t.data for t in ts]
 
     def _heads(self, tag: str, B: int, n: int, kind: int, dtype, device, pad_to: int) -> torch.Tensor:
         """Persistent zero-padded attention operand buffers (pads are never written, so they stay zero)."""
@@ -358,6 +410,9 @@ class DiT(nn.Module):
     def _forward_fp32(self, x, t, y):
         """The reference with autocast off: every Linear, the attention core, LayerNorm, modulate, GELU and the gated
         residuals in fp32 (dit_crossattn.py:184-202 with enable_amp=False).  Reads the fp32 parameters directly."""
+        if self._packed_only:
+            raise RuntimeError("this rank received only the packed 16-bit weights (sharding.broadcast_packed_): the fp32 "
+                               "route needs the fp32 parameters - use broadcast_module_")
         Be, N, Cin = x.shape
         L, Dc = y.shape[1], y.shape[2]
         D, H = self.hidden_size, self.num_heads

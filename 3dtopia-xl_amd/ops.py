@@ -221,7 +221,7 @@ def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: 
     tag = _gemm_tag(0, M, N, K, A.dtype)
     if M <= 4 and N % 4 == 0 and K % 8 == 0 and act == 0 and out_scale == 1.0 and os.environ.get("PRIMX_GEMM_NOGEMV") != "1":
         tag = f"gemv16_kernel<{dtype_code(A.dtype)}>"     # few-row streaming path (csrc/gemm.hip primx_linear)
-    _timed(tag, 2.0 * M * N * K, lambda: check(_lib.load().primx_linear(
+    _timed(f"{tag} {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear(
         _dev(A, "A"), _dev(W, "W"), _dev(bias, "bias", A.dtype) if bias is not None else None,
         _dev(out, "out", A.dtype), M, N, K, dtype_code(A.dtype), act, out_scale, _stream()), "primx_linear"))
     return out
@@ -234,7 +234,7 @@ def linear_gate_residual(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.
     N = W.shape[0]
     if gate.stride(-1) != 1 or gate.dtype != A.dtype or not gate.is_cuda:
         raise RuntimeError("gate must be a last-dim-contiguous 16-bit device view")
-    _timed(_gemm_tag(1, M, N, K, A.dtype), 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_gate_residual(
+    _timed(f"{_gemm_tag(1, M, N, K, A.dtype)} {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_gate_residual(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None,
         gate.data_ptr(), gate.stride(0), _dev(x, "x", torch.float32), M, N, K, rows_per_batch,
         dtype_code(A.dtype), _stream()), "primx_linear_gate_residual"))
@@ -250,7 +250,7 @@ def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     n_seg = len(kinds)
     kind_arr = (C.c_int * n_seg)(*kinds)
     dst_arr = (C.c_void_p * n_seg)(*[_dev(d, "dst", A.dtype) for d in dsts])
-    _timed(_gemm_tag(2, M, N, K, A.dtype, (heads, dh, rows_per_batch)), 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_heads(
+    _timed(f"{_gemm_tag(2, M, N, K, A.dtype, (heads, dh, rows_per_batch))} {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_heads(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None, M, N, K,
         rows_per_batch, heads, dh, n_seg, kind_arr, dst_arr, n_rep, rep_batches, n_pad, scale0, dtype_code(A.dtype),
         _stream()),
@@ -296,8 +296,8 @@ def attention(Qp: torch.Tensor, Kp: torch.Tensor, Vt: torch.Tensor, nq: int, nkv
     if out is None:
         out = torch.empty(B, nq, H * dh, dtype=Qp.dtype, device=Qp.device)
     # algorithmic FLOPs: QK^T + PV on the unpadded head dim, softmax excluded
-    _timed(f"attn_kernel<{dtype_code(Qp.dtype)}, {padded_head_dim(dh) // 16}, {(dh + 31) // 32}, {int(padded_head_dim(dh) == dh)}, 0>",
-           4.0 * B * H * nq * nkv * dh, lambda: check(_lib.load().primx_attention(
+    _timed(f"attn_kernel<{dtype_code(Qp.dtype)}, {padded_head_dim(dh) // 16}, {(dh + 31) // 32}, {int(padded_head_dim(dh) == dh)}, 0> "
+           f"{B * H}x{nq}x{nkv}x{dh}", 4.0 * B * H * nq * nkv * dh, lambda: check(_lib.load().primx_attention(
         _dev(Qp, "Qp"), _dev(Kp, "Kp", Qp.dtype), _dev(Vt, "Vt", Qp.dtype), _dev(out, "out", Qp.dtype), B, H, nq,
         nq_pad, nkv, nkv_pad, dh, scale, dtype_code(Qp.dtype), _stream()), "primx_attention"))
     return out
@@ -361,9 +361,9 @@ def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
     """x: [P, V, C] 16-bit channels-last."""
     P, V, Cc = x.shape
     out = torch.empty_like(x)
-    check(_lib.load().primx_groupnorm_silu(_dev(x, "x"), _dev(gamma, "gamma", torch.float32),
-                                           _dev(beta, "beta", torch.float32), out.data_ptr(), P, V, Cc, groups, eps,
-                                           int(silu), dtype_code(x.dtype), _stream()), "primx_groupnorm_silu")
+    _timed(f"groupnorm_silu {Cc}ch @{V}vox x{P}", 0.0, lambda: check(_lib.load().primx_groupnorm_silu(
+        _dev(x, "x"), _dev(gamma, "gamma", torch.float32), _dev(beta, "beta", torch.float32), out.data_ptr(), P, V, Cc,
+        groups, eps, int(silu), dtype_code(x.dtype), _stream()), "primx_groupnorm_silu"))
     return out
 
 
@@ -373,12 +373,10 @@ def conv3d_k3(x: torch.Tensor, Wk: torch.Tensor, bias: Optional[torch.Tensor], S
     P, V, Cin = x.shape
     Cout, Kpad = Wk.shape
     out = torch.empty(P, V, Cout, dtype=x.dtype, device=x.device)
-    check(_lib.load().primx_conv3d_k3(_dev(x, "x"), _dev(Wk, "Wk", x.dtype),
-                                      _dev(bias, "bias", x.dtype) if bias is not None else None,
-                                      _dev(res, "res", x.dtype) if res is not None else None, res_scale,
-                                      out.data_ptr(), P, S, Cin, Cout, Kpad,
-                                      dtype_code(x.dtype), _stream()),
-          "primx_conv3d_k3")
+    _timed(f"conv3d_k3 {Cin}->{Cout} @{S}^3 x{P}", 2.0 * P * V * Cout * 27 * Cin, lambda: check(_lib.load().primx_conv3d_k3(
+        _dev(x, "x"), _dev(Wk, "Wk", x.dtype), _dev(bias, "bias", x.dtype) if bias is not None else None,
+        _dev(res, "res", x.dtype) if res is not None else None, res_scale, out.data_ptr(), P, S, Cin, Cout, Kpad,
+        dtype_code(x.dtype), _stream()), "primx_conv3d_k3"))
     return out
 
 
@@ -388,11 +386,10 @@ def linear_residual(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tenso
     M, K = A.shape
     N = W.shape[0]
     out = torch.empty(M, N, dtype=A.dtype, device=A.device)
-    check(_lib.load().primx_linear_residual(_dev(A, "A"), _dev(W, "W", A.dtype),
-                                            _dev(bias, "bias", A.dtype) if bias is not None else None,
-                                            _dev(res, "res", A.dtype) if res is not None else None, scale,
-                                            out.data_ptr(), M, N, K, dtype_code(A.dtype), _stream()),
-          "primx_linear_residual")
+    _timed(f"linear_residual {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_residual(
+        _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None,
+        _dev(res, "res", A.dtype) if res is not None else None, scale, out.data_ptr(), M, N, K, dtype_code(A.dtype),
+        _stream()), "primx_linear_residual"))
     return out
 
 
@@ -413,9 +410,10 @@ def convtranspose_k2s2(x: torch.Tensor, Wt: torch.Tensor, bias: torch.Tensor, S:
     P, V, Cin = x.shape
     Cout = Wt.shape[0] // 8
     out = torch.empty(P, 8 * V, Cout, dtype=x.dtype, device=x.device)
-    check(_lib.load().primx_convtranspose_k2s2(_dev(x, "x"), _dev(Wt, "Wt", x.dtype), _dev(bias, "bias", x.dtype),
-                                               out.data_ptr(), P, S, Cin, Cout, dtype_code(x.dtype), _stream()),
-          "primx_convtranspose_k2s2")
+    _timed(f"convtranspose_k2s2 {Cin}->{Cout} @{S}^3 x{P}", 2.0 * P * V * 8 * Cout * Cin, lambda: check(
+        _lib.load().primx_convtranspose_k2s2(_dev(x, "x"), _dev(Wt, "Wt", x.dtype), _dev(bias, "bias", x.dtype),
+                                             out.data_ptr(), P, S, Cin, Cout, dtype_code(x.dtype), _stream()),
+        "primx_convtranspose_k2s2"))
     return out
 
 

@@ -61,6 +61,31 @@ def broadcast_module_(module: torch.nn.Module, src: int = 0) -> int:
     return total
 
 
+def broadcast_packed_(model: torch.nn.Module, dtype: torch.dtype, src: int = 0) -> int:
+    """Broadcast what the 16-bit sampling path actually reads instead of the fp32 parameters: the model's packed weight
+    blob (ONE flat 16-bit buffer, 1.82 GB for DiT-XL - `DiT.packed`) plus the few fp32 tensors used outside autocast
+    (token / timestep embedders, null conditioning row).  Half the bytes of `broadcast_module_` over the xGMI links, no
+    concatenation copy on either side (the blob IS the storage of the per-layer operands), and the receiving ranks skip
+    the fp32 -> 16-bit repack.  Non-source ranks are marked packed-only: their fp32 parameters are not valid, so the
+    fp32 route and a different dtype raise there.  Returns bytes sent (0 for world size 1)."""
+    rank, world = _world()
+    if world == 1:
+        return 0
+    pk = model.packed(dtype) if rank == src else model.packed_alloc(dtype)
+    dist.broadcast(pk["_flat"], src=src)
+    small = model.small_fp32_tensors()
+    flat32 = torch.cat([t.reshape(-1).float() for t in small])
+    dist.broadcast(flat32, src=src)
+    if rank != src:
+        off = 0
+        for t in small:
+            n = t.numel()
+            t.copy_(flat32[off:off + n].view_as(t))
+            off += n
+        model._packed_only = True
+    return pk["_flat"].numel() * pk["_flat"].element_size() + flat32.numel() * 4
+
+
 def scatter_batch(full: Optional[torch.Tensor], shape_tail: Sequence[int], n_items: int, dtype: torch.dtype,
                   device, src: int = 0) -> torch.Tensor:
     """Rank ``src`` holds ``full`` [n_items, *shape_tail]; every rank receives its contiguous slice."""
@@ -103,12 +128,18 @@ def gather_batch(local: torch.Tensor, n_items: int, dst: int = 0) -> Optional[to
 class ShardedSampler:
     """Batch-sharded DDIM sampling over the ranks of the default process group."""
 
-    def __init__(self, model: torch.nn.Module, diffusion, device, sync_weights: bool = True):
+    def __init__(self, model: torch.nn.Module, diffusion, device, sync_weights: bool = True,
+                 packed_dtype: Optional[torch.dtype] = None):
+        """sync_weights: broadcast rank 0's weights at construction - the packed 16-bit blob when `packed_dtype` is given
+        (the sampling dtype; half the bytes, receivers need no repack), else every fp32 parameter."""
         self.model, self.diffusion, self.device = model, diffusion, torch.device(device)
         if self.device.type == "cuda":
             torch.cuda.set_device(self.device)   # RCCL and the primx_* launches use the current device's streams
         self.rank, self.world = _world()
-        self.weight_bytes = broadcast_module_(model, 0) if sync_weights else 0
+        self.weight_bytes = 0
+        if sync_weights:
+            self.weight_bytes = (broadcast_packed_(model, packed_dtype, 0) if packed_dtype is not None
+                                 else broadcast_module_(model, 0))
 
     def sample(self, batch: int, n_tokens: int, channels: int, cond: Optional[torch.Tensor], seed: Optional[int],
                loop: Optional[Callable] = None, **model_kwargs) -> Optional[torch.Tensor]:
@@ -136,3 +167,41 @@ class ShardedSampler:
                                                   clip_denoised=False, model_kwargs=dict(y=y, **model_kwargs),
                                                   device=self.device)
         return gather_batch(out, batch)
+
+    def sample_and_decode(self, batch: int, n_tokens: int, channels: int, cond: Optional[torch.Tensor],
+                          seed: Optional[int], decode: Callable[[torch.Tensor], torch.Tensor],
+                          loop: Optional[Callable] = None, **model_kwargs) -> Optional[torch.Tensor]:
+        """`sample`, then every rank decodes ITS OWN samples (`decode(samples [b, N, C]) -> [b, N, F]`, e.g.
+        `lambda s: pipeline.latents_to_primitives(s, vae, mean, std)`: primitives are independent, SURVEY.md section
+        8e) and only the decoded primitives are gathered on rank 0 - the 25 MB/sample payload crosses xGMI once, the
+        decoder work is spread over all GPUs."""
+        noise = None
+        if self.rank == 0:
+            gen = torch.Generator().manual_seed(seed) if seed is not None else None
+            noise = torch.randn(batch, n_tokens, channels, generator=gen)
+        if self.world > 1:
+            meta = [tuple(cond.shape[1:])] if self.rank == 0 else [None]
+            dist.broadcast_object_list(meta, src=0)
+            cond_tail = meta[0]
+        else:
+            cond_tail = tuple(cond.shape[1:])
+        x = scatter_batch(noise, (n_tokens, channels), batch, torch.float32, self.device)
+        y = scatter_batch(cond, cond_tail, batch, torch.float32, self.device)
+        if x.shape[0] == 0:
+            dec = None
+        else:
+            if loop is not None:
+                out = loop(x, y)
+            else:
+                out = self.diffusion.ddim_sample_loop(self.model.forward_with_cfg, tuple(x.shape), noise=x,
+                                                      clip_denoised=False, model_kwargs=dict(y=y, **model_kwargs),
+                                                      device=self.device)
+            dec = decode(out)
+        if self.world == 1:
+            return dec
+        # ranks without samples (batch < world size) still take part in the gather: they learn the feature width first
+        width = [int(dec.shape[-1])] if self.rank == 0 else [None]
+        dist.broadcast_object_list(width, src=0)
+        if dec is None:
+            dec = torch.empty(0, n_tokens, width[0], dtype=torch.float32, device=self.device)
+        return gather_batch(dec.float().contiguous(), batch)

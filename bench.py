@@ -1,26 +1,34 @@
 #!/usr/bin/env python
-"""Headline benchmark: DiT denoise-steps/s (N_prim = 2048) on the HIP path.
+"""Headline benchmark of the hot path on the HIP device.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config ddim|decode|c4] [--batch B] [--repeats R]
 
-A "step" is one DDIM iteration of the hot path on one batch of synthetic input: ``forward_with_cfg``
-(effective batch 2B: cond + uncond) through the 28-block PrimX DiT-XL plus the fused diffusion update.
-Workload at N = 1: BASELINE.json configs[1] - DiT-XL (d=1152, 28 blocks, 16 heads x 72), N_prim=2048,
-1370 x 768 conditioning tokens, fp16, CFG 6, batch 1, ddim25 schedule.  N > 1: one process per GPU
-(torch.distributed / RCCL), rank 0's random-init weights are broadcast once as one flat buffer, then
-every rank runs its own batch with no collective inside the loop (weak scaling).
+--config ddim (default): metric = DiT denoise-steps/s.  A "step" is one DDIM iteration on one batch of synthetic input:
+  `forward_with_cfg` (effective batch 2B: cond + uncond) through the 28-block PrimX DiT-XL plus the fused diffusion
+  update.  Workload at N = 1: BASELINE.json configs[1] - DiT-XL (d=1152, 28 blocks, 16 heads x 72), N_prim=2048,
+  1370 x 768 conditioning tokens, fp16, CFG 6, batch 1, ddim25 schedule.
+--config decode: SURVEY.md section 8d metric (2)'s second leg - a "step" is `latents_to_primitives` of one batch of
+  samples (latent de-normalisation + VAE.decode of B x 2048 primitives + inverse normalisation); metric = samples/s.
+--config c4: BASELINE.json configs[3] - batch 8, 100 DDIM steps + decode: K DDIM steps at batch 8 are timed and the
+  decode is timed separately; samples/s = 8 / (100 x step + decode).
 
-Prints ONE JSON line on rank 0: the contract fields + ``roofline`` (dominant kernel, algorithmic
-FLOPs / HIP-event launch time vs the 2.5 PFLOP/s dense fp16 MFMA peak) + ``cpu_baseline`` (the CPU
-oracle - a port of the reference algorithm - timed on this host on a bounded sample of the same step).
-Inputs are resident in HBM before the timed region; random-init weights with the zero-initialised
-adaLN / final layers overwritten (SURVEY.md section 7 "vacuous-parity trap").
+N > 1: one process per GPU (torch.distributed / RCCL); rank 0's packed 16-bit weight blob is broadcast once, then every
+rank runs its own batch with no collective inside the loop (weak scaling).  The timed region is K steps between
+barrier + synchronize, repeated R times (median reported); MAX over ranks.
+
+Prints ONE JSON line on rank 0: the contract fields + `roofline` (dominant kernel BY SHAPE, algorithmic FLOPs /
+HIP-event launch time vs the 2.5 PFLOP/s dense fp16 MFMA peak) + `cpu_baseline` (the CPU oracle - a port of the
+reference algorithm - timed on this host on a bounded sample of the same step) + `parity` (the benchmarked model's own
+output against the fp32 golden of the REAL reference at the full 28-block configuration, and against the fp32 oracle
+forward the cpu_baseline leg computes).  Weights: deterministic synthetic (oracle/synth.py, every layer non-zero - the
+"vacuous-parity trap" of SURVEY.md section 7); inputs resident in HBM before the timed region.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -31,8 +39,12 @@ sys.path.insert(0, ROOT)
 
 XL = dict(seq_length=2048, in_channels=68, condition_channels=768, hidden_size=1152, depth=28, num_heads=16,
           attn_proj_bias=True, cond_drop_prob=0.1, gradient_checkpointing=False)  # configs/inference_dit.yml:52-62
+VAE_CFG = dict(in_channels=6, latent_channels=1, out_channels=6, down_channels=[32, 256], mid_attention=True,
+               up_channels=[256, 32], layers_per_block=2, gradient_checkpointing=False)  # configs/inference_dit.yml:32-43
 L_COND = 1370
-PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, MI355X_MICROARCH.md chip table
+PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA, MI355X_MICROARCH.md chip table
+VAE_FLOPS_PER_PRIM = 2.2428e9
+WEIGHT_SEED = 4321     # = tests/golden/make_golden_xl.py XL_SEED: the benchmarked weights are the golden's weights
 
 
 def forward_flops(N: int, L: int, D: int = 1152, depth: int = 28, Dc: int = 768, C: int = 68) -> float:
@@ -42,21 +54,15 @@ def forward_flops(N: int, L: int, D: int = 1152, depth: int = 28, Dc: int = 768,
     return depth * blk + 2 * N * C * D + 2 * 256 * D + 2 * D * D + 4 * D * D + 4 * N * D * C
 
 
-def random_init_(model: torch.nn.Module, seed: int) -> None:
-    """Non-zero random weights drawn on the device (activations O(1) through depth, small non-zero gates)."""
-    g = torch.Generator(device=next(model.parameters()).device).manual_seed(seed)
-    with torch.no_grad():
-        for name, p in model.named_parameters():
-            if name == "null_cond_embedding":
-                std = 1.0
-            elif name.endswith("bias"):
-                std = 0.05
-            elif "adaLN_modulation" in name:
-                std = 0.6 / p.shape[1] ** 0.5
-            else:
-                std = 1.0 / p.shape[1] ** 0.5
-            p.copy_(torch.randn(p.shape, generator=g, device=p.device) * std)
-    model.repack()
+def kv_projection_flops(L: int, D: int = 1152, depth: int = 28, Dc: int = 768) -> float:
+    """to_k + to_v of every block for one sample (the step-invariant part, counted in forward_flops)."""
+    return depth * 4.0 * L * Dc * D
+
+
+def load_synth_weights(model: torch.nn.Module, depth: int) -> None:
+    from oracle import synth   # deterministic generator only (no oracle arithmetic): same tensors as the goldens
+    sd = synth.dit_state_dict(WEIGHT_SEED, in_channels=68, condition_channels=768, hidden_size=1152, depth=depth)
+    model.load_state_dict(sd, strict=True)
 
 
 def step_stream(diffusion, model, x, kw):
@@ -67,26 +73,94 @@ def step_stream(diffusion, model, x, kw):
             yield out
 
 
-def cpu_baseline(n_prim: int, budget_blocks: int = 14, threads: int = 32):
-    """The CPU oracle (oracle/dit_ref.py, fp32 - the port of the reference algorithm) on a bounded
-    sample: one CFG step (effective batch 2) at the full width with `budget_blocks` of the 28 blocks,
-    extrapolated linearly in depth (blocks are identical in cost; embedders/final layer are < 0.1 %)."""
+def cpu_baseline_ddim(n_prim: int, budget_blocks: int = 14, threads: int = 32):
+    """The CPU oracle (oracle/dit_ref.py, fp32 - the port of the reference algorithm) on a bounded sample: one CFG step
+    (effective batch 2) at the full width with `budget_blocks` of the 28 blocks, extrapolated linearly in depth (blocks
+    are identical in cost; embedders / final layer are < 0.1 %).  Returns (record, oracle output, inputs) - the output
+    is what the `parity` leg compares the GPU's forward of the SAME truncated model with."""
     from oracle import dit_ref, synth
     dit_ref.ATTN_DTYPE = torch.float32
-    cfg = dict(in_channels=68, condition_channels=768, hidden_size=1152, depth=budget_blocks)
-    sd = synth.dit_state_dict(0, **cfg)
-    x = synth.tensor(0, "x", (1, n_prim, 68))
-    y = synth.tensor(0, "y", (1, L_COND, 768))
-    t = torch.tensor([960])
+    sd = synth.dit_state_dict(WEIGHT_SEED, in_channels=68, condition_channels=768, hidden_size=1152, depth=budget_blocks)
+    x = synth.tensor(WEIGHT_SEED, "xl_c2.x", (1, n_prim, 68))
+    y = synth.tensor(WEIGHT_SEED, "xl_c2.y", (1, L_COND, 768))
+    t = torch.tensor([800])
     torch.set_num_threads(min(threads, os.cpu_count() or 1))   # 32 is the measured optimum on the 256-core GPU-box host
     with torch.no_grad():
         t0 = time.perf_counter()
-        dit_ref.dit_forward_with_cfg(sd, x, t, y, 16, 6.0)
+        out = dit_ref.dit_forward_with_cfg(sd, x, t, y, 16, 6.0)
         dt = time.perf_counter() - t0
     per_step = dt * 28.0 / budget_blocks
-    return {"value": 1.0 / per_step, "unit": "denoise-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 CFG step (eff. batch 2), N_prim={n_prim}, L=1370, d=1152, {budget_blocks}/28 blocks timed "
-                      f"({dt:.1f} s) and scaled x{28 // budget_blocks}; fp32 torch-CPU oracle"}
+    rec = {"value": 1.0 / per_step, "unit": "denoise-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"1 CFG step (eff. batch 2), N_prim={n_prim}, L=1370, d=1152, {budget_blocks}/28 blocks timed "
+                     f"({dt:.1f} s) and scaled x{28 // budget_blocks}; fp32 torch-CPU oracle"}
+    return rec, out, (sd, x, y, t, budget_blocks)
+
+
+def cpu_baseline_decode(vae_sd, n_prims: int = 96, threads: int = 32):
+    """oracle/vae_ref.py (fp32 port of VAE.decode) on a bounded sample of primitives; samples/s = prims/s / 2048."""
+    from oracle import synth, vae_ref
+    z = synth.tensor(WEIGHT_SEED, "bench.vae.z", (n_prims, 1, 4, 4, 4))
+    torch.set_num_threads(min(threads, os.cpu_count() or 1))
+    with torch.no_grad():
+        vae_ref.vae_decode(vae_sd, z[:8])
+        t0 = time.perf_counter()
+        out = vae_ref.vae_decode(vae_sd, z)
+        dt = time.perf_counter() - t0
+    rec = {"value": n_prims / dt / 2048.0, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"VAE.decode of {n_prims} primitives ({dt:.1f} s), scaled to 2048 primitives per sample; fp32 torch-CPU oracle"}
+    return rec, out, z
+
+
+def timed_repeats(run_steps, steps: int, repeats: int, world: int, dist, dev):
+    """R x (barrier, synchronize, K steps, synchronize, barrier); per-repeat elapsed = MAX over ranks."""
+    out = []
+    mine = []
+    for _ in range(repeats):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(steps)
+        torch.cuda.synchronize()
+        local = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+            tm = torch.tensor([local], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            out.append(float(tm.item()))
+        else:
+            out.append(local)
+        mine.append(local)
+    return out, mine
+
+
+def kernel_report(prof, steps: int, traffic_file: str):
+    agg = {}
+    for tag, fl, s, e in prof:
+        a = agg.setdefault(tag, [0.0, 0.0, 0])
+        a[0] += s.elapsed_time(e)
+        a[1] += fl
+        a[2] += 1
+    mfma = {k: v for k, v in agg.items() if v[1] > 0}
+    dom = max(mfma, key=lambda k: mfma[k][0])
+    ms, fl, n = agg[dom]
+    ach = fl / (ms * 1e-3) / 1e12
+    traffic, src = None, None
+    if os.path.exists(traffic_file):
+        rec = json.load(open(traffic_file)).get(dom)
+        if rec:
+            traffic = rec.get("hbm_bytes_per_launch")
+            src = f"static profile {os.path.relpath(traffic_file, ROOT)} (separate rocprofv3 --pmc passes of this command; not re-measured in this run)"
+    roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS,
+            "traffic": traffic, "traffic_source": src, "launches": n, "avg_launch_ms": ms / n,
+            "algorithmic_gflop_per_launch": fl / n / 1e9,
+            "note": "kernel name as rocprofv3 prints it + the launch shape (GEMM MxNxK / attention problems x Nq x Nkv x dh); "
+                    "HIP events bracket every launch on the launch stream over a separate pass right after the timed "
+                    "one (inside the timed region they cost 12.6 % and would deflate `value`); traffic = (2*FETCH_SIZE "
+                    "+ WRITE_SIZE) KiB per launch (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md HBM section)"}
+    kernels = {k: {"ms_per_step": v[0] / steps, "launches_per_step": v[2] / steps,
+                   "tflops": (v[1] / (v[0] * 1e-3) / 1e12) if v[1] else None} for k, v in sorted(agg.items())}
+    return roof, kernels
 
 
 def main() -> None:
@@ -94,10 +168,15 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1, help="user samples per GPU (effective batch is 2x with CFG)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed repeats of K steps; the median is reported")
+    ap.add_argument("--config", default="ddim", choices=["ddim", "decode", "c4"])
+    ap.add_argument("--batch", type=int, default=None, help="user samples per GPU (default 1; c4: 8)")
     ap.add_argument("--n-prim", type=int, default=2048)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--reuse-cond-kv", action="store_true",
+                    help="opt-in exact algebra: compute the step-invariant cross-attention K/V once per sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline leg)")
     args = ap.parse_args()
 
@@ -119,100 +198,185 @@ def main() -> None:
     if world > 1:
         dist.barrier()
     import topia_xl_amd as pkg
-    from topia_xl_amd import ops
-    from topia_xl_amd.sharding import broadcast_module_
+    from topia_xl_amd import ops, pipeline
+    from topia_xl_amd.sharding import broadcast_module_, broadcast_packed_
 
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
-    with torch.device(dev):                                    # construct on the GPU: no 3.6 GB host init + H2D
-        model = pkg.DiT(**XL).eval()
-    if rank == 0:
-        random_init_(model, 42)
-    wbytes = broadcast_module_(model, 0)                      # RCCL broadcast, one flat buffer (N > 1)
-    B, N = args.batch, args.n_prim
-    gen = torch.Generator().manual_seed(42 + rank)
-    x = torch.randn(B, N, 68, generator=gen).to(dev)           # CPU draw then H2D, as inference.py:316
-    y = torch.randn(B, L_COND, 768, generator=gen).to(dev)
-    diffusion = pkg.create_diffusion("ddim25", noise_schedule="squaredcos_cap_v2", parameterization="v")
-    kw = dict(y=y, cfg_scale=6.0, precision_dtype=dt, enable_amp=True)
-    stream = step_stream(diffusion, model, x, kw)
+    B = args.batch if args.batch is not None else (8 if args.config == "c4" else 1)
+    N = args.n_prim
+    res = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f16" if dt == torch.float16 else "bf16"}
 
-    for _ in range(args.warmup):
-        next(stream)
+    # ------------------------------------------------------------------ models
+    model = vae = None
+    wbytes = 0
+    if args.config in ("ddim", "c4"):
+        with torch.device(dev):                                    # construct on the GPU: no 3.6 GB host init + H2D
+            model = pkg.DiT(**XL).eval()
+        if rank == 0:
+            load_synth_weights(model, 28)
+        model.reuse_cond_kv = bool(args.reuse_cond_kv)
+        wbytes = broadcast_packed_(model, dt, 0)                  # RCCL: the packed 16-bit blob (N > 1)
+    if args.config in ("decode", "c4"):
+        from oracle import synth
+        with torch.device(dev):
+            vae = pkg.VAE(**VAE_CFG).eval()
+        vae_sd = synth.state_dict_like(WEIGHT_SEED, {k: v.cpu() for k, v in vae.state_dict().items()})
+        if rank == 0:
+            vae.load_state_dict(vae_sd, strict=True)
+        wbytes += broadcast_module_(vae, 0)
+        vae.compute_dtype = dt
+
+    from oracle import synth
+    gen = torch.Generator().manual_seed(42 + rank)
+    if B == 1 and rank == 0 and N == 2048:
+        x = synth.tensor(WEIGHT_SEED, "xl_c2.x", (1, N, 68)).to(dev)          # the golden's inputs (parity leg)
+        y = synth.tensor(WEIGHT_SEED, "xl_c2.y", (1, L_COND, 768)).to(dev)
+    else:
+        x = torch.randn(B, N, 68, generator=gen).to(dev)           # CPU draw then H2D, as inference.py:316
+        y = torch.randn(B, L_COND, 768, generator=gen).to(dev)
+    mean = torch.linspace(-0.2, 0.2, 68).tolist()                  # stand-ins for configs/inference_dit.yml:64-65
+    std = torch.linspace(0.8, 1.2, 68).tolist()
+
+    # ------------------------------------------------------------------ the step
+    if args.config in ("ddim", "c4"):
+        diffusion = pkg.create_diffusion("ddim25" if args.config == "ddim" else "ddim100", noise_schedule="squaredcos_cap_v2",
+                                         parameterization="v")
+        kw = dict(y=y, cfg_scale=6.0, precision_dtype=dt, enable_amp=True)
+        stream = step_stream(diffusion, model, x, kw)
+        last = {}
+
+        def run_steps(k):
+            for _ in range(k):
+                last["out"] = next(stream)
+    else:
+        samples = x
+
+        def run_steps(k):
+            for _ in range(k):
+                last_dec["out"] = pipeline.latents_to_primitives(samples, vae, mean, std)
+        last_dec = {}
+
+    run_steps(args.warmup)
+    elapsed_all, mine = timed_repeats(run_steps, args.steps, max(1, args.repeats), world, dist, dev)
+    elapsed = statistics.median(elapsed_all)
+    if args.config in ("ddim", "c4"):
+        assert torch.isfinite(last["out"]["sample"]).all(), "non-finite sample"
+    else:
+        assert torch.isfinite(last_dec["out"]).all(), "non-finite decode"
+    per_rank = None
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = next(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    # Roofline leg: HIP events around every GEMM / attention launch (ops._timed, on the launch stream) over a SECOND pass of
-    # the same K steps, right after the timed one (same process, buffers and clocks).  Bracketing every launch inside the
-    # timed region itself was measured to cost 12.6 % (11.69 vs 10.21 ms/step at configs[1]: ~400 event packets per step,
-    # each a bubble between two dependent kernels), which would deflate `value`; kernel durations are unaffected.
-    prof, t_instr = None, None
+        t = torch.tensor([statistics.median(mine)], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allr, t)
+        ms = [1e3 * float(a.item()) / args.steps for a in allr]
+        per_rank = {"min": min(ms), "max": max(ms), "all": ms}
+
+    # Roofline leg: HIP events around every MFMA-kernel launch (ops._timed, on the launch stream) over a SEPARATE pass of the
+    # same K steps, right after the timed ones (same process, buffers and clocks).
+    prof = None
     if not args.no_kernel_events and rank == 0:
         ops.PROFILE = []
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            next(stream)
+        run_steps(args.steps)
         torch.cuda.synchronize()
-        t_instr = time.perf_counter() - t1
         prof, ops.PROFILE = ops.PROFILE, None
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    assert torch.isfinite(last["sample"]).all(), "non-finite sample"
+
+    # c4: the decode leg, timed separately (median of R)
+    decode_s = None
+    if args.config == "c4":
+        pipeline.latents_to_primitives(last["out"]["sample"], vae, mean, std)
+        dl = []
+        for _ in range(max(1, args.repeats)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rp = pipeline.latents_to_primitives(last["out"]["sample"], vae, mean, std)
+            torch.cuda.synchronize()
+            dl.append(time.perf_counter() - t0)
+        assert rp.shape == (B, N, 3076) and torch.isfinite(rp).all()
+        decode_s = statistics.median(dl)
 
     if rank == 0:
-        steps_per_s = world * B * args.steps / elapsed
-        flops_step = 2 * B * forward_flops(N, L_COND)
-        res = {
-            "metric": "DiT denoise-steps/sec (N_prim=2048) + samples/sec @25-step DDIM",
-            "value": steps_per_s, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16" if dt == torch.float16 else "bf16",
-            "data": "synthetic (randn latents + randn conditioning tokens, random-init weights, all layers non-zero)",
-            "config": {"workload": f"BASELINE configs[1]: DiT-XL d=1152 depth=28 heads=16x72, N_prim={N}, "
-                                   f"L_cond={L_COND}x768, CFG 6 (eff. batch {2 * B}/GPU), batch {B}/GPU, ddim25",
-                       "parallelism": f"batch-sharded replicas x{world}, no collective in the loop",
-                       "weight_broadcast_bytes": wbytes},
-            "samples_per_s_at_25_steps": steps_per_s / 25.0,
-            "algorithmic_tflops_per_step": flops_step / 1e12,
-            "achieved_tflops_whole_step": world * flops_step * args.steps / elapsed / 1e12,
-            "frac_of_mfma_peak_whole_step": flops_step * args.steps / elapsed / 1e12 / PEAK_TFLOPS,
-        }
+        ms_step = 1e3 * elapsed / args.steps
+        res.update({"ms_per_step": ms_step, "repeats": len(elapsed_all),
+                    "repeats_ms_per_step": [1e3 * e / args.steps for e in elapsed_all],
+                    "data": "synthetic (seeded normal latents + conditioning tokens, deterministic synthetic weights "
+                            "oracle/synth.py seed 4321, all layers non-zero)"})
+        if per_rank:
+            res["per_rank_ms_per_step"] = per_rank
+        par = f"batch-sharded replicas x{world}, no collective in the loop"
+        if args.config == "ddim":
+            steps_per_s = world * B * args.steps / elapsed
+            flops_step = 2 * B * forward_flops(N, L_COND)
+            res.update({
+                "metric": "DiT denoise-steps/sec (N_prim=2048) + samples/sec @25-step DDIM",
+                "value": steps_per_s, "unit": "denoise-steps/s",
+                "config": {"workload": f"BASELINE configs[1]: DiT-XL d=1152 depth=28 heads=16x72, N_prim={N}, "
+                                       f"L_cond={L_COND}x768, CFG 6 (eff. batch {2 * B}/GPU), batch {B}/GPU, ddim25",
+                           "parallelism": par, "weight_broadcast_bytes": wbytes, "reuse_cond_kv": bool(args.reuse_cond_kv)},
+                "samples_per_s_at_25_steps": steps_per_s / 25.0,
+                "algorithmic_tflops_per_step": flops_step / 1e12,
+                "achieved_tflops_whole_step": world * flops_step * args.steps / elapsed / 1e12,
+                "frac_of_mfma_peak_whole_step": flops_step * args.steps / elapsed / 1e12 / PEAK_TFLOPS})
+            if args.reuse_cond_kv:   # report against the UNREDUCED count, and the executed one next to it
+                ex = flops_step - B * kv_projection_flops(L_COND) * (1.0 - 1.0 / 25.0)
+                res["executed_tflops_per_step"] = ex / 1e12
+        elif args.config == "decode":
+            res.update({
+                "metric": "VAE decode samples/sec (2048 primitives per sample: latent de-normalise + vae3d_dib decode + inverse normalisation)",
+                "value": world * B * args.steps / elapsed, "unit": "samples/s",
+                "config": {"workload": f"second leg of BASELINE configs[3]: latents_to_primitives of {B} sample(s) x {N} "
+                                       f"primitives (1x4^3 -> 6x8^3), {args.dtype} MFMA inputs / fp32 accumulation",
+                           "parallelism": par, "weight_broadcast_bytes": wbytes},
+                "algorithmic_tflops_per_step": B * N * VAE_FLOPS_PER_PRIM / 1e12,
+                "achieved_tflops_whole_step": world * B * N * VAE_FLOPS_PER_PRIM * args.steps / elapsed / 1e12,
+                "frac_of_mfma_peak_whole_step": B * N * VAE_FLOPS_PER_PRIM * args.steps / elapsed / 1e12 / PEAK_TFLOPS})
+        else:
+            total = 100 * elapsed / args.steps + decode_s
+            res.update({
+                "metric": "samples/sec, 100-step DDIM + vae3d_dib decode (BASELINE configs[3])",
+                "value": world * B / total, "unit": "samples/s",
+                "config": {"workload": f"BASELINE configs[3]: DiT-XL N_prim={N}, batch {B}/GPU (eff. {2 * B}), 100 DDIM steps "
+                                       f"(K = {args.steps} steps timed, x100/K) + decode of {B} x {N} primitives (timed whole)",
+                           "parallelism": par, "weight_broadcast_bytes": wbytes, "reuse_cond_kv": bool(args.reuse_cond_kv)},
+                "ddim_ms_per_step": ms_step, "decode_ms": 1e3 * decode_s, "seconds_per_batch": total})
         if prof:
-            agg = {}
-            for tag, fl, s, e in prof:
-                a = agg.setdefault(tag, [0.0, 0.0, 0])
-                a[0] += s.elapsed_time(e)
-                a[1] += fl
-                a[2] += 1
-            dom = max(agg, key=lambda k: agg[k][0])
-            ms, fl, n = agg[dom]
-            ach = fl / (ms * 1e-3) / 1e12
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "r1_traffic.json")   # PMC pass (tools/pmc_traffic.py), per launch
-            if os.path.exists(tfile):
-                traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
-            res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS, "traffic": traffic,
-                               "launches": n, "avg_launch_ms": ms / n, "algorithmic_gflop_per_launch": fl / n / 1e9,
-                               "instrumented_ms_per_step": 1e3 * t_instr / args.steps,
-                               "note": "kernel name as printed by rocprofv3; HIP events bracket every launch on the launch "
-                                       "stream over a second pass of the same K steps right after the timed one (inside "
-                                       "the timed region they cost 12.6 % and would deflate `value`); traffic = "
-                                       "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch from separate --pmc passes "
-                                       "(gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md HBM section)"}
-            res["kernels"] = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[2] / args.steps,
-                                  "tflops": v[1] / (v[0] * 1e-3) / 1e12} for k, v in sorted(agg.items())}
+            tf = os.path.join(ROOT, "profiles", "r2_traffic.json")
+            res["roofline"], res["kernels"] = kernel_report(prof, args.steps, tf)
+
+        # ------------------------------------------------------------------ parity of the benchmarked model + CPU baseline
+        if world == 1 and args.config == "ddim" and not args.no_parity and N == 2048:
+            parity = {}
+            gfile = os.path.join(ROOT, "tests", "golden", "xl_c2.npz")
+            if os.path.exists(gfile) and B == 1:
+                import numpy as np
+                g = np.load(gfile)
+                stride = int(g["token_stride"])
+                tt = torch.as_tensor(g["t"]).to(dev)
+                out = model.forward_with_cfg(x, tt, y, 6.0, dt, True)
+                ref = torch.from_numpy(g["forward_cfg"])
+                got = out[:, ::stride].float().cpu()
+                parity["rel_l2_vs_reference_fp32_28_blocks"] = float((got - ref).norm() / ref.norm())
+                parity["reference"] = "tests/golden/xl_c2.npz: forward_with_cfg of the REAL reference (fp32, all 28 blocks) on these weights and inputs"
+            res["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(N)
+            if args.config == "ddim":
+                rec, ref, (sd14, xc, yc, tc, nb) = cpu_baseline_ddim(N)
+                res["cpu_baseline"] = rec
+                if not args.no_parity and N == 2048:
+                    with torch.device(dev):
+                        m14 = pkg.DiT(**{**XL, "depth": nb}).eval()
+                    m14.load_state_dict(sd14, strict=True)
+                    got = m14.forward_with_cfg(xc.to(dev), tc.to(dev), yc.to(dev), 6.0, dt, True).float().cpu()
+                    res.setdefault("parity", {}).update({
+                        "rel_l2_vs_fp32_oracle": float((got - ref).norm() / ref.norm()), "blocks": nb,
+                        "oracle": "the cpu_baseline leg's own fp32 forward (oracle/dit_ref.py) of the first 14 blocks + final layer"})
+                    del m14
+            elif args.config == "decode":
+                rec, ref, z = cpu_baseline_decode(vae_sd)
+                res["cpu_baseline"] = rec
+                got = vae.decode(z.to(dev)).float().cpu()
+                res["parity"] = {"max_abs_vs_fp32_oracle": float((got - ref).abs().max()), "primitives": int(z.shape[0]),
+                                 "ref_abs_max": float(ref.abs().max())}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

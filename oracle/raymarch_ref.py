@@ -1,9 +1,10 @@
 """TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): CPU restatement of the forward ray marcher.
 
-PARITY UNPINNED: the reference implementation is a CUDA extension (nvcc, sm_70, 32-lane warp intrinsics) that cannot be
-built or run here, and the reference ships no golden images.  This file restates the kernels' arithmetic from their
-sources; the only cross-check available is the reference's own torch loop in mvpraymarch.py:379-470, which defines the
-same accumulation rule.
+PARITY PINNED against the reference's own executable PyTorch statement of these kernels: tests/golden/raymarch.npz is
+produced by tests/golden/make_golden_raymarch.py, which RUNS the torch march loop of mvpraymarch.py:301-461 (seed 1112)
+and the torch ray-direction code of utils/utils.py:73-148 (seed 1113) unmodified; tests/test_raymarch.py checks this
+file against it (max-abs 1.1e-6 on the image, 1.2e-7 on directions).  The CUDA extension itself (nvcc, sm_70, 32-lane
+warp intrinsics) cannot be built or run here; this file restates the kernels' arithmetic from their sources:
 
   compute_raydirs      dva/mvp/extensions/utils/utils_kernel.cu:15-56
   convert_camera       dva/ray_marcher.py:22-30

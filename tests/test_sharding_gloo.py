@@ -49,6 +49,79 @@ def _worker(rank, world, port, batch, ret):
         dist.destroy_process_group()
 
 
+def _worker_packed(rank, world, port, batch, ret):
+    """Packed-blob broadcast (what the 16-bit path reads: ONE flat 16-bit buffer + the small fp32 tensors) and the
+    sharded decode: every rank decodes its own samples, only decoded primitives are gathered."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import topia_xl_amd as pkg
+        from topia_xl_amd.sharding import ShardedSampler
+        torch.manual_seed(200 + rank)
+        cfg = dict(seq_length=8, in_channels=4, condition_channels=8, hidden_size=64, depth=2, num_heads=2,
+                   cond_drop_prob=0.1, attn_proj_bias=True)
+        model = pkg.DiT(**cfg)
+        for p in model.parameters():                                    # no zero-initialised layers: a real digest
+            torch.nn.init.normal_(p, std=0.1)
+        model.repack()
+        ref_flat = model.packed(torch.float16)["_flat"].clone() if rank == 0 else None
+        model.repack()
+        d = pkg.create_diffusion("ddim5", noise_schedule="squaredcos_cap_v2", parameterization="v")
+        sampler = ShardedSampler(model, d, "cpu", packed_dtype=torch.float16)
+        pk = model.packed(torch.float16)                                # cached: the received blob on rank 1
+        n16 = pk["_flat"].numel()
+        small = sum(t.numel() for t in model.small_fp32_tensors())
+        assert sampler.weight_bytes == 2 * n16 + 4 * small
+        assert sampler.weight_bytes < 0.6 * 4 * sum(p.numel() for p in model.parameters())   # ~half of the fp32 broadcast
+        assert model._packed_only == (rank != 0)
+        # every operand view aliases the blob (no second copy), in blob order
+        assert pk["blocks"][1]["w_fc2"].data_ptr() >= pk["_flat"].data_ptr() and pk["w_final"].shape == (8, 64)
+        dig = torch.stack([pk["_flat"].double().sum(), torch.cat([t.reshape(-1) for t in model.small_fp32_tensors()]).double().sum()])
+        all_d = [torch.zeros(2, dtype=torch.double) for _ in range(world)]
+        dist.all_gather(all_d, dig)
+        assert all(torch.equal(all_d[0], x) for x in all_d), "packed weights differ after broadcast"
+        if rank == 0:
+            assert torch.equal(pk["_flat"], ref_flat)
+        else:
+            with pytest.raises(RuntimeError, match="packed"):
+                model.packed(torch.bfloat16)
+        cond = torch.arange(batch * 3 * 8, dtype=torch.float32).reshape(batch, 3, 8) if rank == 0 else None
+        calls = {}
+
+        def decode(samples):                                            # stand-in for latents_to_primitives
+            calls["n"] = samples.shape[0]
+            return torch.cat([samples, samples.sum(-1, keepdim=True)], dim=-1)
+
+        out = sampler.sample_and_decode(batch, 8, 4, cond, seed=7, decode=decode, loop=lambda x, y: x + y[:, :1, :4])
+        from topia_xl_amd.sharding import shard_bounds
+        lo, hi = shard_bounds(batch, world)[rank]
+        assert calls.get("n", 0) == hi - lo
+        if rank == 0:
+            noise = torch.randn(batch, 8, 4, generator=torch.Generator().manual_seed(7))
+            s = noise + cond[:, :1, :4]
+            assert out.shape == (batch, 8, 5) and torch.equal(out, torch.cat([s, s.sum(-1, keepdim=True)], dim=-1))
+            ret.put("ok")
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [3, 1])
+def test_two_rank_packed_broadcast_and_sharded_decode(batch):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 31500 + os.getpid() % 2000 + batch
+    procs = [ctx.Process(target=_worker_packed, args=(r, 2, port, batch, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) == "ok"
+
+
 @pytest.mark.parametrize("batch", [4, 5, 1])
 def test_two_rank_sharded_sampling(batch):
     ctx = mp.get_context("spawn")
