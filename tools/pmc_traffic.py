@@ -1,24 +1,51 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; csv output) of `bench.py` into per-kernel HBM traffic per
-launch.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes of wide coalesced reads ->
-doubled; both counters are in KiB.   usage: python tools/pmc_traffic.py <fetch_csv> <write_csv> <out.json>"""
+launch, keyed like bench.py's per-shape kernel tags ("<kernel name as rocprofv3 prints it> <shape>").  gfx950 correction
+(MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes of wide coalesced reads -> doubled; both counters are in KiB.
+
+    python tools/pmc_traffic.py <fetch_csv> <write_csv> <out.json> [ddim|decode]
+
+Kernels launched with several shapes are split by their position in the (fixed) launch sequence of one DiT block:
+gemm144_dma_kernel<dt, 1, 0> runs cproj, proj (K = 1152) and fc2 (K = 4608) in that order; attn_kernel alternates
+cross / self attention."""
 import collections, csv, json, re, sys
+
+CYCLES = {  # kernel name prefix -> shape tags in launch order within one block (BASELINE configs[1], fp16)
+    "gemm144_dma_kernel<1, 1, 0>": ["4096x1152x1152", "4096x1152x1152", "4096x1152x4608"],
+    "gemm144_dma_kernel<1, 2, 0>": ["4096x1152x1152"],
+    "gemm288q_dma_kernel<1, 0>": ["4096x4608x1152"],
+    "attn_kernel<1, 5, 3, 0, 0>": ["32x2048x1370x72", "32x2048x2048x72"],
+}
+
 
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
     return name.split("(")[0]
 
+
 def load(path, counter):
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter:
-            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    seen = collections.Counter()
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
+    for r in rows:
+        k = short(r["Kernel_Name"])
+        cyc = CYCLES.get(k)
+        if k.startswith("gemm288q_dma_kernel<1, 2>"):   # qkv per block + ONE batched K/V projection per forward: split by grid
+            tag = k + (" 3072x64512x768" if int(r.get("Grid_Size", 0)) > 512 * 400 else " 4096x3456x1152")
+        elif cyc:
+            tag = f"{k} {cyc[seen[k] % len(cyc)]}"
+            seen[k] += 1
+        else:
+            tag = k
+        acc[tag].append(float(r["Counter_Value"]))
     return acc
+
 
 f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 out = {}
 for k in sorted(set(f) | set(w)):
-    if not ("gemm" in k or "attn" in k or "ln_modulate" in k):
+    if not any(s in k for s in ("gemm", "attn", "ln_modulate", "gemv", "conv", "groupnorm")):
         continue
     fk = sum(f.get(k, [0])) / max(len(f.get(k, [])), 1)
     wk = sum(w.get(k, [0])) / max(len(w.get(k, [])), 1)
