@@ -25,6 +25,10 @@ HEADERS = ["common.h", os.path.join("..", "..", "include", "primx_hip.h")]
 LIB = os.path.join(HERE, "libprimx_hip.so")
 MANIFEST = os.path.join(HERE, "build_manifest.json")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# Per-file additions.  attention.hip: the one-wave-per-SIMD kernel (attn2_kernel) may use > 256 registers, for which hipcc
+# selects the accumulator-file form of EVERY MFMA and then pays a v_accvgpr_read for each VALU use of a score (144 per
+# tile, measured in the ISA); with the VGPR form as the default the allocator moves only what does not fit.
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -47,7 +51,7 @@ def source_hashes() -> dict:
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     out = {}
     for src in SOURCES:
-        out[src.replace(".hip", ".o")] = _sha([os.path.join(HERE, src)] + hdrs, " ".join(FLAGS))
+        out[src.replace(".hip", ".o")] = _sha([os.path.join(HERE, src)] + hdrs, " ".join(FLAGS + EXTRA_FLAGS.get(src, [])))
     out["lib"] = hashlib.sha256("".join(out[k] for k in sorted(out)).encode()).hexdigest()
     return out
 
@@ -75,7 +79,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(HERE, name)
         objs.append(o)
         if force or not os.path.exists(o) or have.get(name) != want[name]:
-            jobs.append((name, [_hipcc(), *FLAGS, "-c", os.path.join(HERE, src), "-o", o]))
+            jobs.append((name, [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(HERE, src), "-o", o]))
             names.append(name)
 
     def run(cmd):

@@ -275,8 +275,14 @@ def alloc_heads(B: int, H: int, n: int, dh: int, kind: int, dtype: torch.dtype, 
     if kind != HEADS_VT and DP > dh:
         if role == "q":
             buf[:, :, :, dh] = 1.0
-        elif role == "k" and n_pad > n:
-            buf[:, :, n:, dh] = KEY_MASK_VALUE
+        elif role == "k":
+            if n_pad > n:
+                buf[:, :, n:, dh] = KEY_MASK_VALUE
+            if DP - dh >= 3:
+                # two more constant columns: the one-wave-per-SIMD attention kernel keeps (-m_hi, -m_lo) - the running row
+                # max split into two 16-bit halves - in ITS register copy of Q's columns dh+1, dh+2, so that q.k comes out
+                # of the MFMA with the max already subtracted; Q holds zeros there in memory, so other readers see no change
+                buf[:, :, :, dh + 1:dh + 3] = 1.0
     if kind == HEADS_VT and DP > dh:
         # row dh of V^T = 1 for every valid key (at its quad-permuted position): the PV MFMA then accumulates
         # sum_k P[k, q] - the softmax denominator - in output row dh for free

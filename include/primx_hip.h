@@ -148,7 +148,10 @@ int primx_linear_heads(const void* A, const void* W, const void* bias, int M, in
  * keys, Vt[.., dh, pos(key)] = 1 for valid keys (the all-ones row: the PV MFMA accumulates the softmax
  * denominator in output row dh), every other pad entry of Qp/Kp/Vt zero - a padded key then scores -30000
  * through the MFMA itself and its probability underflows to exactly 0, with no mask or row-sum code in the
- * softmax (ops.alloc_heads does this).
+ * softmax (ops.alloc_heads does this).  When DP - dh >= 3 the caller additionally sets Kp[.., key, dh+1] =
+ * Kp[.., key, dh+2] = 1 for EVERY key row (Qp stays 0 there): the one-wave-per-SIMD kernel keeps the running row
+ * max, split into two 16-bit halves and negated, in its register copy of Q's columns dh+1 / dh+2, so the MFMA itself
+ * subtracts it (nq_pad % 256 == 0 selects that kernel; PRIMX_ATTN_V2=0 forces the 8-wave kernel).
  * Replaces xformers.ops.memory_efficient_attention(q, k, v) (attention.py:54,109). */
 int primx_attention(const void* Qp, const void* Kp, const void* Vt, void* out, int B, int H, int nq, int nq_pad,
                     int nkv, int nkv_pad, int dh, float scale, int dtype, void* stream);

@@ -59,6 +59,35 @@ def test_forced_rescale_spike(ops):
     assert rel_l2(got, ref) < TOL[torch.float16]
 
 
+def test_deferred_rescale_ramp(ops):
+    """The running max is only raised when a tile's max exceeds it by more than 2^8 (deferred rescale): a key ramp whose
+    scores grow by ~3 (exp2 domain) per 64-key tile keeps the kernel for two or three tiles on a stale max - probabilities
+    up to 2^8 - before each rescale; every query row sees the same ramp."""
+    B, N, H, dh = 1, 1024, 2, 72
+    q = synth.tensor(25, "q", (B, N, H, dh), 0.3).to(torch.float16)
+    k = synth.tensor(25, "k", (B, N, H, dh), 0.3).to(torch.float16)
+    v = synth.tensor(25, "v", (B, N, H, dh)).to(torch.float16)
+    q[..., 0] = 4.0                                               # q . k picks up 4 * k[..., 0]
+    ramp = (torch.arange(N) // 64).float() * 3.0 / (4.0 * dh ** -0.5 * 1.4427)   # +3 in the exp2 domain per tile
+    k[0, :, :, 0] = ramp[:, None].to(torch.float16)
+    ref = dit_ref.attention_core(q, k, v, dh ** -0.5)
+    got = ops.memory_efficient_attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    assert rel_l2(got, ref) < TOL[torch.float16], rel_l2(got, ref)
+
+
+def test_alternative_kernels_stay_correct():
+    """The experimental one-wave-per-SIMD kernel (PRIMX_ATTN_V2=2; correct, slower - csrc/attention.hip) runs the same
+    accuracy tests in a child process (the switch is read once at library load)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PRIMX_ATTN_V2="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k",
+                        "float64 or spike or ramp or strided or properties"], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_properties_at_full_size(ops):
     """N_prim = 2048, 16 heads x 72 (BASELINE config 2 shape), checked through properties that need
     no O(N^2) reference: (1) V = const -> output = const (softmax rows sum to 1); (2) linearity in V;

@@ -18,6 +18,11 @@ for name, B, H, nq, nkv, dh in [("self_b1", 2, 16, 2048, 2048, 72), ("cross_b1",
     for _ in range(3):
         ops.attention(Q, K, Vt, nq, nkv, dh, dh ** -0.5, out=out)
     torch.cuda.synchronize()
+    if B == 2:   # accuracy of this build: two heads against float64
+        qd, kd, vd = (t[0, :, :2].double().permute(1, 0, 2) for t in (q, k, v))
+        ref = (torch.softmax(qd @ kd.transpose(1, 2) * dh ** -0.5, -1) @ vd).permute(1, 0, 2)
+        got = out[0].view(nq, H, dh)[:, :2].double()
+        print(f"   max abs err vs float64 (2 heads): {float((got - ref).abs().max()):.3e}   rel-L2 {float((got - ref).norm() / ref.norm()):.3e}")
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(reps):
