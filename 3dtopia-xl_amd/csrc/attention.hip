@@ -58,11 +58,23 @@ constexpr int BKV = 64;     // keys per tile
 #define PRIMX_ATTN_PRIO 1   // 1: s_setprio 1 around every matrix segment (same-box: 58.1 vs 59.5 us); 2: static prio for group 1 (no gain); 0: off
 #endif
 constexpr int NSTAGE = PRIMX_ATTN_NSTAGE;   // LDS ring depth (3..6 fit one workgroup per CU)
+#ifndef PRIMX_ATTN_QKPV_MIX
+#define PRIMX_ATTN_QKPV_MIX 1   // 1 (with EXP0_IN_L): the first PV MFMAs are interleaved with the QK^T MFMAs
+#endif
+#ifndef PRIMX_ATTN_EXP0_IN_L
+#define PRIMX_ATTN_EXP0_IN_L 1   // 1: the exponentials of a tile's first 32 keys are formed in the light segment (needs MAX_IN_M or max in light before it)
+#endif
+#ifndef PRIMX_ATTN_DMA_IN_M
+#define PRIMX_ATTN_DMA_IN_M 1   // 1: the LDS-DMA of the next pair is issued in the MATRIX segment (behind the QK^T MFMAs) instead of the light one
+#endif
+#ifndef PRIMX_ATTN_MAX_IN_M
+#define PRIMX_ATTN_MAX_IN_M 0   // 1: the row max of the next tile's scores is taken at the end of the matrix segment instead of in the light one
+#endif
 #ifndef PRIMX_ATTN_REGSTAGE
 #define PRIMX_ATTN_REGSTAGE 0   // 1: K / V^T tiles staged through registers (global_load + ds_write) instead of LDS-DMA - measured neutral (54.1 vs 53.9 us)
 #endif
 #ifndef PRIMX_ATTN_QCOL
-#define PRIMX_ATTN_QCOL 0   // 1: running max subtracted by the MFMA through Q's spare columns (dh = 72), see attn_kernel - measured SLOWER (58 - 65 vs 54 us)
+#define PRIMX_ATTN_QCOL 1   // 1: running max subtracted by the MFMA through Q's spare columns (dh = 72), see attn_kernel (alone it unbalances the two segments: 58 - 65 vs 54 us; with DMA_IN_M + EXP0_IN_L + QKPV_MIX 49 us)
 #endif
 #ifndef PRIMX_ATTN_RTZ
 #define PRIMX_ATTN_RTZ 1   // 1: probabilities packed to 16 bits with round-toward-zero (full-rate v_cvt_pkrtz_f16_f32 / v_perm_b32; the
@@ -306,14 +318,20 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
 
     // ---- segments.  WAITB: every DMA older than the newest pair has landed (each wave waits for its OWN pieces), all
     // LDS reads of the segment are home, then the workgroup barrier publishes both.
-#define PRIMX_ATTN_WAITB()                                                                                         \
+#define PRIMX_ATTN_WAITB_N(NF)                                                                                     \
     do {                                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                     /* nothing of the next segment moves above ... */     \
-        __builtin_amdgcn_s_waitcnt((NFLY & 15) | 0x70 | ((NFLY >> 4) << 14)); /* vmcnt(NFLY) lgkmcnt(0) */         \
+        __builtin_amdgcn_s_waitcnt(((NF) & 15) | 0x70 | (((NF) >> 4) << 14)); /* vmcnt(NF) lgkmcnt(0) */           \
         asm volatile("s_barrier" ::: "memory");                                                                    \
         __builtin_amdgcn_sched_barrier(0);                     /* ... and nothing of this one sinks below */        \
     } while (0)
+#define PRIMX_ATTN_WAITB() PRIMX_ATTN_WAITB_N(NFLY)
     constexpr int NFLY = NSLOT * (NSTAGE - 2);   // DMAs of the pairs newer than the one the next light segment reads
+    // The barrier BEHIND a light segment.  DMA in the light segment: the pair the segment just issued may fly (NFLY).  DMA in
+    // the matrix segment (PRIMX_ATTN_DMA_IN_M): nothing was issued since the previous matrix segment, and what that one
+    // issued is read by the OTHER group's next light segment, which starts behind this very barrier - everything must
+    // have landed (a first build waited vmcnt(NFLY) here too: stale tiles, NaNs on some launches).
+    constexpr int NFLY_L = (PRIMX_ATTN_DMA_IN_M && !PRIMX_ATTN_REGSTAGE) ? 0 : NFLY;
     unsigned long long pt = 0, pl = 0, pm = 0, pw = 0, pn = 0, pl_dma = 0, pl_rd = 0;
     auto stamp = [&](unsigned long long& acc) {
         if (PROF) {
@@ -323,26 +341,8 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
         }
     };
     const bool idle = PROF == 2 && grp;   // profiling only: this wave keeps the barriers and does nothing else
-    // LIGHT segment of step j on stage `st` = {K(j+1), V(j)}: DMA of pair j+2 into `st_refill` (last read, by either
-    // group, before the barrier this segment started behind), fragment reads for QK^T(j+1) and the first half of PV(j),
-    // row max of S(j) and the (rare) rescale of O.
-    auto seg_light = [&](int st, int st_refill, int jp, f32x16 (&sc)[2], V8 (&kf)[2][KSTEPS], V8 (&vf0)[DTILES][2],
-                         V8 (&vf1)[DTILES][2], bool first) {
-        if (idle) return;
-#if PRIMX_ATTN_REGSTAGE
-        if (pend_stage >= 0) write_run(pend_stage);   // the pair fetched one step ago
-        gload_run(jp + 1 - grp);
-        pend_stage = st_refill;
-#else
-        issue_pair(jp, st_refill);
-#endif
-        if (PROF) { __builtin_amdgcn_sched_barrier(0); stamp(pl_dma); }
-        read_k(st, kf);
-        read_v(st, 0, vf0);
-#if PRIMX_ATTN_ALLREADS_L
-        read_v(st, 1, vf1);
-#endif
-        if (PROF) { __builtin_amdgcn_sched_barrier(0); stamp(pl_rd); }
+    [[maybe_unused]] V8 pb0_l[2];   // PRIMX_ATTN_EXP0_IN_L: probabilities of the first 32 keys, formed in the light segment
+    auto fold_max = [&](f32x16 (&sc)[2], bool first) {   // row max of a fresh score tile + the (rare) rescale
         float mx = fmaxf(sc[0][0], sc[1][0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sc[0][r]), sc[1][r]);   // 16 x v_max3_f32
@@ -385,12 +385,43 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
                 for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
         }
     };
+    // LIGHT segment of step j on stage `st` = {K(j+1), V(j)}: DMA of pair j+2 into `st_refill` (last read, by either
+    // group, before the barrier this segment started behind), fragment reads for QK^T(j+1) and the first half of PV(j),
+    // row max of S(j) and the (rare) rescale of O.
+    auto seg_light = [&](int st, int st_refill, int jp, f32x16 (&sc)[2], V8 (&kf)[2][KSTEPS], V8 (&vf0)[DTILES][2],
+                         V8 (&vf1)[DTILES][2], bool first) {
+        if (idle) return;
+#if PRIMX_ATTN_REGSTAGE
+        if (pend_stage >= 0) write_run(pend_stage);   // the pair fetched one step ago
+        gload_run(jp + 1 - grp);
+        pend_stage = st_refill;
+#elif !PRIMX_ATTN_DMA_IN_M
+        issue_pair(jp, st_refill);
+#endif
+        if (PROF) { __builtin_amdgcn_sched_barrier(0); stamp(pl_dma); }
+        read_k(st, kf);
+        read_v(st, 0, vf0);
+#if PRIMX_ATTN_ALLREADS_L
+        read_v(st, 1, vf1);
+#endif
+        if (PROF) { __builtin_amdgcn_sched_barrier(0); stamp(pl_rd); }
+#if !PRIMX_ATTN_MAX_IN_M
+        fold_max(sc, first);
+#endif
+#if PRIMX_ATTN_EXP0_IN_L
+        {   // the exponentials of the tile's first 32 keys here: the matrix segment is at its issue bound, this one is not
+            float psum0 = 0.f;
+            probs(sc[0], m_run * c, psum0, pb0_l);
+            if (KMASK) l_run += psum0;
+        }
+#endif
+    };
     // MATRIX segment of step j: QK^T(j+1) with the exponentials of the first 32 keys of tile j in its shadow, PV of
     // those keys with the exponentials of the other 32 in its shadow, PV of the rest.  All operands of the first 16
     // MFMAs are in registers on entry; the second V^T half is read under the QK^T MFMAs.
     // (Moving the first exponentials into the light segment was measured: the matrix segment did not get shorter.)
     auto seg_matrix = [&](int st, int t_next, const f32x16 (&sc)[2], f32x16 (&sn)[2], const V8 (&kf)[2][KSTEPS],
-                          const V8 (&vf0)[DTILES][2], V8 (&vf1)[DTILES][2]) {
+                          const V8 (&vf0)[DTILES][2], V8 (&vf1)[DTILES][2], int jp, int st_refill) {
         if (idle) return;
 #if PRIMX_ATTN_PRIO == 1
         __builtin_amdgcn_s_setprio(1);   // the matrix segment outranks its partner's light segment at the issue arbiter
@@ -401,14 +432,54 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
 #if !PRIMX_ATTN_ALLREADS_L
         read_v(st, 1, vf1);
 #endif
+#if PRIMX_ATTN_EXP0_IN_L && PRIMX_ATTN_QKPV_MIX
+        // P of the first 32 keys is ready on entry: its 6 PV MFMAs are woven into the 10 QK^T MFMAs, so that no MFMA depends on
+        // the one two slots before it (the two score chains alone sit exactly one MFMA latency apart: ~10 stall cycles each)
+        pb0[0] = pb0_l[0];
+        pb0[1] = pb0_l[1];
+        {
+            int pvi = 0;
+#pragma unroll
+            for (int s_ = 0; s_ < KSTEPS; ++s_) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) sn[kt] = T16<DT>::mfma32(kf[kt][s_], qf[s_], s_ == 0 ? zero16 : sn[kt]);
+                if (pvi < 2 * DTILES) { o[pvi % DTILES] = T16<DT>::mfma32(vf0[pvi % DTILES][pvi / DTILES], pb0[pvi / DTILES], o[pvi % DTILES]); ++pvi; }
+            }
+#pragma unroll
+            for (; pvi < 2 * DTILES; ++pvi) o[pvi % DTILES] = T16<DT>::mfma32(vf0[pvi % DTILES][pvi / DTILES], pb0[pvi / DTILES], o[pvi % DTILES]);
+            if (KMASK && (t_next + 1) * BKV > nkv) {   // same key mask as qk() (head dims without a spare padded column)
+                const int kbase = t_next * BKV + 4 * hi;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kbase + kt * 32 + (r & 3) + 8 * (r >> 2) >= nkv) sn[kt][r] = -1e30f;
+            }
+        }
+#if PRIMX_ATTN_DMA_IN_M && !PRIMX_ATTN_REGSTAGE
+        issue_pair(jp, st_refill);
+#endif
+#else
         qk(kf, t_next, sn);
+#if PRIMX_ATTN_DMA_IN_M && !PRIMX_ATTN_REGSTAGE
+        issue_pair(jp, st_refill);      // among the MFMAs (~60 issue cycles each there, 150 - 330 in the light segment)
+#endif
+#if PRIMX_ATTN_EXP0_IN_L
+        pb0[0] = pb0_l[0];
+        pb0[1] = pb0_l[1];
+#else
         probs(sc[0], mc, psum, pb0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         pv(vf0, pb0);
+#endif
         probs(sc[1], mc, psum, pb1);
         fence_lds();
         pv(vf1, pb1);
         if (KMASK) l_run += psum;
+#if PRIMX_ATTN_MAX_IN_M
+        fold_max(sn, false);            // max of the NEXT tile's scores here, in the shadow of the PV MFMAs just issued
+#endif
 #if PRIMX_ATTN_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -433,6 +504,9 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
         asm volatile("s_barrier" ::: "memory");   // group 0's L(0) refills this stage: everyone's K(0) reads are home first
         qk(kf0, 0, sA);                   // S(0)
     }
+#if PRIMX_ATTN_MAX_IN_M
+    fold_max(sA, true);
+#endif
 #if PRIMX_ATTN_PRIO == 2
     if (grp) __builtin_amdgcn_s_setprio(1);
 #endif
@@ -449,9 +523,9 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
         if (grp) { PRIMX_ATTN_WAITB(); stamp(pw); }
         seg_light(st, st_free, j + NSTAGE - 1, sA, kf, vf0, vf1, j == 0);
         stamp(pl);
-        PRIMX_ATTN_WAITB();
+        PRIMX_ATTN_WAITB_N(NFLY_L);
         stamp(pw);
-        seg_matrix(st, j + 1, sA, sB, kf, vf0, vf1);      // softmax + PV of tile j, QK^T of tile j+1
+        seg_matrix(st, j + 1, sA, sB, kf, vf0, vf1, j + NSTAGE - 1, st_free);      // softmax + PV of tile j, QK^T of tile j+1
         stamp(pm);
         if (!grp) { PRIMX_ATTN_WAITB(); stamp(pw); }
         st_free = st;
@@ -459,9 +533,9 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
         if (grp) { PRIMX_ATTN_WAITB(); stamp(pw); }
         seg_light(st, st_free, j + NSTAGE, sB, kf, vf0, vf1, false);
         stamp(pl);
-        PRIMX_ATTN_WAITB();
+        PRIMX_ATTN_WAITB_N(NFLY_L);
         stamp(pw);
-        seg_matrix(st, min(j + 2, ntiles - 1), sB, sA, kf, vf0, vf1);
+        seg_matrix(st, min(j + 2, ntiles - 1), sB, sA, kf, vf0, vf1, j + NSTAGE, st_free);
         stamp(pm);
         if (!grp) { PRIMX_ATTN_WAITB(); stamp(pw); }
         st_free = st;
@@ -471,12 +545,13 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     if (j < ntiles) {                     // odd tile count (the DMAs are clamped and redundant: uniform vmcnt bookkeeping)
         if (grp) PRIMX_ATTN_WAITB();
         seg_light(st, st_free, j + NSTAGE - 1, sA, kf, vf0, vf1, j == 0);
-        PRIMX_ATTN_WAITB();
-        seg_matrix(st, ntiles - 1, sA, sB, kf, vf0, vf1);
+        PRIMX_ATTN_WAITB_N(NFLY_L);
+        seg_matrix(st, ntiles - 1, sA, sB, kf, vf0, vf1, j + NSTAGE - 1, st_free);
         if (!grp) PRIMX_ATTN_WAITB();
     }
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): drain the clamped tail DMAs before the workgroup retires
 #undef PRIMX_ATTN_WAITB
+#undef PRIMX_ATTN_WAITB_N
     if (PROF && lane == 0 && !idle) {
         atomicAdd(&g_attn_prof[0], pl); atomicAdd(&g_attn_prof[1], pm); atomicAdd(&g_attn_prof[2], pw);
         atomicAdd(&g_attn_prof[3], pn); atomicAdd(&g_attn_prof[4], pl_dma); atomicAdd(&g_attn_prof[5], pl_rd);
