@@ -43,7 +43,7 @@ def test_groupnorm_silu(pkg, dtype, C, S, groups, silu):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("Cin,Cout,S,P", [(256, 256, 4, 5), (256, 32, 8, 2), (32, 32, 8, 3), (32, 6, 8, 3)])
+@pytest.mark.parametrize("Cin,Cout,S,P", [(256, 256, 4, 5), (256, 512, 4, 4), (256, 32, 8, 2), (32, 32, 8, 3), (32, 6, 8, 3)])
 def test_conv3d_k3_and_residual(pkg, dtype, Cin, Cout, S, P):
     from topia_xl_amd import ops
     from topia_xl_amd.vae import _conv_weight_as_gemm
