@@ -1727,22 +1727,12 @@ extern "C" int primx_linear_heads(const void* A, const void* W, const void* bias
     return PRIMX_OK;
 }
 
-// conv3.hip: register-resident 4^3 x 256-channel convolution (PRIMX_CONV_REG=0 falls back to the implicit GEMM for A/B runs)
-int primx_conv3_s4c256_launch(const void* in, const void* Wk, const void* bias, const void* res, float res_scale, void* out,
-                              int P, int Cout, int Kpad, int dtype, hipStream_t stream);
-static const bool g_conv_reg = [] {
-    const char* e = getenv("PRIMX_CONV_REG");
-    return !(e && e[0] == '0');
-}();
-
 extern "C" int primx_conv3d_k3(const void* in, const void* Wk, const void* bias, const void* res, float res_scale,
                                void* out, int P, int S, int Cin, int Cout, int Kpad, int dtype, void* stream) {
     PRIMX_REQUIRE(in && Wk && out, "primx_conv3d_k3: null pointer");
     const int cl = ilog2_exact(Cin);
     PRIMX_REQUIRE(P > 0 && S > 0 && Cout > 0 && cl >= 3, "primx_conv3d_k3: Cin must be a power of two >= 8 (Cin=%d)", Cin);
     PRIMX_REQUIRE(Kpad >= 27 * Cin && Kpad % BK == 0, "primx_conv3d_k3: Kpad must be a multiple of 64 >= 27*Cin");
-    if (g_conv_reg && S == 4 && Cin == 256 && Cout % 256 == 0 && Kpad == 27 * 256)
-        return primx_conv3_s4c256_launch(in, Wk, bias, res, res_scale, out, P, Cout, Kpad, dtype, (hipStream_t)stream);
     PRIMX_DISPATCH_16(dtype, "primx_conv3d_k3", {
         using Sx = typename T16<DT>::S;
         GemmArgs<DT> a = {};

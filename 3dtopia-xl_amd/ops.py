@@ -373,15 +373,34 @@ def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
     return out
 
 
+def pack_conv3_s4(Wk: torch.Tensor, Cin: int) -> Optional[torch.Tensor]:
+    """The 4^3-stage weight image of csrc/conv3.hip for a [Cout, 27*Cin] conv3d_k3 weight, or None when the shape is not
+    the register-resident kernel's (Cin == 256, Cout % 256 == 0) or PRIMX_CONV_REG=0 asks for the implicit GEMM (A/B runs)."""
+    if Cin != 256 or Wk.shape[0] % 256 != 0 or Wk.shape[1] != 27 * 256 or not Wk.is_cuda or os.environ.get("PRIMX_CONV_REG", "1") == "0":
+        return None
+    Wp = torch.empty_like(Wk)
+    with torch.cuda.device(Wk.device):
+        check(_lib.load().primx_conv3d_s4_pack(_dev(Wk, "Wk"), Wp.data_ptr(), Wk.shape[0], dtype_code(Wk.dtype), _stream()),
+              "primx_conv3d_s4_pack")
+    return Wp
+
+
 def conv3d_k3(x: torch.Tensor, Wk: torch.Tensor, bias: Optional[torch.Tensor], S: int,
-              res: Optional[torch.Tensor] = None, res_scale: float = 1.0) -> torch.Tensor:
-    """x: [P, S^3, Cin]; Wk: [Cout, Kpad] 16-bit (k = tap*Cin + ci); optional fused (conv + res) * res_scale."""
+              res: Optional[torch.Tensor] = None, res_scale: float = 1.0, Wp: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x: [P, S^3, Cin]; Wk: [Cout, Kpad] 16-bit (k = tap*Cin + ci); optional fused (conv + res) * res_scale.
+    Wp (pack_conv3_s4(Wk)) selects the register-resident kernel when the grid is 4^3."""
     P, V, Cin = x.shape
     Cout, Kpad = Wk.shape
     out = torch.empty(P, V, Cout, dtype=x.dtype, device=x.device)
+    bias_p = _dev(bias, "bias", x.dtype) if bias is not None else None
+    res_p = _dev(res, "res", x.dtype) if res is not None else None
+    if Wp is not None and S == 4 and Cin == 256:
+        _timed(f"conv3d_k3 {Cin}->{Cout} @{S}^3 x{P}", 2.0 * P * V * Cout * 27 * Cin, lambda: check(_lib.load().primx_conv3d_s4_packed(
+            _dev(x, "x"), _dev(Wp, "Wp", x.dtype), bias_p, res_p, res_scale, out.data_ptr(), P, Cout, dtype_code(x.dtype), _stream()),
+            "primx_conv3d_s4_packed"))
+        return out
     _timed(f"conv3d_k3 {Cin}->{Cout} @{S}^3 x{P}", 2.0 * P * V * Cout * 27 * Cin, lambda: check(_lib.load().primx_conv3d_k3(
-        _dev(x, "x"), _dev(Wk, "Wk", x.dtype), _dev(bias, "bias", x.dtype) if bias is not None else None,
-        _dev(res, "res", x.dtype) if res is not None else None, res_scale, out.data_ptr(), P, S, Cin, Cout, Kpad,
+        _dev(x, "x"), _dev(Wk, "Wk", x.dtype), bias_p, res_p, res_scale, out.data_ptr(), P, S, Cin, Cout, Kpad,
         dtype_code(x.dtype), _stream()), "primx_conv3d_k3"))
     return out
 

@@ -181,6 +181,9 @@ class VAE(nn.Module):
              "g2": f32(blk.norm2.weight), "b2": f32(blk.norm2.bias), "groups2": blk.norm2.num_groups,
              "eps2": blk.norm2.eps, "w2": _conv_weight_as_gemm(blk.conv2.weight.detach(), dt), "c2": c16(blk.conv2.bias),
              "wsc": None, "csc": None}
+        # weight images of the register-resident 4^3 kernel (None for other shapes; used only when the grid is 4^3)
+        d["w1p"] = ops.pack_conv3_s4(d["w1"], blk.conv1.in_channels)
+        d["w2p"] = ops.pack_conv3_s4(d["w2"], blk.conv2.in_channels)
         if isinstance(blk.shortcut, nn.Conv3d):
             d["wsc"] = c16(blk.shortcut.weight.reshape(blk.out_channels, blk.in_channels))
             d["csc"] = c16(blk.shortcut.bias)
@@ -234,12 +237,12 @@ class VAE(nn.Module):
     def _resnet(self, h: torch.Tensor, w: Dict, S: int) -> torch.Tensor:
         P, V, Cin = h.shape
         t = ops.groupnorm_silu(h, w["g1"], w["b1"], w["groups1"], w["eps1"], True)
-        t = ops.conv3d_k3(t, w["w1"], w["c1"], S)
+        t = ops.conv3d_k3(t, w["w1"], w["c1"], S, Wp=w["w1p"])
         t = ops.groupnorm_silu(t, w["g2"], w["b2"], w["groups2"], w["eps2"], True)
         res = h
         if w["wsc"] is not None:
             res = ops.linear_residual(h.view(P * V, Cin), w["wsc"], w["csc"], None, 1.0).view(P, V, -1)
-        return ops.conv3d_k3(t, w["w2"], w["c2"], S, res=res, res_scale=self.skip_scale)
+        return ops.conv3d_k3(t, w["w2"], w["c2"], S, res=res, res_scale=self.skip_scale, Wp=w["w2p"])
 
     def _attention(self, h: torch.Tensor, w: Dict) -> torch.Tensor:
         P, V, Cc = h.shape

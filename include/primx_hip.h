@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 13
+#define PRIMX_ABI_VERSION 14
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -202,6 +202,16 @@ int primx_groupnorm_silu(const void* in, const float* gamma, const float* beta, 
  * ConvTranspose3d(k=3, s=1, p=1) (vae3d_dib.py:367,385). */
 int primx_conv3d_k3(const void* in, const void* Wk, const void* bias, const void* res, float res_scale,
                     void* out, int P, int S, int Cin, int Cout, int Kpad, int dtype, void* stream);
+
+/* The same convolution for the decoder's 4^3 stage (S = 4, Cin = 256, Cout a multiple of 256: the eight ResnetBlock
+ * convolutions of mid_block and up_blocks[0], vae3d_dib.py:62-75 / 251-261) with the activations held in registers as
+ * MFMA operand fragments and the taps formed by fragment selection + DPP row shifts (csrc/conv3.hip).  The weight is
+ * pre-packed ONCE by primx_conv3d_s4_pack from the [Cout, 27*256] layout of primx_conv3d_k3 (Kpad == 6912) into the
+ * LDS images of the kernel's [256 cout][64 k] tiles (same size: Cout * 6912 elements; Wp must not alias Wk).
+ * Same result formula and rounding as primx_conv3d_k3. */
+int primx_conv3d_s4_pack(const void* Wk, void* Wp, int Cout, int dtype, void* stream);
+int primx_conv3d_s4_packed(const void* in, const void* Wp, const void* bias, const void* res, float res_scale, void* out,
+                           int P, int Cout, int dtype, void* stream);
 
 /* out[M, N] (16-bit) = ((A W^T + bias) + res) * scale with no intermediate rounding; res may be NULL.
  * The 1x1 shortcut conv (vae3d_dib.py:124-125) and VolumeAttention's proj + `(x + res) * skip_scale`
