@@ -373,33 +373,54 @@ def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
     return out
 
 
-def pack_conv3_s4(Wk: torch.Tensor, Cin: int) -> Optional[torch.Tensor]:
-    """The 4^3-stage weight image of csrc/conv3.hip for a [Cout, 27*Cin] conv3d_k3 weight, or None when the shape is not
-    the register-resident kernel's (Cin == 256, Cout % 256 == 0) or PRIMX_CONV_REG=0 asks for the implicit GEMM (A/B runs)."""
-    if Cin != 256 or Wk.shape[0] % 256 != 0 or Wk.shape[1] != 27 * 256 or not Wk.is_cuda or os.environ.get("PRIMX_CONV_REG", "1") == "0":
+class PackedConv3:
+    """Weight image of one of the activation-resident 3x3x3 kernels: kind "s4" (csrc/conv3.hip: 4^3 grid, Cin 256, Cout %
+    256 == 0) or "s8" (csrc/conv3s8.hip: 8^3 grid, Cin 256, Cout 32)."""
+    __slots__ = ("kind", "S", "Cin", "Cout", "Wp")
+
+    def __init__(self, kind: str, S: int, Cin: int, Cout: int, Wp: torch.Tensor):
+        self.kind, self.S, self.Cin, self.Cout, self.Wp = kind, S, Cin, Cout, Wp
+
+
+def pack_conv3(Wk: torch.Tensor, Cin: int) -> Optional[PackedConv3]:
+    """PackedConv3 for a [Cout, 27*Cin] conv3d_k3 weight whose shape one of the activation-resident kernels covers, else
+    None (also with PRIMX_CONV_REG=0, which keeps the implicit GEMM for A/B runs).  The grid edge the image is for is part
+    of the result; conv3d_k3 only uses it on that grid."""
+    if Cin != 256 or Wk.shape[1] != 27 * 256 or not Wk.is_cuda or os.environ.get("PRIMX_CONV_REG", "1") == "0":
+        return None
+    Cout = Wk.shape[0]
+    if Cout % 256 != 0 and Cout != 32:
         return None
     Wp = torch.empty_like(Wk)
     with torch.cuda.device(Wk.device):
-        check(_lib.load().primx_conv3d_s4_pack(_dev(Wk, "Wk"), Wp.data_ptr(), Wk.shape[0], dtype_code(Wk.dtype), _stream()),
-              "primx_conv3d_s4_pack")
-    return Wp
+        if Cout == 32:
+            check(_lib.load().primx_conv3d_s8_pack(_dev(Wk, "Wk"), Wp.data_ptr(), dtype_code(Wk.dtype), _stream()), "primx_conv3d_s8_pack")
+            return PackedConv3("s8", 8, Cin, Cout, Wp)
+        check(_lib.load().primx_conv3d_s4_pack(_dev(Wk, "Wk"), Wp.data_ptr(), Cout, dtype_code(Wk.dtype), _stream()), "primx_conv3d_s4_pack")
+        return PackedConv3("s4", 4, Cin, Cout, Wp)
 
 
 def conv3d_k3(x: torch.Tensor, Wk: torch.Tensor, bias: Optional[torch.Tensor], S: int,
-              res: Optional[torch.Tensor] = None, res_scale: float = 1.0, Wp: Optional[torch.Tensor] = None) -> torch.Tensor:
+              res: Optional[torch.Tensor] = None, res_scale: float = 1.0, Wp: Optional[PackedConv3] = None) -> torch.Tensor:
     """x: [P, S^3, Cin]; Wk: [Cout, Kpad] 16-bit (k = tap*Cin + ci); optional fused (conv + res) * res_scale.
-    Wp (pack_conv3_s4(Wk)) selects the register-resident kernel when the grid is 4^3."""
+    Wp (pack_conv3(Wk)) selects the activation-resident kernel when the grid is the one it was packed for."""
     P, V, Cin = x.shape
     Cout, Kpad = Wk.shape
     out = torch.empty(P, V, Cout, dtype=x.dtype, device=x.device)
     bias_p = _dev(bias, "bias", x.dtype) if bias is not None else None
     res_p = _dev(res, "res", x.dtype) if res is not None else None
-    if Wp is not None and S == 4 and Cin == 256:
-        _timed(f"conv3d_k3 {Cin}->{Cout} @{S}^3 x{P}", 2.0 * P * V * Cout * 27 * Cin, lambda: check(_lib.load().primx_conv3d_s4_packed(
-            _dev(x, "x"), _dev(Wp, "Wp", x.dtype), bias_p, res_p, res_scale, out.data_ptr(), P, Cout, dtype_code(x.dtype), _stream()),
-            "primx_conv3d_s4_packed"))
+    tag, flops = f"conv3d_k3 {Cin}->{Cout} @{S}^3 x{P}", 2.0 * P * V * Cout * 27 * Cin
+    if Wp is not None and Wp.S == S and Wp.Cin == Cin and Wp.Cout == Cout:
+        if Wp.kind == "s4":
+            _timed(tag, flops, lambda: check(_lib.load().primx_conv3d_s4_packed(
+                _dev(x, "x"), _dev(Wp.Wp, "Wp", x.dtype), bias_p, res_p, res_scale, out.data_ptr(), P, Cout, dtype_code(x.dtype),
+                _stream()), "primx_conv3d_s4_packed"))
+        else:
+            _timed(tag, flops, lambda: check(_lib.load().primx_conv3d_s8_packed(
+                _dev(x, "x"), _dev(Wp.Wp, "Wp", x.dtype), bias_p, res_p, res_scale, out.data_ptr(), P, dtype_code(x.dtype),
+                _stream()), "primx_conv3d_s8_packed"))
         return out
-    _timed(f"conv3d_k3 {Cin}->{Cout} @{S}^3 x{P}", 2.0 * P * V * Cout * 27 * Cin, lambda: check(_lib.load().primx_conv3d_k3(
+    _timed(tag, flops, lambda: check(_lib.load().primx_conv3d_k3(
         _dev(x, "x"), _dev(Wk, "Wk", x.dtype), bias_p, res_p, res_scale, out.data_ptr(), P, S, Cin, Cout, Kpad,
         dtype_code(x.dtype), _stream()), "primx_conv3d_k3"))
     return out

@@ -181,9 +181,9 @@ class VAE(nn.Module):
              "g2": f32(blk.norm2.weight), "b2": f32(blk.norm2.bias), "groups2": blk.norm2.num_groups,
              "eps2": blk.norm2.eps, "w2": _conv_weight_as_gemm(blk.conv2.weight.detach(), dt), "c2": c16(blk.conv2.bias),
              "wsc": None, "csc": None}
-        # weight images of the register-resident 4^3 kernel (None for other shapes; used only when the grid is 4^3)
-        d["w1p"] = ops.pack_conv3_s4(d["w1"], blk.conv1.in_channels)
-        d["w2p"] = ops.pack_conv3_s4(d["w2"], blk.conv2.in_channels)
+        # weight images of the activation-resident kernels (None for other shapes; each is used only on the grid it is for)
+        d["w1p"] = ops.pack_conv3(d["w1"], blk.conv1.in_channels)
+        d["w2p"] = ops.pack_conv3(d["w2"], blk.conv2.in_channels)
         if isinstance(blk.shortcut, nn.Conv3d):
             d["wsc"] = c16(blk.shortcut.weight.reshape(blk.out_channels, blk.in_channels))
             d["csc"] = c16(blk.shortcut.bias)

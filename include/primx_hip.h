@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 14
+#define PRIMX_ABI_VERSION 15
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -212,6 +212,15 @@ int primx_conv3d_k3(const void* in, const void* Wk, const void* bias, const void
 int primx_conv3d_s4_pack(const void* Wk, void* Wp, int Cout, int dtype, void* stream);
 int primx_conv3d_s4_packed(const void* in, const void* Wp, const void* bias, const void* res, float res_scale, void* out,
                            int P, int Cout, int dtype, void* stream);
+
+/* The same convolution for S = 8, Cin = 256, Cout = 32 (conv1 of up_blocks[1].nets[0], vae3d_dib.py:62-75 / 262-270):
+ * one workgroup per primitive, each wave keeps one input z-plane in registers and scatters every tap's product into an
+ * fp32 image of the output in LDS (csrc/conv3s8.hip).  primx_conv3d_s8_pack re-lays the [32, 6912] weight of
+ * primx_conv3d_k3 into the kernel's LDS tile images (same size; Wp must not alias Wk).  Same result formula as
+ * primx_conv3d_k3; the fp32 summation order differs (per tap over all channels, then over taps). */
+int primx_conv3d_s8_pack(const void* Wk, void* Wp, int dtype, void* stream);
+int primx_conv3d_s8_packed(const void* in, const void* Wp, const void* bias, const void* res, float res_scale, void* out,
+                           int P, int dtype, void* stream);
 
 /* out[M, N] (16-bit) = ((A W^T + bias) + res) * scale with no intermediate rounding; res may be NULL.
  * The 1x1 shortcut conv (vae3d_dib.py:124-125) and VolumeAttention's proj + `(x + res) * skip_scale`

@@ -58,11 +58,11 @@ def test_conv3d_k3_and_residual(pkg, dtype, Cin, Cout, S, P):
     assert rel_l2(_cf(got, S), ref) < tol, rel_l2(_cf(got, S), ref)
     got = ops.conv3d_k3(_cl(x).to(DEV), wk, b.to(DEV), S, res=_cl(res).to(DEV), res_scale=0.5 ** 0.5)
     assert rel_l2(_cf(got, S), (ref + res.double()) * 0.5 ** 0.5) < tol
-    wp = ops.pack_conv3_s4(wk, Cin)
-    assert (wp is not None) == (S == 4 and Cin == 256 and Cout % 256 == 0)
-    if wp is not None:
-        # the register-resident 4^3 kernel: same sums in a different order - against fp64, and within accumulation-order
-        # noise of the implicit GEMM (both round the fp32 result once)
+    wp = ops.pack_conv3(wk, Cin)
+    assert (wp is not None) == (Cin == 256 and (Cout % 256 == 0 or Cout == 32))
+    if wp is not None and wp.S == S:
+        # the activation-resident kernels (4^3: csrc/conv3.hip, 8^3: csrc/conv3s8.hip): same sums in a different order -
+        # against fp64, and within accumulation-order noise of the implicit GEMM (both round the fp32 result once)
         got_p = ops.conv3d_k3(_cl(x).to(DEV), wk, b.to(DEV), S, res=_cl(res).to(DEV), res_scale=0.5 ** 0.5, Wp=wp)
         assert rel_l2(_cf(got_p, S), (ref + res.double()) * 0.5 ** 0.5) < tol
         assert rel_l2(got_p, got) < (2e-4 if dtype == torch.float16 else 2e-3), rel_l2(got_p, got)
