@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512) void conv3_s8c256n32_kernel(const typename T16
         // write of one 16-byte chunk per (cg, ni) - this wave is the only writer of the target plane in this phase - under the
         // lane's validity (exec mask).  (ds_add_f32 measured ~166 cycles per wave-instruction: LDS float atomics are
         // serialised per lane; the kernel took 4.5 ms with them.)
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);   // the read-modify-writes stay behind the tap's MFMAs
         const int xo = x - dx;
         const bool xok = (unsigned)xo < 8u;
 #pragma unroll
@@ -140,6 +140,9 @@ __global__ __launch_bounds__(512) void conv3_s8c256n32_kernel(const typename T16
             }
         }
     };
+    // NOT unrolled / peeled: with hipcc's default (it peels the first three taps and specialises the loop by phase) the
+    // contributions of steps 1..5 were lost on the GPU (tools/probe/conv_s8_taps.py: one nonzero tap at a time) although
+    // the peeled ISA reads correctly; the rolled loop is also a third of the code.
 #pragma clang loop unroll(disable)
     for (int t = 0; t < 27; ++t) tap_step(t);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
