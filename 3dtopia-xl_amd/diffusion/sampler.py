@@ -150,6 +150,10 @@ class GaussianDiffusion(DiffusionTables):
         want = (B, nt, C * 2) if learned else (B, nt, C)
         if tuple(model_output.shape) != want:
             raise AssertionError(f"model output shape {tuple(model_output.shape)} != {want}")
+        # eta == 0: the reference still draws `th.randn_like(x)` every DDIM step and multiplies it by sigma = 0
+        # (gaussian_diffusion.py:569-579).  The sample is identical without the draw; what differs is the process-global
+        # RNG position afterwards, so a LATER seeded draw in the same process (the next sample's initial noise when no
+        # generator is passed) does not replay a reference run.  Callers that need that pass explicit noise / a generator.
         need_noise = (kind == "ancestral") or (eta != 0.0)
         noise = torch.randn_like(x) if need_noise else None
         sample, pred_xstart = ops.diffusion_step(

@@ -6,8 +6,10 @@ unit of sharding is the user sample and the DDIM loop itself needs NO collective
 
     once   : broadcast(weights)   - ONE flat buffer per dtype (the reference has 515 tensors; a single
              large broadcast is link-efficient on point-to-point xGMI, 515 small ones are latency-bound)
-             scatter(noise), scatter(conditioning)   (rank 0 draws the whole batch's noise from the one
-             seeded CPU generator, preserving the reference's seed semantics - inference.py:251,316)
+             scatter(noise), scatter(conditioning)   (rank 0 draws the whole batch's INITIAL noise from one seeded CPU
+             generator, so a seed gives the same starting latents for any world size - the role of the seeded
+             `torch.randn` of inference.py:251,316.  It is not a replay of the reference process's global RNG stream:
+             the reference also draws an unused noise tensor per DDIM step at eta = 0, see diffusion/sampler.py)
     loop   : per-rank ``ddim_sample_loop`` on its slice            (zero collectives)
     end    : gather(samples) to rank 0
 
