@@ -247,16 +247,20 @@ __global__ __launch_bounds__(512) void conv3_s4c256_kernel(const typename T16<DT
     const int rr = lane >> 4, cc = lane & 15;          // row-major walk: row 4 i + rr, channels 8 cc .. + 8
     const int nb = cb * 256 + wn * 128 + 8 * cc;
     // (two straight-line variants, all 16 residual loads first: with the loads inside the row loop hipcc waited vmcnt(0)
-    // per row, which on gfx9 also waits for the previous row's STORE - sixteen serialized store round trips per wave)
+    // per row, which on gfx9 also waits for the previous row's STORE - sixteen serialized store round trips per wave.
+    // No buffering of the converted rows: that version spilled 30 VGPRs per lane = 31 MB of scratch writes per launch,
+    // visible as WRITE_SIZE 110 MB against 67 MB of output)
     auto epilogue = [&](auto has_res_c) {
         constexpr bool HAS_RES = decltype(has_res_c)::value;
         const int64_t off0 = ((int64_t)prim * VOX + rr) * Cout + nb;
-        V8 rq[8];
-        auto load_res = [&](int p2) {
+        // all 16 residual rows first (64 registers, the accumulators' 128 are still live; fragments and weights are dead)
+        V8 rq[2][8];
+        if constexpr (HAS_RES) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) rq[i] = *reinterpret_cast<const V8*>(res + off0 + (int64_t)(p2 * 32 + 4 * i) * Cout);
-        };
-        if constexpr (HAS_RES) load_res(0);
+            for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rq[p2][i] = *reinterpret_cast<const V8*>(res + off0 + (int64_t)(p2 * 32 + 4 * i) * Cout);
+        }
         V8 bv = V8{};
         if (bias) bv = *reinterpret_cast<const V8*>(bias + nb);
 #pragma unroll
@@ -268,27 +272,19 @@ __global__ __launch_bounds__(512) void conv3_s4c256_kernel(const typename T16<DT
                     const int row = m2 * 16 + lr, chunk = (lg * 8 + ni) ^ (row & 7);
                     *reinterpret_cast<f32x4*>(stg + row * 128 + chunk * 4) = acc[2 * p2 + m2][ni];
                 }
-            V8 o[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int row = 4 * i + rr;
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * 128 + ((2 * cc) ^ (row & 7)) * 4);
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * 128 + ((2 * cc + 1) ^ (row & 7)) * 4);
+                V8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float y = (e < 4 ? v0[e] : v1[e - 4]) + (float)bv[e];
-                    if constexpr (HAS_RES) y += (float)rq[i][e];
-                    o[i][e] = (S)(y * res_scale);
+                    if constexpr (HAS_RES) y += (float)rq[p2][i][e];
+                    o[e] = (S)(y * res_scale);
                 }
-            }
-            // the second half's residual rows are requested BEFORE the first half's stores: vmcnt is in order, loads behind
-            // stores would wait for the stores' round trip
-            if constexpr (HAS_RES) {
-                if (p2 == 0) load_res(1);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                *reinterpret_cast<V8*>(out + off0 + (int64_t)(p2 * 32 + 4 * i) * Cout) = o[i];
+                *reinterpret_cast<V8*>(out + off0 + (int64_t)(p2 * 32 + 4 * i) * Cout) = o;
             }
         }
     };

@@ -271,7 +271,10 @@ def alloc_heads(B: int, H: int, n: int, dh: int, kind: int, dtype: torch.dtype, 
     DP = padded_head_dim(dh)
     n_pad = round_up(n, pad_to)
     shape = {HEADS_ROWS: (B, H, n_pad, DP), HEADS_KROWS: (B, H, n_pad, DP + 8), HEADS_VT: (B, H, DP, n_pad)}[kind]
-    buf = torch.zeros(shape, dtype=dtype, device=device)
+    # (no pad rows and no pad columns - the VAE's 64-token, 32-wide heads: every element is written by the projection
+    # epilogue, so the 67 MB zero fill per operand is skipped; the KROWS layout always has its 8 pad columns per row)
+    exact = DP == dh and n_pad == n and kind != HEADS_KROWS
+    buf = torch.empty(shape, dtype=dtype, device=device) if exact else torch.zeros(shape, dtype=dtype, device=device)
     if kind != HEADS_VT and DP > dh:
         if role == "q":
             buf[:, :, :, dh] = 1.0
@@ -411,11 +414,14 @@ def conv3d_k3(x: torch.Tensor, Wk: torch.Tensor, bias: Optional[torch.Tensor], S
     res_p = _dev(res, "res", x.dtype) if res is not None else None
     tag, flops = f"conv3d_k3 {Cin}->{Cout} @{S}^3 x{P}", 2.0 * P * V * Cout * 27 * Cin
     if Wp is not None and Wp.S == S and Wp.Cin == Cin and Wp.Cout == Cout:
+        # (tags of the activation-resident kernels: the kernel name as rocprofv3 prints it + the shape, like the GEMMs')
         if Wp.kind == "s4":
+            tag = f"conv3_s4c256_kernel<{dtype_code(x.dtype)}, 0> {Cin}->{Cout} @{S}^3 x{P}"
             _timed(tag, flops, lambda: check(_lib.load().primx_conv3d_s4_packed(
                 _dev(x, "x"), _dev(Wp.Wp, "Wp", x.dtype), bias_p, res_p, res_scale, out.data_ptr(), P, Cout, dtype_code(x.dtype),
                 _stream()), "primx_conv3d_s4_packed"))
         else:
+            tag = f"conv3_s8c256n32_kernel<{dtype_code(x.dtype)}> {Cin}->{Cout} @{S}^3 x{P}"
             _timed(tag, flops, lambda: check(_lib.load().primx_conv3d_s8_packed(
                 _dev(x, "x"), _dev(Wp.Wp, "Wp", x.dtype), bias_p, res_p, res_scale, out.data_ptr(), P, dtype_code(x.dtype),
                 _stream()), "primx_conv3d_s8_packed"))

@@ -1,13 +1,18 @@
 #!/bin/bash
-# round-end artefacts: GPU tests + smoke + default bench, kernel trace of the bench command, PMC traffic passes
-mkdir -p gpurun_out/final
+# round-end artefacts: GPU tests + smoke + benches (default ddim, decode, c4), kernel traces of the bench commands, PMC traffic passes
+OUT=gpurun_out/final
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/final/gpu_tests.log 2>&1; echo "pytest exit $?" >> gpurun_out/final/gpu_tests.log; tail -2 gpurun_out/final/gpu_tests.log
+timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $OUT/gpu_tests.log 2>&1; echo "pytest exit $?" >> $OUT/gpu_tests.log; tail -2 $OUT/gpu_tests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu | tail -2
-timeout 900 python bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err; echo "bench exit $?"; cat gpurun_out/final/bench_default.json
-timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/final -o trace -- python bench.py --no-cpu-baseline --steps 25 > gpurun_out/final/bench_trace.json 2> gpurun_out/final/bench_trace.err
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/final -o fetch -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 --no-kernel-events > /dev/null 2> gpurun_out/final/fetch.err
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/final -o write -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 --no-kernel-events > /dev/null 2> gpurun_out/final/write.err
-for db in gpurun_out/final/*.db; do python tools/rocprof_summary.py $db gpurun_out/final/kernel_trace_summary.txt; done
-tail -22 gpurun_out/final/kernel_trace_summary.txt | cut -c1-200
-ls -la gpurun_out/final | head -30
+timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench exit $?"; cat $OUT/bench_default.json | cut -c1-600
+timeout 600 python bench.py --config decode > $OUT/bench_decode.json 2> $OUT/bench_decode.err; echo "decode exit $?"
+timeout 900 python bench.py --config c4 --no-cpu-baseline > $OUT/bench_c4.json 2> $OUT/bench_c4.err; echo "c4 exit $?"
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python bench.py --no-cpu-baseline --no-parity --steps 25 > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o trace_decode -- python bench.py --config decode --no-cpu-baseline --no-parity > $OUT/bench_trace_decode.json 2> $OUT/bench_trace_decode.err
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- python bench.py --no-cpu-baseline --no-parity --steps 3 --warmup 1 --repeats 1 --no-kernel-events > /dev/null 2> $OUT/fetch.err
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- python bench.py --no-cpu-baseline --no-parity --steps 3 --warmup 1 --repeats 1 --no-kernel-events > /dev/null 2> $OUT/write.err
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch_decode -- python bench.py --config decode --no-cpu-baseline --no-parity --steps 2 --warmup 1 --repeats 1 --no-kernel-events > /dev/null 2> $OUT/fetch_decode.err
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o write_decode -- python bench.py --config decode --no-cpu-baseline --no-parity --steps 2 --warmup 1 --repeats 1 --no-kernel-events > /dev/null 2> $OUT/write_decode.err
+for db in $OUT/*.db; do python tools/rocprof_summary.py $db ${db%.db}_summary.txt; done
+ls -la $OUT | head -40

@@ -23,7 +23,7 @@ def main():
         print(f"{n:7d} {s/1e3:12.1f} {a/1e3:10.2f} {mn/1e3:9.2f} {mx/1e3:9.2f} {100*s/tot:6.2f}  {short(name)}", file=out)
     print("\n# per (kernel, grid) breakdown of the primx kernels", file=out)
     rows = db.execute("select name, grid_x, grid_y, count(*), avg(duration), vgpr_count, accum_vgpr_count, lds_size from kernels "
-                      "where name like '%gemm_kernel%' or name like '%attn_kernel%' group by name, grid_x, grid_y "
+                      "where name like '%gemm%' or name like '%attn_kernel%' or name like '%conv%' or name like '%groupnorm%' group by name, grid_x, grid_y "
                       "order by sum(duration) desc").fetchall()
     print(f"{'calls':>7} {'avg_us':>10} {'grid':>14} {'vgpr':>5} {'agpr':>5} {'lds':>7}  kernel", file=out)
     for name, gx, gy, n, a, vg, ag, lds in rows:
