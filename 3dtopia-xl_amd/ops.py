@@ -378,7 +378,8 @@ def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
 
 class PackedConv3:
     """Weight image of one of the activation-resident 3x3x3 kernels: kind "s4" (csrc/conv3.hip: 4^3 grid, Cin 256, Cout %
-    256 == 0) or "s8" (csrc/conv3s8.hip: 8^3 grid, Cin 256, Cout 32)."""
+    256 == 0), "s8" (csrc/conv3s8.hip: 8^3 grid, Cin 256, Cout 32) or "s8c32" (csrc/conv3s8c32.hip: 8^3 grid, Cin 32, Cout 32
+    or <= 16; the only one that can take the preceding GroupNorm + SiLU into the kernel)."""
     __slots__ = ("kind", "S", "Cin", "Cout", "Wp")
 
     def __init__(self, kind: str, S: int, Cin: int, Cout: int, Wp: torch.Tensor):
@@ -389,9 +390,18 @@ def pack_conv3(Wk: torch.Tensor, Cin: int) -> Optional[PackedConv3]:
     """PackedConv3 for a [Cout, 27*Cin] conv3d_k3 weight whose shape one of the activation-resident kernels covers, else
     None (also with PRIMX_CONV_REG=0, which keeps the implicit GEMM for A/B runs).  The grid edge the image is for is part
     of the result; conv3d_k3 only uses it on that grid."""
-    if Cin != 256 or Wk.shape[1] != 27 * 256 or not Wk.is_cuda or os.environ.get("PRIMX_CONV_REG", "1") == "0":
+    if not Wk.is_cuda or os.environ.get("PRIMX_CONV_REG", "1") == "0":
         return None
     Cout = Wk.shape[0]
+    if Cin == 32 and Wk.shape[1] >= 864 and (Cout == 32 or Cout <= 16):
+        NI = 2 if Cout == 32 else 1
+        Wp = torch.empty(27 * NI * 16 * 32, dtype=Wk.dtype, device=Wk.device)
+        with torch.cuda.device(Wk.device):
+            check(_lib.load().primx_conv3d_s8c32_pack(_dev(Wk, "Wk"), Wp.data_ptr(), Cout, Wk.shape[1], dtype_code(Wk.dtype), _stream()),
+                  "primx_conv3d_s8c32_pack")
+        return PackedConv3("s8c32", 8, Cin, Cout, Wp)
+    if Cin != 256 or Wk.shape[1] != 27 * 256:
+        return None
     if Cout % 256 != 0 and Cout != 32:
         return None
     Wp = torch.empty_like(Wk)
@@ -403,16 +413,34 @@ def pack_conv3(Wk: torch.Tensor, Cin: int) -> Optional[PackedConv3]:
         return PackedConv3("s4", 4, Cin, Cout, Wp)
 
 
+def conv3_takes_groupnorm(Wp: Optional[PackedConv3], S: int, groups: int) -> bool:
+    """True when conv3d_k3(..., Wp=Wp, gn=...) can apply the preceding GroupNorm(groups) + SiLU inside the kernel."""
+    return Wp is not None and Wp.kind == "s8c32" and Wp.S == S and groups == Wp.Cin
+
+
 def conv3d_k3(x: torch.Tensor, Wk: torch.Tensor, bias: Optional[torch.Tensor], S: int,
-              res: Optional[torch.Tensor] = None, res_scale: float = 1.0, Wp: Optional[PackedConv3] = None) -> torch.Tensor:
+              res: Optional[torch.Tensor] = None, res_scale: float = 1.0, Wp: Optional[PackedConv3] = None,
+              gn: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None) -> torch.Tensor:
     """x: [P, S^3, Cin]; Wk: [Cout, Kpad] 16-bit (k = tap*Cin + ci); optional fused (conv + res) * res_scale.
-    Wp (pack_conv3(Wk)) selects the activation-resident kernel when the grid is the one it was packed for."""
+    Wp (pack_conv3(Wk)) selects the activation-resident kernel when the grid is the one it was packed for.
+    gn = (gamma, beta, eps): the input is silu(group_norm(x)) with one channel per group, computed inside the kernel - only
+    where conv3_takes_groupnorm(Wp, S, groups) holds."""
     P, V, Cin = x.shape
     Cout, Kpad = Wk.shape
     out = torch.empty(P, V, Cout, dtype=x.dtype, device=x.device)
     bias_p = _dev(bias, "bias", x.dtype) if bias is not None else None
     res_p = _dev(res, "res", x.dtype) if res is not None else None
     tag, flops = f"conv3d_k3 {Cin}->{Cout} @{S}^3 x{P}", 2.0 * P * V * Cout * 27 * Cin
+    if gn is not None and not conv3_takes_groupnorm(Wp, S, Cin):
+        raise ValueError("conv3d_k3: gn= needs the 8^3 / 32-channel kernel (pack_conv3) and one channel per group")
+    if Wp is not None and Wp.S == S and Wp.Cin == Cin and Wp.Cout == Cout and Wp.kind == "s8c32":
+        tag = f"conv3_s8c32_kernel<{dtype_code(x.dtype)}, {2 if Cout == 32 else 1}> {'gn+' if gn else ''}{Cin}->{Cout} @{S}^3 x{P}"
+        g_p = _dev(gn[0], "gamma", torch.float32) if gn else None
+        b_p = _dev(gn[1], "beta", torch.float32) if gn else None
+        _timed(tag, flops, lambda: check(_lib.load().primx_conv3d_s8c32_packed(
+            _dev(x, "x"), _dev(Wp.Wp, "Wp", x.dtype), bias_p, g_p, b_p, float(gn[2]) if gn else 0.0, res_p, res_scale, out.data_ptr(),
+            P, Cout, dtype_code(x.dtype), _stream()), "primx_conv3d_s8c32_packed"))
+        return out
     if Wp is not None and Wp.S == S and Wp.Cin == Cin and Wp.Cout == Cout:
         # (tags of the activation-resident kernels: the kernel name as rocprofv3 prints it + the shape, like the GEMMs')
         if Wp.kind == "s4":

@@ -212,6 +212,7 @@ class VAE(nn.Module):
                 "w_out": _conv_weight_as_gemm(dec.conv_out.weight.detach().flip(2, 3, 4).permute(1, 0, 2, 3, 4), dt),
                 "c_out": c16(dec.conv_out.bias),
             }
+            pk["w_outp"] = ops.pack_conv3(pk["w_out"], dec.conv_out.in_channels)
             for a in dec.mid_block.attns:
                 if a is None:
                     pk["attn"].append(None)
@@ -236,12 +237,19 @@ class VAE(nn.Module):
     # ------------------------------------------------------------------ decode
     def _resnet(self, h: torch.Tensor, w: Dict, S: int) -> torch.Tensor:
         P, V, Cin = h.shape
-        t = ops.groupnorm_silu(h, w["g1"], w["b1"], w["groups1"], w["eps1"], True)
-        t = ops.conv3d_k3(t, w["w1"], w["c1"], S, Wp=w["w1p"])
-        t = ops.groupnorm_silu(t, w["g2"], w["b2"], w["groups2"], w["eps2"], True)
+        # GroupNorm + SiLU goes into the convolution kernel where that kernel holds the whole primitive (8^3 x 32 channels)
+        if ops.conv3_takes_groupnorm(w["w1p"], S, w["groups1"]):
+            t = ops.conv3d_k3(h, w["w1"], w["c1"], S, Wp=w["w1p"], gn=(w["g1"], w["b1"], w["eps1"]))
+        else:
+            t = ops.groupnorm_silu(h, w["g1"], w["b1"], w["groups1"], w["eps1"], True)
+            t = ops.conv3d_k3(t, w["w1"], w["c1"], S, Wp=w["w1p"])
         res = h
         if w["wsc"] is not None:
             res = ops.linear_residual(h.view(P * V, Cin), w["wsc"], w["csc"], None, 1.0).view(P, V, -1)
+        if ops.conv3_takes_groupnorm(w["w2p"], S, w["groups2"]):
+            return ops.conv3d_k3(t, w["w2"], w["c2"], S, res=res, res_scale=self.skip_scale, Wp=w["w2p"],
+                                 gn=(w["g2"], w["b2"], w["eps2"]))
+        t = ops.groupnorm_silu(t, w["g2"], w["b2"], w["groups2"], w["eps2"], True)
         return ops.conv3d_k3(t, w["w2"], w["c2"], S, res=res, res_scale=self.skip_scale, Wp=w["w2p"])
 
     def _attention(self, h: torch.Tensor, w: Dict) -> torch.Tensor:
@@ -288,8 +296,11 @@ class VAE(nn.Module):
                 if u["w_up"] is not None:
                     h = ops.convtranspose_k2s2(h, u["w_up"], u["c_up"], S)
                     S *= 2
-            h = ops.groupnorm_silu(h, pk["g_out"], pk["b_out"], pk["groups_out"], pk["eps_out"], True)
-            h = ops.conv3d_k3(h, pk["w_out"], pk["c_out"], S)
+            if ops.conv3_takes_groupnorm(pk["w_outp"], S, pk["groups_out"]):
+                h = ops.conv3d_k3(h, pk["w_out"], pk["c_out"], S, Wp=pk["w_outp"], gn=(pk["g_out"], pk["b_out"], pk["eps_out"]))
+            else:
+                h = ops.groupnorm_silu(h, pk["g_out"], pk["b_out"], pk["groups_out"], pk["eps_out"], True)
+                h = ops.conv3d_k3(h, pk["w_out"], pk["c_out"], S)
             out = ops.vae_output(h, denormalize)
         return out.view(P, -1, S, S, S)
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 15
+#define PRIMX_ABI_VERSION 16
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -221,6 +221,18 @@ int primx_conv3d_s4_packed(const void* in, const void* Wp, const void* bias, con
 int primx_conv3d_s8_pack(const void* Wk, void* Wp, int dtype, void* stream);
 int primx_conv3d_s8_packed(const void* in, const void* Wp, const void* bias, const void* res, float res_scale, void* out,
                            int P, int dtype, void* stream);
+
+/* The same convolution for S = 8, Cin = 32, Cout = 32 or <= 16, optionally with the preceding GroupNorm (ONE channel per
+ * group: per-(primitive, channel) statistics over the 512 voxels) + SiLU applied to the input inside the kernel
+ * (gamma/beta fp32 [32], both NULL = plain convolution of `in`): conv2 of up_blocks[1].nets[0], conv1/conv2 of nets[1] and
+ * norm_out + conv_out (vae3d_dib.py:62-75, 262-270, 366-367, 383-385).  The primitive's activations live in LDS as a
+ * zero-haloed volume next to the whole weight (csrc/conv3s8c32.hip).  primx_conv3d_s8c32_pack re-lays the [Cout, Kpad]
+ * weight of primx_conv3d_k3 (Kpad >= 864) into the kernel's image: 27 * 32 * 32 elements for Cout = 32, 27 * 16 * 32
+ * for Cout <= 16.  out = ((conv(silu(gn(in))) + bias) + res) * res_scale, one rounding; the normalised activations are
+ * rounded to 16 bits before the convolution exactly as primx_groupnorm_silu rounds them. */
+int primx_conv3d_s8c32_pack(const void* Wk, void* Wp, int Cout, int Kpad, int dtype, void* stream);
+int primx_conv3d_s8c32_packed(const void* in, const void* Wp, const void* bias, const float* gamma, const float* beta, float eps,
+                              const void* res, float res_scale, void* out, int P, int Cout, int dtype, void* stream);
 
 /* out[M, N] (16-bit) = ((A W^T + bias) + res) * scale with no intermediate rounding; res may be NULL.
  * The 1x1 shortcut conv (vae3d_dib.py:124-125) and VolumeAttention's proj + `(x + res) * skip_scale`

@@ -59,15 +59,44 @@ def test_conv3d_k3_and_residual(pkg, dtype, Cin, Cout, S, P):
     got = ops.conv3d_k3(_cl(x).to(DEV), wk, b.to(DEV), S, res=_cl(res).to(DEV), res_scale=0.5 ** 0.5)
     assert rel_l2(_cf(got, S), (ref + res.double()) * 0.5 ** 0.5) < tol
     wp = ops.pack_conv3(wk, Cin)
-    assert (wp is not None) == (Cin == 256 and (Cout % 256 == 0 or Cout == 32))
+    assert (wp is not None) == ((Cin == 256 and (Cout % 256 == 0 or Cout == 32)) or (Cin == 32 and (Cout == 32 or Cout <= 16)))
     if wp is not None and wp.S == S:
-        # the activation-resident kernels (4^3: csrc/conv3.hip, 8^3: csrc/conv3s8.hip): same sums in a different order -
+        # the activation-resident kernels (4^3: csrc/conv3.hip, 8^3: csrc/conv3s8.hip, conv3s8c32.hip): same sums in a different order -
         # against fp64, and within accumulation-order noise of the implicit GEMM (both round the fp32 result once)
         got_p = ops.conv3d_k3(_cl(x).to(DEV), wk, b.to(DEV), S, res=_cl(res).to(DEV), res_scale=0.5 ** 0.5, Wp=wp)
         assert rel_l2(_cf(got_p, S), (ref + res.double()) * 0.5 ** 0.5) < tol
         assert rel_l2(got_p, got) < (2e-4 if dtype == torch.float16 else 2e-3), rel_l2(got_p, got)
         got_p = ops.conv3d_k3(_cl(x).to(DEV), wk, None, S, Wp=wp)
         assert rel_l2(_cf(got_p, S), ref - b.double().view(1, -1, 1, 1, 1)) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Cout,P", [(32, 3), (6, 2), (32, 300)])
+def test_conv3d_with_groupnorm_silu_inside(pkg, dtype, Cout, P):
+    """csrc/conv3s8c32.hip: GroupNorm(32 groups of one channel) + SiLU applied inside the 8^3 convolution kernel ==
+    groupnorm_silu followed by the convolution (the normalised activations are rounded to 16 bits in both), and both
+    against fp64.  P = 300 makes the persistent workgroups walk more than one primitive."""
+    from topia_xl_amd import ops
+    from topia_xl_amd.vae import _conv_weight_as_gemm
+    S, Cin = 8, 32
+    x = synth.tensor(35, "cg.x", (P, Cin, S, S, S), 1.4, 0.3).to(dtype)
+    w = synth.tensor(35, "cg.w", (Cout, Cin, 3, 3, 3), (27 * Cin) ** -0.5).to(dtype)
+    b = synth.tensor(35, "cg.b", (Cout,), 0.2).to(dtype)
+    g, be = synth.tensor(35, "cg.g", (Cin,), 0.2, 1.0), synth.tensor(35, "cg.be", (Cin,), 0.2)
+    res = synth.tensor(35, "cg.r", (P, Cout, S, S, S)).to(dtype)
+    wk = _conv_weight_as_gemm(w, dtype).to(DEV)
+    wp = ops.pack_conv3(wk, Cin)
+    assert ops.conv3_takes_groupnorm(wp, S, 32) and not ops.conv3_takes_groupnorm(wp, S, 8)
+    xd = _cl(x).to(DEV)
+    n16 = ops.groupnorm_silu(xd, g.to(DEV), be.to(DEV), 32, 1e-5, True)
+    two = ops.conv3d_k3(n16, wk, b.to(DEV), S, res=_cl(res).to(DEV), res_scale=0.5 ** 0.5)          # implicit GEMM on the 16-bit GN output
+    got = ops.conv3d_k3(xd, wk, b.to(DEV), S, res=_cl(res).to(DEV), res_scale=0.5 ** 0.5, Wp=wp, gn=(g.to(DEV), be.to(DEV), 1e-5))
+    assert rel_l2(got, two) < (3e-4 if dtype == torch.float16 else 3e-3), rel_l2(got, two)
+    ref = F.conv3d(F.silu(F.group_norm(x.double(), 32, g.double(), be.double(), 1e-5)), w.double(), b.double(), padding=1)
+    ref = (ref + res.double()) * 0.5 ** 0.5
+    assert rel_l2(_cf(got, S), ref) < (1.5e-3 if dtype == torch.float16 else 1.2e-2)
+    with pytest.raises(ValueError):
+        ops.conv3d_k3(xd, wk, b.to(DEV), S, gn=(g.to(DEV), be.to(DEV), 1e-5))                        # gn needs the packed kernel
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
