@@ -15,7 +15,7 @@ P = int(os.environ.get("P", 2048))
 REPS = int(os.environ.get("REPS", 10))
 x = torch.randn(P, 64, 256, device="cuda", dtype=torch.float16)
 w = torch.randn(256, 6912, device="cuda", dtype=torch.float16) * 0.012
-wp = ops.pack_conv3_s4(w, 256)
+wp = ops.pack_conv3(w, 256)
 b = torch.zeros(256, device="cuda", dtype=torch.float16)
 for _ in range(3):
     ops.conv3d_k3(x, w, b, 4, Wp=wp)
