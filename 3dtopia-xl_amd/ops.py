@@ -485,16 +485,53 @@ def conv_in(z: torch.Tensor, pq_scale: float, pq_bias: float, W: torch.Tensor, b
     return out
 
 
-def convtranspose_k2s2(x: torch.Tensor, Wt: torch.Tensor, bias: torch.Tensor, S: int) -> torch.Tensor:
-    """x: [P, S^3, Cin]; Wt: [8*Cout, Cin] 16-bit (row = tap*Cout + co) -> [P, (2S)^3, Cout]."""
+def pack_convt_s4(Wt: torch.Tensor) -> Optional[torch.Tensor]:
+    """Weight image of csrc/convt.hip for the [8*256, 256] k2s2 weight, or None for other shapes / PRIMX_CONV_REG=0."""
+    if tuple(Wt.shape) != (8 * 256, 256) or not Wt.is_cuda or os.environ.get("PRIMX_CONV_REG", "1") == "0":
+        return None
+    Wp = torch.empty_like(Wt)
+    with torch.cuda.device(Wt.device):
+        check(_lib.load().primx_convtranspose_s4_pack(_dev(Wt, "Wt"), Wp.data_ptr(), dtype_code(Wt.dtype), _stream()),
+              "primx_convtranspose_s4_pack")
+    return Wp
+
+
+def convtranspose_k2s2(x: torch.Tensor, Wt: torch.Tensor, bias: torch.Tensor, S: int, Wp: Optional[torch.Tensor] = None,
+                       want_stats: bool = False):
+    """x: [P, S^3, Cin]; Wt: [8*Cout, Cin] 16-bit (row = tap*Cout + co) -> [P, (2S)^3, Cout].
+    With Wp (pack_convt_s4(Wt)) and S == 4 the weight-stationary kernel runs; with want_stats as well the result is
+    (out, part): part [P, 16, 32, 2] fp32 = partial shifted sums per group of 8 output channels (include/primx_hip.h);
+    group_stats(part, bias, eps) turns them into mean / rstd."""
     P, V, Cin = x.shape
     Cout = Wt.shape[0] // 8
     out = torch.empty(P, 8 * V, Cout, dtype=x.dtype, device=x.device)
+    if Wp is not None and S == 4 and Cin == 256 and Cout == 256:
+        part = torch.empty(P, 16, 32, 2, dtype=torch.float32, device=x.device) if want_stats else None
+        _timed(f"convt_s4c256_kernel<{dtype_code(x.dtype)}> {Cin}->{Cout} @{S}^3 x{P}", 2.0 * P * V * 8 * Cout * Cin, lambda: check(
+            _lib.load().primx_convtranspose_s4_packed(_dev(x, "x"), _dev(Wp, "Wp", x.dtype), _dev(bias, "bias", x.dtype), out.data_ptr(),
+                                                      part.data_ptr() if part is not None else None, P, dtype_code(x.dtype),
+                                                      _stream()), "primx_convtranspose_s4_packed"))
+        return (out, part) if want_stats else out
+    if want_stats:
+        raise ValueError("convtranspose_k2s2: statistics come only from the packed 4^3 kernel (pack_convt_s4)")
     _timed(f"convtranspose_k2s2 {Cin}->{Cout} @{S}^3 x{P}", 2.0 * P * V * 8 * Cout * Cin, lambda: check(
         _lib.load().primx_convtranspose_k2s2(_dev(x, "x"), _dev(Wt, "Wt", x.dtype), _dev(bias, "bias", x.dtype),
                                              out.data_ptr(), P, S, Cin, Cout, dtype_code(x.dtype), _stream()),
         "primx_convtranspose_k2s2"))
     return out
+
+
+def group_stats(part: torch.Tensor, bias: torch.Tensor, eps: float, count: int = 4096) -> torch.Tensor:
+    """[P, 16, 32, 2] partial shifted sums of convtranspose_k2s2(..., want_stats=True) -> [P, 32, 2] (mean, rstd), in the
+    arithmetic of the consuming kernel (fp32, partials added in index order).  Host-side helper for tests and callers that
+    want the statistics themselves; the fused convolution does this sum in its prologue."""
+    acc = torch.zeros_like(part[:, 0])
+    for i in range(part.shape[1]):
+        acc = acc + part[:, i]
+    shift = bias.float()[0::8].view(1, 32)
+    m = acc[..., 0] / count
+    var = (acc[..., 1] / count - m * m).clamp_min(0.0)
+    return torch.stack([shift + m, torch.rsqrt(var + eps)], dim=-1)
 
 
 def vae_output(x: torch.Tensor, denorm: bool, sdf_div: float = 5.0) -> torch.Tensor:

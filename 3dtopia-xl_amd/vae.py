@@ -225,11 +225,12 @@ class VAE(nn.Module):
                     "heads": a.attn.num_heads, "residual": a.residual,
                 })
             for ub in dec.up_blocks:
-                u = {"nets": [self._res_pack(n, dt) for n in ub.nets], "w_up": None, "c_up": None}
+                u = {"nets": [self._res_pack(n, dt) for n in ub.nets], "w_up": None, "c_up": None, "w_upp": None}
                 if ub.upsample is not None:
                     w = ub.upsample.weight.detach()  # [Cin, Cout, 2, 2, 2]
                     u["w_up"] = c16(w.permute(2, 3, 4, 1, 0).reshape(8 * w.shape[1], w.shape[0]))
                     u["c_up"] = c16(ub.upsample.bias)
+                    u["w_upp"] = ops.pack_convt_s4(u["w_up"])
                 pk["up"].append(u)
         self._pack = {key: pk}
         return pk
@@ -294,7 +295,7 @@ class VAE(nn.Module):
                 for rw in u["nets"]:
                     h = self._resnet(h, rw, S)
                 if u["w_up"] is not None:
-                    h = ops.convtranspose_k2s2(h, u["w_up"], u["c_up"], S)
+                    h = ops.convtranspose_k2s2(h, u["w_up"], u["c_up"], S, Wp=u["w_upp"])
                     S *= 2
             if ops.conv3_takes_groupnorm(pk["w_outp"], S, pk["groups_out"]):
                 h = ops.conv3d_k3(h, pk["w_out"], pk["c_out"], S, Wp=pk["w_outp"], gn=(pk["g_out"], pk["b_out"], pk["eps_out"]))

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 16
+#define PRIMX_ABI_VERSION 17
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -233,6 +233,17 @@ int primx_conv3d_s8_packed(const void* in, const void* Wp, const void* bias, con
 int primx_conv3d_s8c32_pack(const void* Wk, void* Wp, int Cout, int Kpad, int dtype, void* stream);
 int primx_conv3d_s8c32_packed(const void* in, const void* Wp, const void* bias, const float* gamma, const float* beta, float eps,
                               const void* res, float res_scale, void* out, int P, int Cout, int dtype, void* stream);
+
+/* primx_convtranspose_k2s2 for S = 4, Cin = Cout = 256 (UpBlock.upsample of up_blocks[0], vae3d_dib.py:250-261),
+ * weight-stationary: a workgroup keeps one tap's [256, 256] matrix in LDS and walks primitives (csrc/convt.hip).
+ * primx_convtranspose_s4_pack re-lays Wt [8*256, 256] (row = tap*256 + co, as primx_convtranspose_k2s2 takes it) into the
+ * kernel's LDS images (same size; must not alias).  `part` (may be NULL): [P, 16, 32, 2] fp32 - for every primitive, 16
+ * partial pairs (sum of (x - shift), sum of (x - shift)^2) per group of 8 output channels over disjoint 32-voxel pieces of
+ * the ROUNDED 16-bit output, shift = (float) bias[8 * group]: added up in index order they are the statistics of the
+ * GroupNorm(32) that follows (ResnetBlock.norm1, vae3d_dib.py:109); primx_conv3d_s8_packed consumes them. */
+int primx_convtranspose_s4_pack(const void* Wt, void* Wp, int dtype, void* stream);
+int primx_convtranspose_s4_packed(const void* in, const void* Wp, const void* bias, void* out, float* part, int P, int dtype,
+                                  void* stream);
 
 /* out[M, N] (16-bit) = ((A W^T + bias) + res) * scale with no intermediate rounding; res may be NULL.
  * The 1x1 shortcut conv (vae3d_dib.py:124-125) and VolumeAttention's proj + `(x + res) * skip_scale`

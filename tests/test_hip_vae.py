@@ -105,6 +105,35 @@ def test_conv3d_with_groupnorm_silu_inside(pkg, dtype, Cout, P):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("P", [3, 37])
+def test_convtranspose_s4_with_group_statistics(pkg, dtype, P):
+    """csrc/convt.hip: the activation-resident k2s2 upsample == the GEMM form (same rounding: one per output), against
+    fp64, and its per-(primitive, group) statistics == mean / rstd of the 16-bit output it wrote."""
+    from topia_xl_amd import ops
+    if os.environ.get("PRIMX_CONV_REG", "1") == "0":
+        pytest.skip("PRIMX_CONV_REG=0 keeps the GEMM form")
+    S, C = 4, 256
+    x = synth.tensor(36, "ct.x", (P, C, S, S, S)).to(dtype)
+    w = synth.tensor(36, "ct.w", (C, C, 2, 2, 2), C ** -0.5).to(dtype)            # ConvTranspose3d weight [Cin, Cout, 2, 2, 2]
+    b = synth.tensor(36, "ct.b", (C,), 0.3).to(dtype)
+    wt = w.permute(2, 3, 4, 1, 0).reshape(8 * C, C).contiguous().to(DEV)
+    wp = ops.pack_convt_s4(wt)
+    assert wp is not None
+    xd = _cl(x).to(DEV)
+    gemm = ops.convtranspose_k2s2(xd, wt, b.to(DEV), S)
+    got, part = ops.convtranspose_k2s2(xd, wt, b.to(DEV), S, Wp=wp, want_stats=True)
+    st = ops.group_stats(part, b.to(DEV), 1e-5)
+    assert rel_l2(got, gemm) < (2e-4 if dtype == torch.float16 else 2e-3), rel_l2(got, gemm)
+    ref = F.conv_transpose3d(x.double(), w.double(), b.double(), stride=2)
+    assert rel_l2(_cf(got, 2 * S), ref) < (1e-3 if dtype == torch.float16 else 8e-3)
+    g = got.float().cpu().view(P, 512, 32, 8).permute(0, 2, 1, 3).reshape(P, 32, -1).double()   # [P, group, voxels x 8 channels]
+    mean, var = g.mean(-1), g.var(-1, unbiased=False)
+    assert float((st[..., 0].cpu().double() - mean).abs().max()) < 2e-5
+    assert float((st[..., 1].cpu().double() * (var + 1e-5).sqrt() - 1).abs().max()) < 1e-4
+    assert isinstance(ops.convtranspose_k2s2(xd, wt, b.to(DEV), S, Wp=wp), torch.Tensor)              # without statistics: the tensor alone
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_conv_in_convtranspose_and_output(pkg, dtype):
     from topia_xl_amd import ops
     P, S = 4, 4
