@@ -8,22 +8,23 @@
 // EPI_CONVT: M = P * 64, N = 8 * 256, K = 256) it has FOUR k-tiles - all prologue and epilogue: 16,384 workgroups each
 // loading 128 KB of operands for 32 KB of output (2.1 GB through L2 -> LDS, 344 us).
 //
-// WEIGHT-STATIONARY: a workgroup owns ONE tap - its [256 cout][256 cin] matrix is exactly 128 KB of LDS, loaded once - and
-// walks primitives; wave = (z-half of the primitive, 64 output channels): the 32 voxels x 256 channels it multiplies come
-// straight from global memory into registers in MFMA fragment layout (16 loads per lane, the NEXT primitive's already in
-// flight), 64 MFMAs 16x16x32, bias + rounding, four 16-byte stores.  No barrier and no counted wait in the loop: the
-// waves never share anything but the read-only weights, and hipcc's own waitcnt pass orders loads and stores.
-// (An activation-stationary version with the weights streaming through an LDS-DMA ring measured 286 us: gfx9's vmcnt is
-// ONE in-order counter for loads, LDS-DMA and stores, so every counted wait for a weight tile issued after a tap's output
-// stores also waited for those stores.  Here the next primitive's loads are issued BEFORE the current one's stores, so
-// waiting for them never waits for a store.)
-// Measured: 300-320 us per launch for 2048 primitives (GEMM form 345-375).  Probes: without the output stores 261, without
-// the activation loads 155, with an L2-resident 1 MB activation set 326 - i.e. not HBM and not L2 misses but the REQUEST
-// rate: a `global_load_dwordx4` in MFMA fragment layout has consecutive lanes on consecutive ROWS (512 B apart), 64
-// separate 16-byte requests per instruction (128 load + 32 store instructions per primitive-tap per CU = ~10k cycles,
-// against 2k of MFMA).  Next: the activations through LDS-DMA (8 lanes per 128-byte line) with this tap's weights in
-// registers instead.
-//
+// WEIGHT-STATIONARY: a workgroup owns ONE tap and walks primitives; wave = (z-half of the primitive, 64 output
+// channels) keeps ITS slice of the tap's matrix - 64 cout x 256 cin = 32 fragments - in 128 VGPRs for the whole kernel.
+// The activations of a primitive (64 voxels x 256 channels, 32 KB) come through a 4-deep LDS ring filled by LDS-DMA:
+// 64 MFMAs 16x16x32 per wave per primitive against 16 ds_read_b128, bias + rounding, four 16-byte stores.
+// How it got here (2048 primitives; GEMM form 345-375 us):
+//  * activation-stationary, weights streaming through an LDS-DMA ring: 286 us.  gfx9's vmcnt is ONE in-order counter for
+//    loads, LDS-DMA and stores: every counted wait for a weight tile issued after a tap's output stores also waited for
+//    those stores, two tile periods later;
+//  * weight in LDS (128 KB), activations straight from global memory into registers in MFMA fragment layout with a ping-pong
+//    prefetch: 300-320 us.  Probes: without the output stores 261, without the activation loads 155, with an L2-resident
+//    1 MB activation set 326 - not HBM, not L2 misses, but the REQUEST rate: a `global_load_dwordx4` in fragment layout
+//    has consecutive lanes on consecutive ROWS (512 B apart) = 64 separate 16-byte requests per instruction (128 of them
+//    per primitive-tap per CU: ~10k cycles against 2k of MFMA).  (Also: a prefetch under `if` made hipcc's waitcnt pass
+//    merge the two paths and wait as if the newer loads did not exist - the prefetches must be unconditional.)
+//  * this version: the DMA's per-lane source addresses put 8 lanes on each 128-byte line (8 requests per instruction), the
+//    ring is deep enough that an output store has three steps before a counted wait reaches it: **182 us** (754 TFLOP/s;
+//    the 537 MB of output alone are 78 us at the 6.9 TB/s a pure fill reaches).
 // Statistics: per lane shifted sums (x - shift, (x - shift)^2 of the ROUNDED 16-bit outputs, shift = the group's first bias)
 // over the wave's 32 voxels, a 16-lane reduction, one (s1, s2) pair per (primitive, tap, z-half, group) written to
 // `part[P][16][32][2]`; the consumer adds the 16 pairs in fixed order (deterministic; no atomics).
@@ -49,46 +50,78 @@ __global__ __launch_bounds__(512) void convt_s4c256_kernel(const typename T16<DT
                                                           int ngroups) {
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
-    constexpr int CIN = 256, COUT = 256, KT = 256 * 64;               // halves per k-tile image [256 cout][64 k]
-    __shared__ __attribute__((aligned(16))) S wl[4 * KT];             // this tap's weight: 128 KB
+    typedef __attribute__((address_space(3))) void LV;
+    constexpr int CIN = 256, COUT = 256, KT = 256 * 64;               // halves per weight k-tile image [256 cout][64 k]
+    constexpr int NST = 4, AST = 64 * 256;                            // activation ring: 4 primitives x [4 k-tiles][64 voxels][64 ch] (32 KB each)
+    __shared__ __attribute__((aligned(16))) S ring[NST * AST];        // 128 KB
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wz = wave >> 2, wn = wave & 3;                          // z-half of the primitive, group of 64 output channels
     const int lr = lane & 15, lg = lane >> 4;
     // workgroups are dealt to the 8 XCDs round-robin: the eight taps of a primitive group share blockIdx & 7, i.e. one XCD's
-    // L2, and walk the same primitives at the same time (a primitive is fetched from HBM once, not eight times)
-    // (needs a multiple of 8 groups; otherwise the plain order)
+    // L2, and walk the same primitives at the same time (needs a multiple of 8 groups; otherwise the plain order)
     const bool xcd = (ngroups & 7) == 0;
     const int tap = xcd ? (blockIdx.x >> 3) & 7 : blockIdx.x & 7;
     const int grp = xcd ? (blockIdx.x & 7) | ((blockIdx.x >> 6) << 3) : blockIdx.x >> 3;
     const int dz = tap >> 2, dy = (tap >> 1) & 1, dx = tap & 1;
+    const int nstep = grp < P ? (P - grp + ngroups - 1) / ngroups : 0;   // primitives grp, grp + ngroups, ...
 
-    // ---- the tap's weight image, once
+    // ---- activation DMA: primitive n -> stage n & 3.  Instruction i of this wave copies rows 8 wave .. + 8 of k-tile i: the
+    // lane's 16 bytes are chunk (lane & 7) ^ swizzle of row 8 wave + (lane >> 3) - 8 lanes per 128-byte line, where a load
+    // in MFMA fragment layout would be one 16-byte request per lane (this kernel's first version: 10k cycles per step)
+    const int drow = 8 * wave + (lane >> 3);
+    const unsigned voff = (unsigned)((drow * CIN + (((lane & 7) ^ ((drow >> 1) & 7)) << 3)) * 2);      // bytes inside the primitive
+    const unsigned lds0 = (unsigned)(uintptr_t)(LV*)ring + (unsigned)wave * 1024u;
+    auto issue = [&](int n) {
+        const int p = min(grp + n * ngroups, P - 1);                  // (past the end: a harmless reload of the last primitive)
+        const char* sb = reinterpret_cast<const char*>(in) + (int64_t)__builtin_amdgcn_readfirstlane(p) * (64 * CIN * 2);
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(n & 3) * (AST * 2));
+        // (the instruction offset of an LDS-DMA load is added to the LDS address as well as to the global one: k-tile i is 128 i
+        // bytes further in memory and 8 KB i further in LDS, so M0 advances by 0x2000 - 0x80 per instruction)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                     "s_add_u32 m0, m0, 0x1f80\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:128\n\t"
+                     "s_add_u32 m0, m0, 0x1f80\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:256\n\t"
+                     "s_add_u32 m0, m0, 0x1f80\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:384"
+                     ::"s"(m0v), "v"(voff), "s"(sb) : "memory");
+    };
+    issue(0);
+    issue(1);
+    issue(2);
+
+    // ---- this wave's weights: 64 output channels x 256 k of the tap = 32 fragments = 128 registers, read once from the packed
+    // image (same offsets as an LDS read of it would use)
+    V8 wreg[8][4];
     {
-        const u32x4* src = reinterpret_cast<const u32x4*>(Wp + (int64_t)tap * 4 * KT);
-        u32x4* dst = reinterpret_cast<u32x4*>(wl);
-        for (int c = tid; c < 4 * KT / 8; c += 512) dst[c] = src[c];
+        const S* wsrc = Wp + (int64_t)tap * 4 * KT;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                wreg[ks][ni] = *reinterpret_cast<const V8*>(wsrc + (ks >> 1) * KT + lds_off(wn * 64 + ni * 16 + lr, (ks & 1) * 4 + lg));
     }
-
     const int c0 = wn * 64 + lg * 16;                                 // this lane's 16 output channels = groups c0 / 8, c0 / 8 + 1
     V8 b0 = V8{}, b1 = V8{};
     if (bias) { b0 = *reinterpret_cast<const V8*>(bias + c0); b1 = *reinterpret_cast<const V8*>(bias + c0 + 8); }
     const float sh0 = (float)b0[0], sh1 = (float)b1[0];
     const int vy = lr >> 2, vx = lr & 3;                              // in-plane position of this lane's input voxel
-    const int w_row = wn * 64 + lr;
+    // all of the above "used" here, so that hipcc waits for these loads once, before the loop (conv3s8.hip)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) asm volatile("" ::"v"(wreg[ks][ni]));
+    asm volatile("" ::"v"(b0), "v"(b1));
 
-    // Two fragment sets in ping-pong: the loads of primitive n + 1 are issued BEFORE the MFMAs of primitive n (a whole
-    // iteration of latency cover) and before n's stores (so waiting for them never waits for a store).
-    V8 a0[8][2], a1[8][2];
-    auto load_a = [&](V8 (&a)[8][2], int p) {
-        const S* src = in + ((int64_t)p * 64 + wz * 32 + lr) * CIN + lg * 8;
-#pragma unroll
-        for (int z = 0; z < 2; ++z)
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) a[ks][z] = *reinterpret_cast<const V8*>(src + z * 16 * CIN + ks * 32);
-    };
-    auto one = [&](const V8 (&a)[8][2], int p) {
+#pragma clang loop unroll(disable)
+    for (int n = 0; n < nstep; ++n) {
+        // Primitive n landed for this wave.  vmcnt is ONE in-order counter: behind D(n) [issued at step n - 3] sit S(n-3), D(n+1),
+        // S(n-2), D(n+2), S(n-1) - two groups of 4 DMAs and three groups of 4 (+ 1 with statistics) stores may stay in flight,
+        // so an output store has three steps to complete.
+        if (part) asm volatile("s_waitcnt vmcnt(23)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");
+        issue(n + 3);                                                 // into the stage of primitive n - 1, which every wave has left
+        const int p = grp + n * ngroups;
+        const S* As = ring + (n & 3) * AST;
         f32x4 acc[2][4];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -96,17 +129,14 @@ __global__ __launch_bounds__(512) void convt_s4c256_kernel(const typename T16<DT
             for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            // (compiler fence per k-tile: the weight image is loop-invariant and read-only, so hipcc otherwise hoists all 32
-            // fragment reads - 128 registers - out of the primitive loop and spills around them)
-            if ((ks & 1) == 0) asm volatile("" ::: "memory");
-            const S* Wt = wl + (ks >> 1) * KT;
-            V8 wf[4];
+            V8 af[2];
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) wf[ni] = *reinterpret_cast<const V8*>(Wt + lds_off(w_row + ni * 16, (ks & 1) * 4 + lg));
+            for (int mi = 0; mi < 2; ++mi)
+                af[mi] = *reinterpret_cast<const V8*>(As + (ks >> 1) * (64 * 64) + lds_off(wz * 32 + mi * 16 + lr, (ks & 1) * 4 + lg));
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T16<DT>::mfma16(wf[ni], a[ks][mi], acc[mi][ni]);
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T16<DT>::mfma16(wreg[ks][ni], af[mi], acc[mi][ni]);
         }
         // ---- 32 voxels x 64 channels: bias, rounding, store at (2z+dz, 2y+dy, 2x+dx), statistics
         float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
@@ -140,22 +170,8 @@ __global__ __launch_bounds__(512) void convt_s4c256_kernel(const typename T16<DT
                 *reinterpret_cast<f32x4*>(dst) = f32x4{s1[0], s2[0], s1[1], s2[1]};
             }
         }
-    };
-    int p = grp;
-    load_a(a0, p < P ? p : P - 1);
-    __syncthreads();                                                  // weight image complete
-    // (the prefetches are UNCONDITIONAL, past the end they re-read the current primitive: under an `if` hipcc's waitcnt pass
-    // merges the two paths and waits as if the 16 newer loads did not exist - vmcnt(11) where vmcnt(23) would do - which
-    // drains the prefetch it was meant to overlap; measured 300 us either way until this went)
-    while (p < P) {
-        const int p1 = p + ngroups, p2 = p + 2 * ngroups;
-        load_a(a1, p1 < P ? p1 : p);
-        one(a0, p);
-        if (p1 >= P) break;
-        load_a(a0, p2 < P ? p2 : p1);
-        one(a1, p1);
-        p = p2;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the tail DMAs must not outlive the workgroup's LDS
 }
 
 // Wt [8 * 256][256] (row = tap * 256 + co, K = ci) -> Wp[tap][kc][rho][slot][8]; one 16-byte chunk per thread
