@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PRIMX_LIB") or os.path.join(_HERE, "csrc", "libprimx_
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
 HEADS_ROWS, HEADS_VT, HEADS_KROWS = 0, 1, 2
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -45,7 +45,8 @@ SIGNATURES = {
     "primx_conv3d_k3": [_p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _i, _p],
     "primx_conv3d_s4_pack": [_p, _p, _i, _i, _p],
     "primx_conv3d_s4_packed": [_p, _p, _p, _p, _f, _p, _i, _i, _i, _p],
-    "primx_conv3d_s8_pack": [_p, _p, _i, _p],
+    "primx_conv3d_s8_pack": [_p, _p, _p, _i, _p],
+    "primx_conv3d_s8_fused": [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _p],
     "primx_conv3d_s8_packed": [_p, _p, _p, _p, _f, _p, _i, _i, _p],
     "primx_convtranspose_s4_pack": [_p, _p, _i, _p],
     "primx_convtranspose_s4_packed": [_p, _p, _p, _p, _p, _i, _i, _p],

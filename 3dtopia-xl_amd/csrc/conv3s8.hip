@@ -29,18 +29,39 @@ namespace {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
-template <int DT>
+// Arguments of the FUSED form (conv1 of up_blocks[1].nets[0] with everything around it, vae3d_dib.py:109-125): `in` is the RAW
+// upsample output; its GroupNorm(32 groups of 8 channels) statistics arrive as the 16 partial shifted sums per (primitive,
+// group) that convt.hip wrote (shift = up_bias[8 g]); the kernel normalises + SiLUs its plane in registers after it has
+// used the raw plane for the 1x1 shortcut convolution (weight block 27 of the image, output `sc_out`).
+template <typename S>
+struct FusedArgs {
+    const float* part;       // [P][16][32][2]
+    const S* up_bias;        // [256] bias of the producing upsample (the statistics' shifts)
+    const float* gamma;      // [256]
+    const float* beta;       // [256]
+    float eps;
+    const S* sc_bias;        // [32] or null
+    S* sc_out;               // [P][512][32]
+};
+
+__device__ __forceinline__ float silu_fast(float v) {   // v * sigmoid(v) with v_exp_f32 + v_rcp_f32 (1 ulp) - silu_f's IEEE
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));   // division is ~12 VALU instructions
+}
+
+template <int DT, int FUSED>
 __global__ __launch_bounds__(512) void conv3_s8c256n32_kernel(const typename T16<DT>::S* __restrict__ in,
                                                              const typename T16<DT>::S* __restrict__ Wp,
                                                              const typename T16<DT>::S* __restrict__ bias,
                                                              const typename T16<DT>::S* __restrict__ res, float res_scale,
-                                                             typename T16<DT>::S* __restrict__ out) {
+                                                             typename T16<DT>::S* __restrict__ out,
+                                                             const FusedArgs<typename T16<DT>::S> fa) {
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
     typedef __attribute__((address_space(3))) void LV;
     constexpr int CIN = 256, COUT = 32, VOX = 512, NST = 4, TAPB = 4 * 32 * 64;   // halves per tap block (16 KB)
     __shared__ __attribute__((aligned(16))) float obuf[VOX * COUT];               // 64 KB
     __shared__ __attribute__((aligned(16))) S wring[NST * TAPB];                  // 64 KB
+    __shared__ __attribute__((aligned(16))) float gab[FUSED ? 2 * 256 : 4];       // FUSED: per-channel scale / shift of the normalisation
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int zi = __builtin_amdgcn_readfirstlane(tid >> 6);                      // wave = input plane
@@ -54,12 +75,32 @@ __global__ __launch_bounds__(512) void conv3_s8c256n32_kernel(const typename T16
         for (int i = 0; i < 8; ++i) o4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    if constexpr (FUSED) {
+        // per-channel scale and shift from the 16 partial sums of the channel's group, added in index order
+        if (tid < 256) {
+            const int g = tid >> 3;
+            const float* pp = fa.part + ((int64_t)prim * 16 * 32 + g) * 2;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s1 += pp[i * 64]; s2 += pp[i * 64 + 1]; }
+            const float m = s1 * (1.0f / 4096.0f), var = s2 * (1.0f / 4096.0f) - m * m;
+            const float mean = (float)fa.up_bias[8 * g] + m;
+            const float r = 1.0f / sqrtf(fmaxf(var, 0.f) + fa.eps);
+            const float ga = fa.gamma[tid] * r;
+            gab[tid] = ga;
+            gab[256 + tid] = fa.beta[tid] - mean * ga;
+        }
+    }
+
     // ---- weight ring: step t handles tap (dzs + 1) * 9 + t % 9 with dzs = 0, +1, -1 for t / 9 = 0, 1, 2
+    // FUSED: one more step in front - weight block 27, the shortcut - so taps are steps 1 .. 27
+    constexpr int NSTEP = 27 + FUSED;
     auto tap_of = [](int t) { return (t < 9 ? 9 : t < 18 ? 18 : 0) + (t < 9 ? t : t < 18 ? t - 9 : t - 18); };
+    auto block_of = [&](int s) { return FUSED ? (s == 0 ? 27 : tap_of(s - 1)) : tap_of(s); };
     const unsigned lds_w0 = (unsigned)(uintptr_t)(LV*)wring + (unsigned)zi * 2048u;
     const unsigned voff = (unsigned)(zi * 2048 + lane * 16);
     auto issue = [&](int t, int stage) {   // (SGPR base + 32-bit lane offset; M0 = LDS byte address of the 1 KB piece)
-        const char* sb = reinterpret_cast<const char*>(Wp) + (int64_t)__builtin_amdgcn_readfirstlane(tap_of(t)) * (TAPB * 2);
+        const char* sb = reinterpret_cast<const char*>(Wp) + (int64_t)__builtin_amdgcn_readfirstlane(block_of(t)) * (TAPB * 2);
         const unsigned m0a = __builtin_amdgcn_readfirstlane(lds_w0 + (unsigned)stage * (TAPB * 2));
         // (no instruction offset on the second piece: for LDS-DMA that field is added to the LDS address as well)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
@@ -96,8 +137,12 @@ __global__ __launch_bounds__(512) void conv3_s8c256n32_kernel(const typename T16
         // taps <= t landed for this wave (t + 1, t + 2 may stay in flight: 2 DMA instructions each); this wave's adds of the
         // previous tap are done; after the barrier the DMA below may overwrite the stage of tap t - 1
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        issue(min(t + 3, 26), (t + 3) & 3);                              // (past the end: a harmless reload of the last tap)
-        const int ph = t < 9 ? 0 : t < 18 ? 1 : 2, dydx = t - 9 * ph;
+        issue(min(t + 3, NSTEP - 1), (t + 3) & 3);                       // (past the end: a harmless reload of the last block)
+        if constexpr (FUSED) {
+            if (t == 0) return;                                          // (step 0 is the shortcut, handled before the loop)
+        }
+        const int tt = t - FUSED;                                        // tap sequence number
+        const int ph = tt < 9 ? 0 : tt < 18 ? 1 : 2, dydx = tt - 9 * ph;
         const int dzs = ph == 0 ? 0 : ph == 1 ? 1 : -1;
         const int dy = dydx / 3 - 1, dx = dydx - 3 * (dydx / 3) - 1;
         const int zo = zi - dzs;                                          // out[z] += W[dz] * in[z + dz]
@@ -143,8 +188,46 @@ __global__ __launch_bounds__(512) void conv3_s8c256n32_kernel(const typename T16
     // NOT unrolled / peeled: with hipcc's default (it peels the first three taps and specialises the loop by phase) the
     // contributions of steps 1..5 were lost on the GPU (tools/probe/conv_s8_taps.py: one nonzero tap at a time) although
     // the peeled ISA reads correctly; the rolled loop is also a third of the code.
+    if constexpr (FUSED) {
+        // ---- step 0: 1x1 shortcut on the RAW plane (weight block 27 in stage 0), straight to memory; then the plane is
+        // normalised in place: 256 values per lane, scale / shift of its 8 channels per k-step from LDS
+        tap_step(0);                                                     // wait + barrier + DMA of step 3 (returns before any tap work)
+        f32x4 sacc[4][2];
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) sacc[cg][0] = sacc[cg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const S* Wt = wring + (ks >> 1) * (32 * 64);
+            const V8 w0 = *reinterpret_cast<const V8*>(Wt + lds_off(w_row, (ks & 1) * 4 + lg));
+            const V8 w1 = *reinterpret_cast<const V8*>(Wt + lds_off(w_row + 16, (ks & 1) * 4 + lg));
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) {
+                sacc[cg][0] = T16<DT>::mfma16(w0, a[ks][cg], sacc[cg][0]);
+                sacc[cg][1] = T16<DT>::mfma16(w1, a[ks][cg], sacc[cg][1]);
+            }
+        }
+        V8 sb8 = V8{};
+        if (fa.sc_bias) sb8 = *reinterpret_cast<const V8*>(fa.sc_bias + lg * 8);
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) {
+            V8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (S)(sacc[cg][e >> 2][e & 3] + (float)sb8[e]);
+            *reinterpret_cast<V8*>(fa.sc_out + ((int64_t)prim * VOX + zi * 64 + cg * 16 + j) * COUT + lg * 8) = o;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gab + ks * 32 + lg * 8), g1 = *reinterpret_cast<const f32x4*>(gab + ks * 32 + lg * 8 + 4);
+            const f32x4 h0 = *reinterpret_cast<const f32x4*>(gab + 256 + ks * 32 + lg * 8), h1 = *reinterpret_cast<const f32x4*>(gab + 256 + ks * 32 + lg * 8 + 4);
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    a[ks][cg][e] = (S)silu_fast((float)a[ks][cg][e] * (e < 4 ? g0[e & 3] : g1[e & 3]) + (e < 4 ? h0[e & 3] : h1[e & 3]));
+        }
+    }
 #pragma clang loop unroll(disable)
-    for (int t = 0; t < 27; ++t) tap_step(t);
+    for (int t = FUSED; t < NSTEP; ++t) tap_step(t);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     // ---- epilogue: one voxel per thread, 32 channels = 64 contiguous bytes of the output
@@ -174,25 +257,28 @@ __global__ __launch_bounds__(512) void conv3_s8c256n32_kernel(const typename T16
     }
 }
 
-// Wk [32][27 * 256] (k = tap * 256 + ci) -> Wp[tap][kc][rho][slot][8]; one 16-byte chunk per thread
-__global__ __launch_bounds__(256) void conv3_s8_pack_kernel(const unsigned short* __restrict__ Wk, unsigned short* __restrict__ Wp) {
+// Wk [32][27 * 256] (k = tap * 256 + ci) -> Wp[tap][kc][rho][slot][8]; one 16-byte chunk per thread.  Block 27 (optional):
+// the 1x1 shortcut weight Wsc [32][256].
+__global__ __launch_bounds__(256) void conv3_s8_pack_kernel(const unsigned short* __restrict__ Wk, const unsigned short* __restrict__ Wsc,
+                                                           unsigned short* __restrict__ Wp) {
     const int cid = blockIdx.x * 256 + threadIdx.x;       // chunk index in Wp
-    if (cid >= 27 * 4 * 32 * 8) return;
+    if (cid >= (Wsc ? 28 : 27) * 4 * 32 * 8) return;
     const int slot = cid & 7, rho = (cid >> 3) & 31, kc = (cid >> 8) & 3, tap = cid >> 10;
     const int i16 = rho & 15, ni = rho >> 4;
     const int n = (i16 >> 2) * 8 + ni * 4 + (i16 & 3);
     const int c = slot ^ ((rho >> 1) & 7);
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    *reinterpret_cast<u4*>(Wp + (int64_t)cid * 8) = *reinterpret_cast<const u4*>(Wk + (int64_t)n * (27 * 256) + tap * 256 + kc * 64 + c * 8);
+    const unsigned short* src = tap < 27 ? Wk + (int64_t)n * (27 * 256) + tap * 256 + kc * 64 + c * 8 : Wsc + n * 256 + kc * 64 + c * 8;
+    *reinterpret_cast<u4*>(Wp + (int64_t)cid * 8) = *reinterpret_cast<const u4*>(src);
 }
 
 }  // namespace
 
-extern "C" int primx_conv3d_s8_pack(const void* Wk, void* Wp, int dtype, void* stream) {
-    PRIMX_REQUIRE(Wk && Wp && Wk != Wp, "primx_conv3d_s8_pack: null or aliased pointer");
+extern "C" int primx_conv3d_s8_pack(const void* Wk, const void* Wsc, void* Wp, int dtype, void* stream) {
+    PRIMX_REQUIRE(Wk && Wp && Wk != Wp && Wsc != Wp, "primx_conv3d_s8_pack: null or aliased pointer");
     PRIMX_REQUIRE(dtype == PRIMX_F16 || dtype == PRIMX_BF16, "primx_conv3d_s8_pack: dtype must be PRIMX_F16 or PRIMX_BF16");
-    hipLaunchKernelGGL(conv3_s8_pack_kernel, dim3(27 * 4 * 32 * 8 / 256), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)Wk, (unsigned short*)Wp);
+    hipLaunchKernelGGL(conv3_s8_pack_kernel, dim3(28 * 4 * 32 * 8 / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)Wk, (const unsigned short*)Wsc, (unsigned short*)Wp);
     PRIMX_CHECK_LAUNCH("primx_conv3d_s8_pack");
     return PRIMX_OK;
 }
@@ -203,9 +289,24 @@ extern "C" int primx_conv3d_s8_packed(const void* in, const void* Wp, const void
     PRIMX_REQUIRE(P > 0, "primx_conv3d_s8_packed: need P > 0 (P=%d)", P);
     PRIMX_DISPATCH_16(dtype, "primx_conv3d_s8_packed", {
         using Sx = typename T16<DT>::S;
-        hipLaunchKernelGGL((conv3_s8c256n32_kernel<DT>), dim3(P), dim3(512), 0, (hipStream_t)stream, (const Sx*)in, (const Sx*)Wp,
-                           (const Sx*)bias, (const Sx*)res, res_scale, (Sx*)out);
+        hipLaunchKernelGGL((conv3_s8c256n32_kernel<DT, 0>), dim3(P), dim3(512), 0, (hipStream_t)stream, (const Sx*)in, (const Sx*)Wp,
+                           (const Sx*)bias, (const Sx*)res, res_scale, (Sx*)out, FusedArgs<Sx>{});
     });
     PRIMX_CHECK_LAUNCH("primx_conv3d_s8_packed");
+    return PRIMX_OK;
+}
+
+extern "C" int primx_conv3d_s8_fused(const void* in_raw, const void* Wp28, const void* bias, const float* part, const void* up_bias,
+                                     const float* gamma, const float* beta, float eps, const void* sc_bias, void* out, void* sc_out,
+                                     int P, int dtype, void* stream) {
+    PRIMX_REQUIRE(in_raw && Wp28 && part && up_bias && gamma && beta && out && sc_out, "primx_conv3d_s8_fused: null pointer");
+    PRIMX_REQUIRE(P > 0, "primx_conv3d_s8_fused: need P > 0 (P=%d)", P);
+    PRIMX_DISPATCH_16(dtype, "primx_conv3d_s8_fused", {
+        using Sx = typename T16<DT>::S;
+        FusedArgs<Sx> fa = {part, (const Sx*)up_bias, gamma, beta, eps, (const Sx*)sc_bias, (Sx*)sc_out};
+        hipLaunchKernelGGL((conv3_s8c256n32_kernel<DT, 1>), dim3(P), dim3(512), 0, (hipStream_t)stream, (const Sx*)in_raw, (const Sx*)Wp28,
+                           (const Sx*)bias, (const Sx*)nullptr, 1.0f, (Sx*)out, fa);
+    });
+    PRIMX_CHECK_LAUNCH("primx_conv3d_s8_fused");
     return PRIMX_OK;
 }

@@ -380,13 +380,13 @@ class PackedConv3:
     """Weight image of one of the activation-resident 3x3x3 kernels: kind "s4" (csrc/conv3.hip: 4^3 grid, Cin 256, Cout %
     256 == 0), "s8" (csrc/conv3s8.hip: 8^3 grid, Cin 256, Cout 32) or "s8c32" (csrc/conv3s8c32.hip: 8^3 grid, Cin 32, Cout 32
     or <= 16; the only one that can take the preceding GroupNorm + SiLU into the kernel)."""
-    __slots__ = ("kind", "S", "Cin", "Cout", "Wp")
+    __slots__ = ("kind", "S", "Cin", "Cout", "Wp", "has_sc")
 
     def __init__(self, kind: str, S: int, Cin: int, Cout: int, Wp: torch.Tensor):
-        self.kind, self.S, self.Cin, self.Cout, self.Wp = kind, S, Cin, Cout, Wp
+        self.kind, self.S, self.Cin, self.Cout, self.Wp, self.has_sc = kind, S, Cin, Cout, Wp, False
 
 
-def pack_conv3(Wk: torch.Tensor, Cin: int) -> Optional[PackedConv3]:
+def pack_conv3(Wk: torch.Tensor, Cin: int, Wsc: Optional[torch.Tensor] = None) -> Optional[PackedConv3]:
     """PackedConv3 for a [Cout, 27*Cin] conv3d_k3 weight whose shape one of the activation-resident kernels covers, else
     None (also with PRIMX_CONV_REG=0, which keeps the implicit GEMM for A/B runs).  The grid edge the image is for is part
     of the result; conv3d_k3 only uses it on that grid."""
@@ -407,10 +407,35 @@ def pack_conv3(Wk: torch.Tensor, Cin: int) -> Optional[PackedConv3]:
     Wp = torch.empty_like(Wk)
     with torch.cuda.device(Wk.device):
         if Cout == 32:
-            check(_lib.load().primx_conv3d_s8_pack(_dev(Wk, "Wk"), Wp.data_ptr(), dtype_code(Wk.dtype), _stream()), "primx_conv3d_s8_pack")
-            return PackedConv3("s8", 8, Cin, Cout, Wp)
+            # (with the ResnetBlock's 1x1 shortcut weight [32, 256] a 28th block is appended: conv3d_s8_fused)
+            if Wsc is not None:
+                Wp = torch.empty(28 * 8192, dtype=Wk.dtype, device=Wk.device)
+            check(_lib.load().primx_conv3d_s8_pack(_dev(Wk, "Wk"), _dev(Wsc, "Wsc", Wk.dtype) if Wsc is not None else None, Wp.data_ptr(),
+                                                   dtype_code(Wk.dtype), _stream()), "primx_conv3d_s8_pack")
+            pc = PackedConv3("s8", 8, Cin, Cout, Wp)
+            pc.has_sc = Wsc is not None
+            return pc
         check(_lib.load().primx_conv3d_s4_pack(_dev(Wk, "Wk"), Wp.data_ptr(), Cout, dtype_code(Wk.dtype), _stream()), "primx_conv3d_s4_pack")
         return PackedConv3("s4", 4, Cin, Cout, Wp)
+
+
+def conv3d_s8_fused(x_raw: torch.Tensor, Wp: PackedConv3, bias: Optional[torch.Tensor], part: torch.Tensor, up_bias: torch.Tensor,
+                    gamma: torch.Tensor, beta: torch.Tensor, eps: float, sc_bias: Optional[torch.Tensor]):
+    """(conv1(silu(group_norm(x_raw))), shortcut(x_raw)) of the 256 -> 32 ResnetBlock on the 8^3 grid in ONE kernel: x_raw is the
+    upsample output [P, 512, 256], `part` / `up_bias` its partial GroupNorm sums and their shifts (convtranspose_k2s2(...,
+    want_stats=True)), Wp a pack_conv3(Wk, 256, Wsc) image with the shortcut block."""
+    P, V, Cin = x_raw.shape
+    if not (Wp.kind == "s8" and Wp.has_sc and V == 512 and Cin == 256):
+        raise ValueError("conv3d_s8_fused: needs the 8^3 256 -> 32 image with the shortcut block")
+    out = torch.empty(P, V, 32, dtype=x_raw.dtype, device=x_raw.device)
+    sc = torch.empty(P, V, 32, dtype=x_raw.dtype, device=x_raw.device)
+    tag = f"conv3_s8c256n32_kernel<{dtype_code(x_raw.dtype)}, 1> gn+256->32+sc @8^3 x{P}"
+    _timed(tag, 2.0 * P * V * 32 * 28 * 256, lambda: check(_lib.load().primx_conv3d_s8_fused(
+        _dev(x_raw, "x_raw"), _dev(Wp.Wp, "Wp", x_raw.dtype), _dev(bias, "bias", x_raw.dtype) if bias is not None else None,
+        _dev(part, "part", torch.float32), _dev(up_bias, "up_bias", x_raw.dtype), _dev(gamma, "gamma", torch.float32),
+        _dev(beta, "beta", torch.float32), float(eps), _dev(sc_bias, "sc_bias", x_raw.dtype) if sc_bias is not None else None,
+        out.data_ptr(), sc.data_ptr(), P, dtype_code(x_raw.dtype), _stream()), "primx_conv3d_s8_fused"))
+    return out, sc
 
 
 def conv3_takes_groupnorm(Wp: Optional[PackedConv3], S: int, groups: int) -> bool:
@@ -449,7 +474,7 @@ def conv3d_k3(x: torch.Tensor, Wk: torch.Tensor, bias: Optional[torch.Tensor], S
                 _dev(x, "x"), _dev(Wp.Wp, "Wp", x.dtype), bias_p, res_p, res_scale, out.data_ptr(), P, Cout, dtype_code(x.dtype),
                 _stream()), "primx_conv3d_s4_packed"))
         else:
-            tag = f"conv3_s8c256n32_kernel<{dtype_code(x.dtype)}> {Cin}->{Cout} @{S}^3 x{P}"
+            tag = f"conv3_s8c256n32_kernel<{dtype_code(x.dtype)}, 0> {Cin}->{Cout} @{S}^3 x{P}"
             _timed(tag, flops, lambda: check(_lib.load().primx_conv3d_s8_packed(
                 _dev(x, "x"), _dev(Wp.Wp, "Wp", x.dtype), bias_p, res_p, res_scale, out.data_ptr(), P, dtype_code(x.dtype),
                 _stream()), "primx_conv3d_s8_packed"))

@@ -182,11 +182,13 @@ class VAE(nn.Module):
              "eps2": blk.norm2.eps, "w2": _conv_weight_as_gemm(blk.conv2.weight.detach(), dt), "c2": c16(blk.conv2.bias),
              "wsc": None, "csc": None}
         # weight images of the activation-resident kernels (None for other shapes; each is used only on the grid it is for)
-        d["w1p"] = ops.pack_conv3(d["w1"], blk.conv1.in_channels)
-        d["w2p"] = ops.pack_conv3(d["w2"], blk.conv2.in_channels)
         if isinstance(blk.shortcut, nn.Conv3d):
             d["wsc"] = c16(blk.shortcut.weight.reshape(blk.out_channels, blk.in_channels))
             d["csc"] = c16(blk.shortcut.bias)
+        # (the 256 -> 32 block's image carries its 1x1 shortcut as a 28th weight block: ops.conv3d_s8_fused)
+        d["w1p"] = ops.pack_conv3(d["w1"], blk.conv1.in_channels,
+                                  Wsc=d["wsc"] if (blk.in_channels, blk.out_channels) == (256, 32) else None)
+        d["w2p"] = ops.pack_conv3(d["w2"], blk.conv2.in_channels)
         return d
 
     def packed(self, dt: torch.dtype) -> Dict:
@@ -236,8 +238,17 @@ class VAE(nn.Module):
         return pk
 
     # ------------------------------------------------------------------ decode
-    def _resnet(self, h: torch.Tensor, w: Dict, S: int) -> torch.Tensor:
+    def _resnet(self, h: torch.Tensor, w: Dict, S: int, gn_part=None) -> torch.Tensor:
+        """gn_part = (partial GroupNorm sums of h, their shifts) when h comes straight from the upsample kernel."""
         P, V, Cin = h.shape
+        if gn_part is not None and self._fusable_front(w, S):
+            # norm1 + SiLU + conv1 and the 1x1 shortcut in one kernel, on the raw upsample output
+            t, res = ops.conv3d_s8_fused(h, w["w1p"], w["c1"], gn_part[0], gn_part[1], w["g1"], w["b1"], w["eps1"], w["csc"])
+            if ops.conv3_takes_groupnorm(w["w2p"], S, w["groups2"]):
+                return ops.conv3d_k3(t, w["w2"], w["c2"], S, res=res, res_scale=self.skip_scale, Wp=w["w2p"],
+                                     gn=(w["g2"], w["b2"], w["eps2"]))
+            t = ops.groupnorm_silu(t, w["g2"], w["b2"], w["groups2"], w["eps2"], True)
+            return ops.conv3d_k3(t, w["w2"], w["c2"], S, res=res, res_scale=self.skip_scale, Wp=w["w2p"])
         # GroupNorm + SiLU goes into the convolution kernel where that kernel holds the whole primitive (8^3 x 32 channels)
         if ops.conv3_takes_groupnorm(w["w1p"], S, w["groups1"]):
             t = ops.conv3d_k3(h, w["w1"], w["c1"], S, Wp=w["w1p"], gn=(w["g1"], w["b1"], w["eps1"]))
@@ -252,6 +263,11 @@ class VAE(nn.Module):
                                  gn=(w["g2"], w["b2"], w["eps2"]))
         t = ops.groupnorm_silu(t, w["g2"], w["b2"], w["groups2"], w["eps2"], True)
         return ops.conv3d_k3(t, w["w2"], w["c2"], S, res=res, res_scale=self.skip_scale, Wp=w["w2p"])
+
+    @staticmethod
+    def _fusable_front(w: Dict, S: int) -> bool:
+        p = w.get("w1p")
+        return p is not None and p.kind == "s8" and p.has_sc and p.S == S and w["groups1"] == 32 and w["wsc"] is not None
 
     def _attention(self, h: torch.Tensor, w: Dict) -> torch.Tensor:
         P, V, Cc = h.shape
@@ -291,11 +307,20 @@ class VAE(nn.Module):
                 if aw is not None:
                     h = self._attention(h, aw)
                 h = self._resnet(h, rw, S)
-            for u in pk["up"]:
-                for rw in u["nets"]:
-                    h = self._resnet(h, rw, S)
+            gn_part = None
+            for iu, u in enumerate(pk["up"]):
+                for k, rw in enumerate(u["nets"]):
+                    h = self._resnet(h, rw, S, gn_part if k == 0 else None)
+                gn_part = None
                 if u["w_up"] is not None:
-                    h = ops.convtranspose_k2s2(h, u["w_up"], u["c_up"], S, Wp=u["w_upp"])
+                    # the upsample kernel also leaves the partial GroupNorm sums of its output when the next block can take them
+                    nxt = pk["up"][iu + 1]["nets"][0] if iu + 1 < len(pk["up"]) else None
+                    want = u["w_upp"] is not None and S == 4 and nxt is not None and self._fusable_front(nxt, 2 * S)
+                    if want:
+                        h, part = ops.convtranspose_k2s2(h, u["w_up"], u["c_up"], S, Wp=u["w_upp"], want_stats=True)
+                        gn_part = (part, u["c_up"])
+                    else:
+                        h = ops.convtranspose_k2s2(h, u["w_up"], u["c_up"], S, Wp=u["w_upp"])
                     S *= 2
             if ops.conv3_takes_groupnorm(pk["w_outp"], S, pk["groups_out"]):
                 h = ops.conv3d_k3(h, pk["w_out"], pk["c_out"], S, Wp=pk["w_outp"], gn=(pk["g_out"], pk["b_out"], pk["eps_out"]))

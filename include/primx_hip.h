@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 17
+#define PRIMX_ABI_VERSION 18
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -218,9 +218,20 @@ int primx_conv3d_s4_packed(const void* in, const void* Wp, const void* bias, con
  * fp32 image of the output in LDS (csrc/conv3s8.hip).  primx_conv3d_s8_pack re-lays the [32, 6912] weight of
  * primx_conv3d_k3 into the kernel's LDS tile images (same size; Wp must not alias Wk).  Same result formula as
  * primx_conv3d_k3; the fp32 summation order differs (per tap over all channels, then over taps). */
-int primx_conv3d_s8_pack(const void* Wk, void* Wp, int dtype, void* stream);
+int primx_conv3d_s8_pack(const void* Wk, const void* Wsc, void* Wp, int dtype, void* stream);
 int primx_conv3d_s8_packed(const void* in, const void* Wp, const void* bias, const void* res, float res_scale, void* out,
                            int P, int dtype, void* stream);
+/* primx_conv3d_s8_pack: Wp holds 27 blocks of 8192 elements; with Wsc != NULL (the [32, 256] weight of the ResnetBlock's
+ * 1x1 shortcut, vae3d_dib.py:124-125) a 28th block is written and Wp must hold 28.
+ * primx_conv3d_s8_fused: the whole front of up_blocks[1].nets[0] (vae3d_dib.py:109-110, 124-125) on the RAW upsample
+ * output: norm1 (GroupNorm, 32 groups of 8 channels) from the partial sums `part` [P, 16, 32, 2] of
+ * primx_convtranspose_s4_packed (shift = up_bias[8 g]) + SiLU applied in registers, conv1 -> out [P, 512, 32], and
+ * shortcut(in_raw) = Wsc x in_raw + sc_bias -> sc_out [P, 512, 32] (what primx_linear_residual(…, res = NULL) gives).
+ * Replaces primx_groupnorm_silu (1.6 GB of traffic at 2048 primitives) + primx_conv3d_s8_packed + primx_linear_residual.
+ * SiLU uses v_rcp_f32 (1 ulp) where primx_groupnorm_silu divides; both round the result to 16 bits. */
+int primx_conv3d_s8_fused(const void* in_raw, const void* Wp28, const void* bias, const float* part, const void* up_bias,
+                          const float* gamma, const float* beta, float eps, const void* sc_bias, void* out, void* sc_out, int P,
+                          int dtype, void* stream);
 
 /* The same convolution for S = 8, Cin = 32, Cout = 32 or <= 16, optionally with the preceding GroupNorm (ONE channel per
  * group: per-(primitive, channel) statistics over the 512 voxels) + SiLU applied to the input inside the kernel

@@ -134,6 +134,40 @@ def test_convtranspose_s4_with_group_statistics(pkg, dtype, P):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fused_front_of_the_256_to_32_block(pkg, dtype):
+    """upsample (with partial statistics) -> ONE kernel for GroupNorm(32) + SiLU + conv1 + 1x1 shortcut == the unfused chain
+    groupnorm_silu -> conv3d_k3 and linear_residual on the same upsample output, and both against fp64."""
+    from topia_xl_amd import ops
+    from topia_xl_amd.vae import _conv_weight_as_gemm
+    if os.environ.get("PRIMX_CONV_REG", "1") == "0":
+        pytest.skip("PRIMX_CONV_REG=0 keeps the unfused kernels")
+    P, C = 5, 256
+    x = synth.tensor(37, "ff.x", (P, C, 4, 4, 4)).to(dtype)
+    wu = synth.tensor(37, "ff.wu", (C, C, 2, 2, 2), C ** -0.5).to(dtype)
+    bu = synth.tensor(37, "ff.bu", (C,), 0.3).to(dtype)
+    g, be = synth.tensor(37, "ff.g", (C,), 0.2, 1.0), synth.tensor(37, "ff.be", (C,), 0.2)
+    w1 = synth.tensor(37, "ff.w1", (32, C, 3, 3, 3), (27 * C) ** -0.5).to(dtype)
+    b1 = synth.tensor(37, "ff.b1", (32,), 0.2).to(dtype)
+    wsc = synth.tensor(37, "ff.wsc", (32, C), C ** -0.5).to(dtype)
+    bsc = synth.tensor(37, "ff.bsc", (32,), 0.2).to(dtype)
+    wt = wu.permute(2, 3, 4, 1, 0).reshape(8 * C, C).contiguous().to(DEV)
+    h8, part = ops.convtranspose_k2s2(_cl(x).to(DEV), wt, bu.to(DEV), 4, Wp=ops.pack_convt_s4(wt), want_stats=True)
+    wk = _conv_weight_as_gemm(w1, dtype).to(DEV)
+    wp = ops.pack_conv3(wk, C, Wsc=wsc.to(DEV))
+    assert wp.has_sc
+    t_f, sc_f = ops.conv3d_s8_fused(h8, wp, b1.to(DEV), part, bu.to(DEV), g.to(DEV), be.to(DEV), 1e-5, bsc.to(DEV))
+    n16 = ops.groupnorm_silu(h8, g.to(DEV), be.to(DEV), 32, 1e-5, True)
+    t_u = ops.conv3d_k3(n16, wk, b1.to(DEV), 8, Wp=ops.pack_conv3(wk, C))
+    sc_u = ops.linear_residual(h8.view(P * 512, C), wsc.to(DEV), bsc.to(DEV), None, 1.0).view(P, 512, 32)
+    tol = 1e-3 if dtype == torch.float16 else 8e-3
+    assert rel_l2(sc_f, sc_u) < 1e-6 + (0 if dtype == torch.float16 else 0), rel_l2(sc_f, sc_u)   # same sums, same rounding
+    assert rel_l2(t_f, t_u) < tol, rel_l2(t_f, t_u)
+    hd = _cf(h8, 8).double().cpu()                                                                  # fp64 from the 16-bit upsample output
+    ref = F.conv3d(F.silu(F.group_norm(hd, 32, g.double(), be.double(), 1e-5)), w1.double(), b1.double(), padding=1)
+    assert rel_l2(_cf(t_f, 8), ref) < (1.5e-3 if dtype == torch.float16 else 1.2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_conv_in_convtranspose_and_output(pkg, dtype):
     from topia_xl_amd import ops
     P, S = 4, 4

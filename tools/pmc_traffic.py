@@ -16,7 +16,9 @@ CYCLES = {  # kernel name prefix -> shape tags in launch order within one block 
     "attn_kernel<1, 5, 3, 0, 0>": ["32x2048x1370x72", "32x2048x2048x72"],
     # --config decode (2048 primitives): one shape per kernel
     "conv3_s4c256_kernel<1, 0>": ["256->256 @4^3 x2048"],
-    "conv3_s8c256n32_kernel<1>": ["256->32 @8^3 x2048"],
+    "conv3_s8c256n32_kernel<1, 0>": ["256->32 @8^3 x2048"],
+    "conv3_s8c256n32_kernel<1, 1>": ["gn+256->32+sc @8^3 x2048"],
+    "convt_s4c256_kernel<1>": ["256->256 @4^3 x2048"],
 }
 
 
