@@ -163,7 +163,10 @@ __global__ __launch_bounds__(512) void conv3_s4c256_kernel(const typename T16<DT
     read_wf(0, 0);
 
     for (int q = 0; q < 4; ++q) {
-        if (q > 0) load_a(q);      // (every MFMA that reads the previous quarter has issued; the loads' latency is exposed)
+        // (every MFMA that reads the previous quarter has issued; the loads' latency is exposed.  Staging the next quarter
+        // through the spare 32 KB of LDS by LDS-DMA a few tiles ahead - coalesced, prefetched - measured 3 % SLOWER same-box:
+        // with four more DMAs in the in-order vmcnt queue the next counted waits stall longer than the exposed loads cost.)
+        if (q > 0) load_a(q);
         const int sq = (3 * q) & 3;
         // one tap column (dy, dx) = 3 tiles; a generic lambda over an integral constant, called nine times: the DPP controls
         // are immediates, so the column index must be a compile-time constant (a 9-way switch per fragment measured as

@@ -1,4 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for i in 1 2; do
 REPS=10 python tools/conv_bench.py
-PRIMX_CONV_PROF=1 REPS=2 python tools/conv_bench.py 2>&1 | tail -2
+PRIMX_LIB=$GRAFT_REPO_ROOT/3dtopia-xl_amd/csrc/libprimx_old.so REPS=10 python tools/conv_bench.py
+done
