@@ -48,6 +48,9 @@ constexpr int QPAD = 128;   // granularity of nq_pad (the Q operand buffers)
 constexpr int NW = 8;       // waves per workgroup: all of them share every K / V^T tile the workgroup stages
 constexpr int BQ = 32 * NW; // query rows per workgroup
 constexpr int BKV = 64;     // keys per tile
+#ifndef PRIMX_ATTN_LDS_EPI
+#define PRIMX_ATTN_LDS_EPI 1     // output tile transposed through LDS: 16-byte row-major stores
+#endif
 #ifndef PRIMX_ATTN_NSTAGE
 #define PRIMX_ATTN_NSTAGE 3
 #endif
@@ -575,8 +578,41 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     }
     const float inv = 1.0f / l_tot;
     const int q = q0 + wave * 32 + l31;
+    const int b = bh / H, h = bh - b * H;
+#if PRIMX_ATTN_LDS_EPI
+    // Row-major stores through LDS.  A lane owns one query row, so storing from the accumulators is 64 separate 8-byte
+    // requests per instruction (9 instructions per wave at dh = 72, every wave at once at the end of the kernel); each wave
+    // instead parks its 32 x dh tile in the idle ring (row stride DP + 8 halves) and walks it in 16-byte pieces, dh / 8
+    // consecutive lanes per output row.
+    if ((dh & 7) == 0) {
+        constexpr int OST = DP + 8;
+        static_assert(NW * 32 * OST <= NSTAGE * BUF, "output staging must fit the ring");
+        __syncthreads();                                  // every wave has left the ring
+        S* ost = smem + wave * (32 * OST);
+#pragma unroll
+        for (int t = 0; t < DTILES; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = t * 32 + 8 * g + 4 * hi;
+                if (d < dh) {
+                    V4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (S)(o[t][4 * g + e] * inv);
+                    *reinterpret_cast<V4*>(ost + l31 * OST + d) = v;
+                }
+            }
+        const int cpr = dh >> 3, npiece = 32 * cpr;       // 16-byte pieces per row / per wave tile
+        for (int p = lane; p < npiece; p += 64) {
+            const int row = p / cpr, c = p - row * cpr;
+            const int qr = q0 + wave * 32 + row;
+            if (qr < nq)
+                *reinterpret_cast<V8*>(out + ((int64_t)b * nq + qr) * ((int64_t)H * dh) + (int64_t)h * dh + 8 * c) =
+                    *reinterpret_cast<const V8*>(ost + row * OST + 8 * c);
+        }
+        return;
+    }
+#endif
     if (q < nq) {
-        const int b = bh / H, h = bh - b * H;
         S* orow = out + ((int64_t)b * nq + q) * ((int64_t)H * dh) + (int64_t)h * dh;
 #pragma unroll
         for (int t = 0; t < DTILES; ++t)
