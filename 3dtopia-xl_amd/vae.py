@@ -167,6 +167,7 @@ class VAE(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self.__dict__["_pack"] = {}
+        self.__dict__["_attn_ws"] = {}
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
@@ -274,9 +275,22 @@ class VAE(nn.Module):
         H = w["heads"]
         dh = Cc // H
         t = ops.groupnorm_silu(h, w["g"], w["b"], w["groups"], w["eps"], False)
-        Q = ops.alloc_heads(P, H, V, dh, HEADS_ROWS, h.dtype, h.device, ops.BQ, "q")
-        K = ops.alloc_heads(P, H, V, dh, HEADS_KROWS, h.dtype, h.device, ops.BQ, "k")
-        Vt = ops.alloc_heads(P, H, V, dh, HEADS_VT, h.dtype, h.device, ops.BQ)
+        # persistent zero-padded operand buffers (the kernels never write the pads, so they stay zero): three 67 MB zero fills
+        # per decode otherwise.  One entry per (P, dtype, device); bounded.
+        def alloc():
+            return (ops.alloc_heads(P, H, V, dh, HEADS_ROWS, h.dtype, h.device, ops.BQ, "q"),
+                    ops.alloc_heads(P, H, V, dh, HEADS_KROWS, h.dtype, h.device, ops.BQ, "k"),
+                    ops.alloc_heads(P, H, V, dh, HEADS_VT, h.dtype, h.device, ops.BQ))
+        if P <= 4096:                                      # (200 MB at P = 2048; larger one-off batches are not kept)
+            key = (P, H, V, dh, h.dtype, h.device)
+            ws = self.__dict__.setdefault("_attn_ws", {})
+            if key not in ws:
+                if len(ws) >= 2:
+                    ws.clear()
+                ws[key] = alloc()
+            Q, K, Vt = ws[key]
+        else:
+            Q, K, Vt = alloc()
         ops.linear_heads(t.view(P * V, Cc), w["w_qkv"], w["b_qkv"], V, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT],
                          [Q, K, Vt], Q.shape[2])
         att = ops.attention(Q, K, Vt, V, V, dh, dh ** -0.5)
