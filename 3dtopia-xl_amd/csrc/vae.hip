@@ -269,9 +269,50 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     }
 }
 
+// S = 4 (the shipped latent grid): no LDS at all.  A primitive's 64 latent values are wave-uniform, so they sit in registers
+// (scalar loads), the 64 x 27 tap loop is unrolled at compile time and the taps that fall into the zero padding are simply
+// not emitted (1000 of 1728 FMAs remain; fmaf(w, 0, acc) == acc, so the result is bit-identical to the padded loop above).
+// The LDS version spent its time ISSUING broadcast reads: 27 ds_read_b32 per output voxel and thread = 7k LDS
+// instructions per workgroup (94 us for 2048 primitives, against 67 MB of output).
+template <int DT>
+__global__ __launch_bounds__(256) void conv_in_s4_kernel(const float* __restrict__ z, float a, float b,
+                                                         const float* __restrict__ W, const float* __restrict__ bias,
+                                                         typename T16<DT>::S* __restrict__ out, int Cout) {
+    using St = typename T16<DT>::S;
+    const int64_t prim = blockIdx.x;
+    const int co = blockIdx.y * 256 + threadIdx.x;
+    if (co >= Cout) return;
+    float zv[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) zv[i] = a * z[prim * 64 + i] + b;
+    float w[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) w[t] = W[co * 27 + t];
+    const float bv = bias[co];
+    St* dst = out + prim * 64 * Cout + co;
+#pragma clang loop unroll(full)
+    for (int v = 0; v < 64; ++v) {
+        const int zc = v >> 4, yc = (v >> 2) & 3, xc = v & 3;
+        float acc = bv;
+#pragma clang loop unroll(full)
+        for (int t = 0; t < 27; ++t) {
+            const int zz = zc + t / 9 - 1, yy = yc + (t / 3) % 3 - 1, xx = xc + t % 3 - 1;
+            if (zz >= 0 && zz < 4 && yy >= 0 && yy < 4 && xx >= 0 && xx < 4) acc = fmaf(w[t], zv[(zz * 4 + yy) * 4 + xx], acc);
+        }
+        dst[(int64_t)v * Cout] = (St)acc;
+    }
+}
+
 extern "C" int primx_conv_in(const float* in, float pq_scale, float pq_bias, const float* W, const float* bias,
                              void* out, int P, int S, int Cout, int dtype, void* stream) {
     PRIMX_REQUIRE(in && W && bias && out && P > 0 && S > 0 && S <= 30 && Cout > 0, "primx_conv_in: bad argument");
+    if (S == 4) {
+        PRIMX_DISPATCH_16(dtype, "primx_conv_in",
+                          hipLaunchKernelGGL((conv_in_s4_kernel<DT>), dim3(P, (Cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, in,
+                                             pq_scale, pq_bias, W, bias, (typename T16<DT>::S*)out, Cout));
+        PRIMX_CHECK_LAUNCH("primx_conv_in");
+        return PRIMX_OK;
+    }
     const size_t lds = (size_t)(S + 2) * (S + 2) * (S + 2) * sizeof(float);
     PRIMX_DISPATCH_16(dtype, "primx_conv_in",
                       hipLaunchKernelGGL((conv_in_kernel<DT>), dim3(P), dim3(256), lds, (hipStream_t)stream, in,
