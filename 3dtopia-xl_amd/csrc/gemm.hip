@@ -70,6 +70,7 @@ struct GemmArgs {
     // EPI_HEADS
     int heads, dh, DP, n_pad, n_seg;
     int kind[3];
+    int xcd_gm;  // 256x288 kernel: workgroups of one XCD form an (mt / xcd_gm) x (nt / (8 / xcd_gm)) block of tiles (0 / 8: whole tile rows)
     int prof;  // PRIMX_GEMM_PROF=1: per-workgroup timeline stamps into g_gemm_prof (128x144 LDS-DMA kernel only)
     S* dst[3];
     float scale0;
@@ -114,6 +115,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int xcd = bid & 7, local = bid >> 3;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + local;
+}
+
+// 2-D variant: the 8 XCDs (private L2s) tile the grid of output tiles gm x (8 / gm); inside its block an XCD walks n fastest.
+// With whole tile rows per XCD (gm = 8) every XCD streams the WHOLE weight matrix through its L2: fc1 at T = 4096 fetched
+// 93 MB per launch for 20 MB of operands (PMC: A 9.4 + 8 x W 10.6); a 2 x 4 / 4 x 2 split replicates both operands a
+// little instead of one of them eightfold.  Host picks gm (launch144_dma); needs mt % gm == 0 and nt % (8 / gm) == 0.
+__device__ __forceinline__ void xcd_tile2d(int bid, int mt, int nt, int gm, int& mi, int& ni) {
+    const int gn = 8 / gm, bm = mt / gm, bn = nt / gn;
+    const int x = bid & 7, local = bid >> 3;
+    const int lm = local / bn, ln = local - lm * bn;
+    mi = (x / gn) * bm + lm;
+    ni = (x - (x / gn) * gn) * bn + ln;
 }
 
 // byte-free LDS addressing in halves: row-major 64-half rows, 16-byte chunks XOR-swizzled
@@ -1229,8 +1242,15 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
     const int lr = lane & 15, lg = lane >> 4;
 
     const int nt = p.N / BN, mt = (p.M + BM - 1) / BM;
-    const int id = xcd_remap(blockIdx.x, nt * mt);
-    const int m0 = (id / nt) * BM, n0 = (id % nt) * BN;
+    int mi_t, ni_t;
+    if (p.xcd_gm > 0 && p.xcd_gm < 8) {
+        xcd_tile2d(blockIdx.x, mt, nt, p.xcd_gm, mi_t, ni_t);
+    } else {
+        const int id = xcd_remap(blockIdx.x, nt * mt);
+        mi_t = id / nt;
+        ni_t = id - mi_t * nt;
+    }
+    const int m0 = mi_t * BM, n0 = ni_t * BN;
 
     const S* gp[NSLOT];
 #pragma unroll
@@ -1494,6 +1514,11 @@ static const int g_big_heads_min = [] {   // fewest 256x288 workgroups for which
     return e ? atoi(e) : 160;
 }();
 
+static const bool g_xcd2d = [] {   // PRIMX_GEMM_XCD2D=0: whole tile rows per XCD in the 256x288 kernel (A/B measurements)
+    const char* e = getenv("PRIMX_GEMM_XCD2D");
+    return !(e && e[0] == '0');
+}();
+
 static const int g_gemm_prof_mode = [] {   // PRIMX_GEMM_PROF=1: synchronous launches + timeline print; 2: without MFMAs and
     const char* e = getenv("PRIMX_GEMM_PROF");   // fragment reads (DMA-only bound probe); 3: without MFMAs
     return e ? atoi(e) : 0;
@@ -1503,6 +1528,18 @@ static const bool g_gemm_prof_on = g_gemm_prof_mode != 0;
 template <int DT, int EPI, int BIG = 0>
 void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     const dim3 grid(BIG ? ((a.M + 255) / 256) * (a.N / 288) : mt * (a.N / 144));
+    GemmArgs<DT> a2 = a;
+    if (BIG && g_xcd2d) {
+        // XCD block shape: minimise (A bytes x column groups + W bytes x row groups) over the splits the tile grid allows
+        const int mtb = (a.M + 255) / 256, ntb = a.N / 288;
+        double best = 1e300;
+        for (int gm = 1; gm <= 8; gm *= 2) {
+            const int gn = 8 / gm;
+            if (mtb % gm || ntb % gn) continue;
+            const double cost = (double)a.M * gn + (double)a.N * gm;      // x K x 2 bytes each
+            if (cost < best) { best = cost; a2.xcd_gm = gm; }
+        }
+    }
     auto go = [&](const GemmArgs<DT>& x) {
         if (BIG && g_big_q && x.K % 32 == 0) hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
         else if (BIG) hipLaunchKernelGGL((gemm288_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
@@ -1510,10 +1547,10 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
         else hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI, 0>), grid, dim3(512), 0, st, x);
     };
     if (!g_gemm_prof_on) {
-        go(a);
+        go(a2);
         return;
     }
-    GemmArgs<DT> b = a;
+    GemmArgs<DT> b = a2;
     b.prof = g_gemm_prof_mode;
     unsigned long long z[12] = {~0ull, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, r[12];
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof(z));
