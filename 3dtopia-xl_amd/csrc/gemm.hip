@@ -284,19 +284,26 @@ __device__ __forceinline__ typename T16<DT>::V4 linear_out4(const GemmArgs<DT>& 
     float y[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) y[j] = rnd16<DT>(a[j] + (p.bias ? (float)bv[j] : 0.f));
+    // The activation's own rounding is folded into the final conversion when no scale follows (rounding twice to the
+    // same type is the identity), and the scale is a real uniform branch: if-converted it cost every element a
+    // multiply, two conversions and a select on top of the ~13 issue slots of the activation itself (the fc1 epilogue
+    // is bound by exactly this arithmetic: DESIGN.md section 4).
     if (p.act == PRIMX_ACT_GELU_TANH) {          // one uniform branch per four elements (see PRIMX_APPLY_ACT)
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = rnd16<DT>(gelu_tanh_f(y[j]));
+        for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(y[j]);
     } else if (p.act == PRIMX_ACT_GELU_ERF) {
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = rnd16<DT>(gelu_erf_f(y[j]));
+        for (int j = 0; j < 4; ++j) y[j] = gelu_erf_f(y[j]);
     }
+    if (p.out_scale != 1.0f) {
+        asm volatile("" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (p.out_scale != 1.0f) y[j] = rnd16<DT>(p.out_scale * y[j]);
-        o[j] = (S)y[j];
+        for (int j = 0; j < 4; ++j) o[j] = (S)(p.out_scale * rnd16<DT>(y[j]));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (S)y[j];
     }
     return o;
 }
@@ -1374,6 +1381,10 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
         __syncthreads();   // every wave is done with the operand stages
         if (!vt_tile) {
             // acc[i][j][r] = C[wm*64 + i*16 + lr][wn*144 + j*16 + 4*lg + r]
+            // (`scaled` is a compile-time flag under a uniform branch: if-converted, the q scale cost every element of
+            // every segment a multiply, two conversions and a select)
+            auto park = [&](auto scaled_t) {
+            constexpr bool scaled = decltype(scaled_t)::value;
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 V4e bv = V4e{};
@@ -1383,13 +1394,15 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
                     V4e o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float y = rnd16<DT>(acc[i][j][r] + (float)bv[r]);
-                        if (sc != 1.0f) y = rnd16<DT>(sc * y);
-                        o[r] = (S)y;
+                        const float y = acc[i][j][r] + (float)bv[r];
+                        o[r] = scaled ? (S)(sc * rnd16<DT>(y)) : (S)y;
                     }
                     *reinterpret_cast<V4e*>(smem + (wm * 64 + i * 16 + lr) * RS_ROWS + wn * 144 + j * 16 + 4 * lg) = o;
                 }
             }
+            };
+            if (sc != 1.0f) { asm volatile("" ::: "memory"); park(std::true_type{}); }
+            else park(std::false_type{});
             __syncthreads();
             const int rs = heads_row_stride(kind, p.DP);
 #pragma unroll 6
@@ -1405,6 +1418,8 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
             }
         } else {
             // acc[i][j][r] = C[wm*64 + i*16 + 4*lg + r][wn*144 + j*16 + lr]  ->  staged transposed [column][token]
+            auto park = [&](auto scaled_t) {
+            constexpr bool scaled = decltype(scaled_t)::value;
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const float bj = p.bias ? (float)p.bias[n0 + wn * 144 + j * 16 + lr] : 0.f;
@@ -1413,13 +1428,15 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
                     V4e o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float y = rnd16<DT>(acc[i][j][r] + bj);
-                        if (sc != 1.0f) y = rnd16<DT>(sc * y);
-                        o[r] = (S)y;
+                        const float y = acc[i][j][r] + bj;
+                        o[r] = scaled ? (S)(sc * rnd16<DT>(y)) : (S)y;
                     }
                     *reinterpret_cast<V4e*>(smem + (wn * 144 + j * 16 + lr) * RS_VT + wm * 64 + i * 16 + 4 * lg) = o;
                 }
             }
+            };
+            if (sc != 1.0f) { asm volatile("" ::: "memory"); park(std::true_type{}); }
+            else park(std::false_type{});
             __syncthreads();
 #pragma unroll 3
             for (int it = 0; it < (BN * (BM / 16)) / 512; ++it) {     // 4608 (column, 16-token) units / 512 threads = 9

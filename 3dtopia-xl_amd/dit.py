@@ -137,7 +137,7 @@ class DiT(nn.Module):
         self._pack: Dict = {}
         self._heads_ws: Dict = {}
         self._cond: Optional[Dict] = None
-        self._packed_only = False   # set on ranks that received the packed blob instead of the fp32 parameters
+        self._packed_only = False   # set when only the packed blob was received / loaded, not the fp32 parameters
         # Opt-in exact-algebra shortcut: to_k(y) / to_v(y) do not depend on the timestep
         # (models/attention.py:106-107), so with this flag the K / V projections of all blocks are computed once per
         # conditioning tensor and reused across DDIM steps.  Off by default: a step then executes the reference's full
@@ -229,38 +229,150 @@ class DiT(nn.Module):
         if key in self._pack:
             return self._pack[key]
         if self._packed_only:
-            raise RuntimeError(f"this rank holds only a broadcast packed blob, and not for ({dtype}, {dev})")
+            raise RuntimeError(f"this module holds only packed 16-bit weights (broadcast_packed_ / pack_from_state_dict / "
+                               f"load_packed), and not for ({dtype}, {dev}): the fp32 parameters were never loaded")
         pk = self.packed_alloc(dtype, dev)
+        self._fill_pack(pk, lambda prm: prm)
+        return pk
+
+    def _fill_pack(self, pk: Dict, src) -> None:
+        """Fill the blob's operand views; `src(parameter)` returns the tensor holding that parameter's values (the
+        parameter itself, or the checkpoint's entry of the same name).  The cast to the blob's dtype happens in the copy."""
         D = self.hidden_size
         with torch.no_grad():
             for i, blk in enumerate(self.blocks):
                 ca, sa, mlp, w = blk.crossattn, blk.attn, blk.mlp, pk["blocks"][i]
                 for name, lin in (("q", ca.to_q), ("cproj", ca.proj), ("qkv", sa.qkv), ("proj", sa.proj), ("fc1", mlp.fc1),
                                   ("fc2", mlp.fc2)):
-                    w["w_" + name].copy_(lin.weight)                     # fp32 -> 16-bit cast in the copy
+                    w["w_" + name].copy_(src(lin.weight))
                     if w["b_" + name] is not None:
-                        w["b_" + name].copy_(lin.bias)
-                pk["w_kv_all"][i * 2 * D:i * 2 * D + D].copy_(ca.to_k.weight)
-                pk["w_kv_all"][i * 2 * D + D:(i + 1) * 2 * D].copy_(ca.to_v.weight)
-                pk["b_kv_all"][i * 2 * D:i * 2 * D + D].copy_(ca.to_k.bias)
-                pk["b_kv_all"][i * 2 * D + D:(i + 1) * 2 * D].copy_(ca.to_v.bias)
-                pk["w_ada"][i * 9 * D:(i + 1) * 9 * D].copy_(blk.adaLN_modulation[1].weight)
-                pk["b_ada"][i * 9 * D:(i + 1) * 9 * D].copy_(blk.adaLN_modulation[1].bias)
+                        w["b_" + name].copy_(src(lin.bias))
+                pk["w_kv_all"][i * 2 * D:i * 2 * D + D].copy_(src(ca.to_k.weight))
+                pk["w_kv_all"][i * 2 * D + D:(i + 1) * 2 * D].copy_(src(ca.to_v.weight))
+                pk["b_kv_all"][i * 2 * D:i * 2 * D + D].copy_(src(ca.to_k.bias))
+                pk["b_kv_all"][i * 2 * D + D:(i + 1) * 2 * D].copy_(src(ca.to_v.bias))
+                pk["w_ada"][i * 9 * D:(i + 1) * 9 * D].copy_(src(blk.adaLN_modulation[1].weight))
+                pk["b_ada"][i * 9 * D:(i + 1) * 9 * D].copy_(src(blk.adaLN_modulation[1].bias))
             base = self.depth * 9 * D
-            pk["w_ada"][base:].copy_(self.final_layer.adaLN_modulation[1].weight)
-            pk["b_ada"][base:].copy_(self.final_layer.adaLN_modulation[1].bias)
-            pk["w_final"].copy_(self.final_layer.linear.weight)
-            pk["b_final"].copy_(self.final_layer.linear.bias)
+            pk["w_ada"][base:].copy_(src(self.final_layer.adaLN_modulation[1].weight))
+            pk["b_ada"][base:].copy_(src(self.final_layer.adaLN_modulation[1].bias))
+            pk["w_final"].copy_(src(self.final_layer.linear.weight))
+            pk["b_final"].copy_(src(self.final_layer.linear.bias))
+
+    # ---- checkpoint -> packed blob without the fp32 round trip (SURVEY.md section 8f, N4).  The reference loads its fp16
+    # `.pt` into fp32 parameters (inference.py:257-259: 3.6 GB) and autocast re-casts them on every use; here the
+    # checkpoint's tensors are copied straight into the 16-bit blob the kernels read, and the blob can be written to /
+    # mapped from ONE flat file so that a later start is a single host-to-device copy of 1.82 GB.
+    def pack_from_state_dict(self, state_dict: Dict, dtype: torch.dtype, device=None) -> Dict:
+        """Strict like `load_state_dict(strict=True)`: every parameter name must be present with its shape, nothing else.
+        The large matrices go only into the blob (this module becomes packed-only: its fp32 route raises); the few
+        fp32 tensors used outside autocast (embedders, null conditioning row) are loaded into their parameters."""
+        names = {id(prm): n for n, prm in self.named_parameters()}
+        missing = [n for n in names.values() if n not in state_dict]
+        extra = [k for k in state_dict if k not in set(names.values())]
+        if missing or extra:
+            raise RuntimeError(f"pack_from_state_dict: missing keys {missing[:4]}{'...' if len(missing) > 4 else ''}, "
+                               f"unexpected keys {extra[:4]}{'...' if len(extra) > 4 else ''}")
+        for prm in self.parameters():
+            if tuple(state_dict[names[id(prm)]].shape) != tuple(prm.shape):
+                raise RuntimeError(f"pack_from_state_dict: shape mismatch for {names[id(prm)]}: checkpoint "
+                                   f"{tuple(state_dict[names[id(prm)]].shape)}, model {tuple(prm.shape)}")
+        self.repack()
+        pk = self.packed_alloc(dtype, device)
+        self._fill_pack(pk, lambda prm: state_dict[names[id(prm)]])
+        with torch.no_grad():
+            for t, prm in zip(self.small_fp32_tensors(), self._small_fp32_params()):
+                t.copy_(state_dict[names[id(prm)]])
+        self._packed_only = True
         return pk
+
+    PACKED_MAGIC = b"PRIMXPK1"
+    _PACKED_FILE_ALIGN = 4096
+
+    def _hyper(self) -> Dict:
+        proj_bias = self.depth > 0 and self.blocks[0].attn.proj.bias is not None
+        return {"seq_length": self.seq_length, "in_channels": self.in_channels, "condition_channels": self.condition_channels,
+                "hidden_size": self.hidden_size, "depth": self.depth, "num_heads": self.num_heads,
+                "mlp_hidden": self.blocks[0].mlp.fc1.out_features if self.depth else 0, "attn_proj_bias": bool(proj_bias),
+                "cond_drop_prob_positive": self.cond_drop_prob > 0, "out_channels": self.out_channels}
+
+    def save_packed(self, path: str, dtype: torch.dtype) -> int:
+        """Write the packed blob + the small fp32 tensors as ONE flat file:
+        magic (8 bytes) | header length (u64 LE) | JSON header | zero pad to 4096 | blob | zero pad | fp32 tensors.
+        The header records the hyper-parameters the blob layout is derived from; `load_packed` refuses a mismatch.
+        Returns the file size."""
+        import json
+        pk = self.packed(dtype)
+        flat = pk["_flat"].detach().cpu().contiguous()
+        small = [t.detach().cpu().float().contiguous() for t in self.small_fp32_tensors()]
+        al = self._PACKED_FILE_ALIGN
+        head = {"format": 1, "dtype": str(dtype).replace("torch.", ""), "hyper": self._hyper(), "pack_align": self._PACK_ALIGN,
+                "blob_elements": flat.numel(),
+                "small_fp32": [list(t.shape) for t in small]}
+        hj = json.dumps(head, sort_keys=True).encode()
+        blob_off = ops.round_up(16 + len(hj), al)
+        blob_bytes = flat.numel() * flat.element_size()
+        small_off = ops.round_up(blob_off + blob_bytes, al)
+        with open(path, "wb") as f:
+            f.write(self.PACKED_MAGIC)
+            f.write(len(hj).to_bytes(8, "little"))
+            f.write(hj)
+            f.write(b"\0" * (blob_off - 16 - len(hj)))
+            raw = flat.view(torch.int16).numpy()
+            for lo in range(0, raw.size, 1 << 25):      # 64 MiB pieces: no second 1.82 GB bytes object
+                f.write(raw[lo:lo + (1 << 25)].tobytes())
+            f.write(b"\0" * (small_off - blob_off - blob_bytes))
+            for t in small:
+                f.write(t.numpy().tobytes())
+            return f.tell()
+
+    def load_packed(self, path: str, device=None) -> Dict:
+        """Map a `save_packed` file and copy it into a freshly allocated blob on `device` (one host-to-device copy straight
+        from the page cache: no fp32 parameters, no per-layer casts).  This module becomes packed-only."""
+        import json
+        import os
+        with open(path, "rb") as f:
+            if f.read(8) != self.PACKED_MAGIC:
+                raise RuntimeError(f"{path}: not a packed PrimX DiT file")
+            hlen = int.from_bytes(f.read(8), "little")
+            head = json.loads(f.read(hlen).decode())
+        if head.get("format") != 1 or head.get("hyper") != self._hyper() or head.get("pack_align") != self._PACK_ALIGN:
+            raise RuntimeError(f"{path}: packed for a different model ({head.get('hyper')}) than this one ({self._hyper()})")
+        dtype = {"float16": torch.float16, "bfloat16": torch.bfloat16}[head["dtype"]]
+        self.repack()
+        pk = self.packed_alloc(dtype, device)
+        flat = pk["_flat"]
+        if flat.numel() != head["blob_elements"]:
+            raise RuntimeError(f"{path}: blob has {head['blob_elements']} elements, this model's layout {flat.numel()}")
+        al = self._PACKED_FILE_ALIGN
+        blob_off = ops.round_up(16 + hlen, al)
+        blob_bytes = flat.numel() * flat.element_size()
+        small_off = ops.round_up(blob_off + blob_bytes, al)
+        mm = torch.from_file(path, shared=False, size=os.path.getsize(path), dtype=torch.uint8)   # private mapping of the file
+        with torch.no_grad():
+            flat.view(torch.int16).copy_(mm[blob_off:blob_off + blob_bytes].view(torch.int16))
+            off = small_off
+            for t, shp in zip(self.small_fp32_tensors(), head["small_fp32"]):
+                if list(t.shape) != shp:
+                    raise RuntimeError(f"{path}: fp32 tensor of shape {shp} does not fit {list(t.shape)}")
+                n = t.numel()
+                t.copy_(mm[off:off + 4 * n].view(torch.float32).view(shp))
+                off += 4 * n
+        del mm
+        self._packed_only = True
+        return pk
+
+    def _small_fp32_params(self):
+        ps = [self.x_embedder.weight, self.x_embedder.bias, self.t_embedder.mlp[0].weight, self.t_embedder.mlp[0].bias,
+              self.t_embedder.mlp[2].weight, self.t_embedder.mlp[2].bias]
+        if self.cond_drop_prob > 0:
+            ps.append(self.null_cond_embedding)
+        return ps
 
     def small_fp32_tensors(self):
         """The fp32 parameters the 16-bit path reads directly (embedders outside autocast, dit_crossattn.py:191-192, and
         the null conditioning row): what travels next to the packed blob in a broadcast."""
-        ts = [self.x_embedder.weight, self.x_embedder.bias, self.t_embedder.mlp[0].weight, self.t_embedder.mlp[0].bias,
-              self.t_embedder.mlp[2].weight, self.t_embedder.mlp[2].bias]
-        if self.cond_drop_prob > 0:
-            ts.append(self.null_cond_embedding)
-        return [t.data for t in ts]
+        return [t.data for t in self._small_fp32_params()]
 
     def _heads(self, tag: str, B: int, n: int, kind: int, dtype, device, pad_to: int) -> torch.Tensor:
         """Persistent zero-padded attention operand buffers (pads are never written, so they stay zero)."""
@@ -411,8 +523,9 @@ class DiT(nn.Module):
         """The reference with autocast off: every Linear, the attention core, LayerNorm, modulate, GELU and the gated
         residuals in fp32 (dit_crossattn.py:184-202 with enable_amp=False).  Reads the fp32 parameters directly."""
         if self._packed_only:
-            raise RuntimeError("this rank received only the packed 16-bit weights (sharding.broadcast_packed_): the fp32 "
-                               "route needs the fp32 parameters - use broadcast_module_")
+            raise RuntimeError("this module holds only packed 16-bit weights (sharding.broadcast_packed_ / pack_from_state_dict "
+                               "/ load_packed): the fp32 route needs the fp32 parameters - use broadcast_module_ / "
+                               "load_state_dict")
         Be, N, Cin = x.shape
         L, Dc = y.shape[1], y.shape[2]
         D, H = self.hidden_size, self.num_heads

@@ -53,12 +53,22 @@ def latents_to_primitives(samples: torch.Tensor, vae, latent_mean: Optional[Sequ
 # On-disk formats of the hot path: the two checkpoints the CLI loads and the `denoised.pt`
 # it writes between sampling and mesh extraction.
 def load_checkpoints(model=None, vae=None, dit_checkpoint_path: Optional[str] = None,
-                     vae_checkpoint_path: Optional[str] = None) -> None:
+                     vae_checkpoint_path: Optional[str] = None, packed_dtype: Optional[torch.dtype] = None) -> None:
     """`model.load_state_dict(torch.load(p)['ema'])` / `vae.load_state_dict(torch.load(p)['model_state_dict'])`, strict,
     as inference.py:257-262 does (fp16 `.pt` files load into the fp32 parameters; the packed 16-bit copies the kernels
-    read are rebuilt lazily on the first forward)."""
+    read are rebuilt lazily on the first forward).
+
+    `packed_dtype` (torch.float16 / torch.bfloat16) takes the direct route for the DiT instead: the checkpoint is memory-
+    mapped and its tensors are copied straight into the packed 16-bit blob on the model's device (`DiT.pack_from_state_dict`)
+    - no 3.6 GB of fp32 parameters, no repack on the first forward; the model is then packed-only (its fp32 route raises).
+    A path ending in `.primxpk` is a `DiT.save_packed` file and is mapped as is (`DiT.load_packed`)."""
     if model is not None and dit_checkpoint_path:
-        model.load_state_dict(torch.load(dit_checkpoint_path, map_location="cpu")["ema"], strict=True)
+        if dit_checkpoint_path.endswith(".primxpk"):
+            model.load_packed(dit_checkpoint_path)
+        elif packed_dtype is not None:
+            model.pack_from_state_dict(torch.load(dit_checkpoint_path, map_location="cpu", mmap=True)["ema"], packed_dtype)
+        else:
+            model.load_state_dict(torch.load(dit_checkpoint_path, map_location="cpu")["ema"], strict=True)
     if vae is not None and vae_checkpoint_path:
         vae.load_state_dict(torch.load(vae_checkpoint_path, map_location="cpu")["model_state_dict"], strict=True)
 

@@ -112,6 +112,28 @@ def test_repack_after_weight_update(pkg):
     assert rel_l2(a, b) > 1e-3
 
 
+def test_packed_only_model_from_checkpoint_and_from_packed_file(pkg, tmp_path):
+    """N4: fp16 checkpoint -> packed blob (no fp32 parameters) and the mapped `.primxpk` file run the same kernels on the same
+    bytes as the reference's load_state_dict route: outputs are bit-identical; the fp32 route refuses on such a model."""
+    name, sd, heads, m, x, y, t = _case(pkg, 0)
+    cfg = DIT_CASES[0][1]
+    N = DIT_CASES[0][3]
+    sd16 = {k: v.half() for k, v in sd.items()}
+    m.load_state_dict(sd16)
+    want = m.forward_with_cfg(x.to(DEV), t.to(DEV), y.to(DEV), 6.0, torch.float16, True).clone()
+    direct = pkg.DiT(seq_length=N, num_heads=heads, attn_proj_bias=True, cond_drop_prob=0.1, **cfg).eval().to(DEV)
+    direct.pack_from_state_dict(sd16, torch.float16)
+    assert torch.equal(direct.forward_with_cfg(x.to(DEV), t.to(DEV), y.to(DEV), 6.0, torch.float16, True), want)
+    with pytest.raises(RuntimeError, match="packed"):
+        direct(x.to(DEV), t.to(DEV), y.to(DEV), torch.float32, False)
+    path = str(tmp_path / "dit.primxpk")
+    m.save_packed(path, torch.float16)
+    mapped = pkg.DiT(seq_length=N, num_heads=heads, attn_proj_bias=True, cond_drop_prob=0.1, **cfg).eval().to(DEV)
+    mapped.load_packed(path)
+    assert mapped.packed(torch.float16)["_flat"].is_cuda
+    assert torch.equal(mapped.forward_with_cfg(x.to(DEV), t.to(DEV), y.to(DEV), 6.0, torch.float16, True), want)
+
+
 def test_full_width_block_at_baseline_shape(pkg):
     """BASELINE configs[1] shapes on ONE block: d=1152, 16 heads x 72, N_prim=2048, 1370 x 768 condition tokens, CFG 6
     (effective batch 2) - the exact GEMM tiles (128x144 LDS-DMA kernel, K = 1152 / 4608 / 768), the 2048 x 2048 and

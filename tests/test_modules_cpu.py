@@ -88,3 +88,86 @@ def test_denoised_pt_round_trip(tmp_path):
                    cond_drop_prob=0.1, attn_proj_bias=True)
     pipeline.load_checkpoints(model=dit2, dit_checkpoint_path=str(ck))
     assert all(torch.equal(a.half(), b.half()) for a, b in zip(dit.state_dict().values(), dit2.state_dict().values()))
+
+
+# ---- checkpoint -> packed 16-bit blob: host-side logic, runs on CPU tensors
+_SMALL_DIT = dict(seq_length=16, in_channels=8, condition_channels=24, hidden_size=64, depth=2, num_heads=4, cond_drop_prob=0.1,
+                  attn_proj_bias=True)
+
+
+def _fp16_checkpoint(pkg):
+    torch.manual_seed(SEED)
+    m = pkg.DiT(**_SMALL_DIT)
+    for prm in m.parameters():
+        prm.data.normal_()
+    return {k: v.half() for k, v in m.state_dict().items()}
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_packed_blob_straight_from_the_checkpoint_equals_the_repacked_parameters(pkg, dtype):
+    sd = _fp16_checkpoint(pkg)
+    a = pkg.DiT(**_SMALL_DIT)
+    a.load_state_dict(sd, strict=True)                       # the reference's route: fp16 file -> fp32 parameters -> 16-bit
+    b = pkg.DiT(**_SMALL_DIT)
+    pb = b.pack_from_state_dict(sd, dtype)
+    assert torch.equal(a.packed(dtype)["_flat"].view(torch.int16), pb["_flat"].view(torch.int16))
+    for x, y in zip(a.small_fp32_tensors(), b.small_fp32_tensors()):
+        assert torch.equal(x, y)
+    assert b._packed_only
+    with pytest.raises(RuntimeError, match="packed"):       # another dtype would need the fp32 parameters it never loaded
+        b.packed(torch.bfloat16 if dtype == torch.float16 else torch.float16)
+
+
+def test_pack_from_state_dict_is_strict(pkg):
+    sd = _fp16_checkpoint(pkg)
+    short = dict(sd)
+    short.pop("blocks.0.mlp.fc1.bias")
+    with pytest.raises(RuntimeError, match="missing keys"):
+        pkg.DiT(**_SMALL_DIT).pack_from_state_dict(short, torch.float16)
+    with pytest.raises(RuntimeError, match="unexpected keys"):
+        pkg.DiT(**_SMALL_DIT).pack_from_state_dict({**sd, "pos_embed": torch.zeros(1)}, torch.float16)
+    bad = dict(sd)
+    bad["blocks.1.attn.qkv.weight"] = bad["blocks.1.attn.qkv.weight"][:-1]
+    with pytest.raises(RuntimeError, match="shape mismatch"):
+        pkg.DiT(**_SMALL_DIT).pack_from_state_dict(bad, torch.float16)
+
+
+def test_packed_file_round_trip_and_layout_check(pkg, tmp_path):
+    sd = _fp16_checkpoint(pkg)
+    a = pkg.DiT(**_SMALL_DIT)
+    a.load_state_dict(sd)
+    path = str(tmp_path / "dit.primxpk")
+    size = a.save_packed(path, torch.float16)
+    assert size == os.path.getsize(path)
+    with open(path, "rb") as f:
+        assert f.read(8) == b"PRIMXPK1"
+    c = pkg.DiT(**_SMALL_DIT)
+    pc = c.load_packed(path)
+    assert torch.equal(a.packed(torch.float16)["_flat"].view(torch.int16), pc["_flat"].view(torch.int16))
+    for x, y in zip(a.small_fp32_tensors(), c.small_fp32_tensors()):
+        assert torch.equal(x, y)
+    with pytest.raises(RuntimeError, match="different model"):
+        pkg.DiT(**{**_SMALL_DIT, "depth": 3}).load_packed(path)
+    with pytest.raises(RuntimeError, match="not a packed"):
+        bogus = str(tmp_path / "x.primxpk")
+        open(bogus, "wb").write(b"\0" * 64)
+        pkg.DiT(**_SMALL_DIT).load_packed(bogus)
+
+
+def test_load_checkpoints_takes_the_packed_routes(pkg, tmp_path):
+    from importlib import import_module
+    pipeline = import_module(pkg.__name__ + ".pipeline")
+    sd = _fp16_checkpoint(pkg)
+    pt = str(tmp_path / "model_sview_dit_fp16.pt")
+    torch.save({"ema": sd}, pt)
+    ref = pkg.DiT(**_SMALL_DIT)
+    pipeline.load_checkpoints(model=ref, dit_checkpoint_path=pt)                                  # inference.py:257-259
+    direct = pkg.DiT(**_SMALL_DIT)
+    pipeline.load_checkpoints(model=direct, dit_checkpoint_path=pt, packed_dtype=torch.float16)
+    want = ref.packed(torch.float16)["_flat"].view(torch.int16)
+    assert torch.equal(want, direct._pack[(torch.float16, torch.device("cpu"))]["_flat"].view(torch.int16))
+    pk_path = str(tmp_path / "dit.primxpk")
+    ref.save_packed(pk_path, torch.float16)
+    mapped = pkg.DiT(**_SMALL_DIT)
+    pipeline.load_checkpoints(model=mapped, dit_checkpoint_path=pk_path)
+    assert torch.equal(want, mapped._pack[(torch.float16, torch.device("cpu"))]["_flat"].view(torch.int16))
