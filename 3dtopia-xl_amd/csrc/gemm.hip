@@ -71,7 +71,6 @@ struct GemmArgs {
     int heads, dh, DP, n_pad, n_seg;
     int kind[3];
     int xcd_gm;  // 256x288 kernel: workgroups of one XCD form an (mt / xcd_gm) x (nt / (8 / xcd_gm)) block of tiles (0 / 8: whole tile rows)
-    int clamp_tail;  // PRIMX_GEMM_TAILDMA=1: the LDS-DMA rings keep issuing (redundant, clamped) tile fetches in the last steps (A/B)
     int prof;  // PRIMX_GEMM_PROF=1: per-workgroup timeline stamps into g_gemm_prof (128x144 LDS-DMA kernel only)
     S* dst[3];
     float scale0;
@@ -850,14 +849,10 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     auto step = [&](int kt, const V8 (&ac)[MI], const V8 (&bc)[NI], V8 (&an)[MI], V8 (&bn)[NI]) {
         // vmcnt(4): tile kt+1 landed for this wave (tile kt+2 may stay in flight); lgkmcnt(0): this wave's reads of
         // tile kt's stage have completed, so after the barrier that stage can be overwritten by the DMA below
-        // The last steps have nothing left to fetch: they issue no DMA (a clamped re-fetch of the last tile there was 3 of
-        // K/64 + 3 tile fetches on a loop that is bound by exactly this path) and, with no newer tile in flight, wait for
-        // everything outstanding.
-        if (kt + 2 < nk || p.clamp_tail) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // (Spreading these DMA issues between the MFMA groups, which pays in the 256x288 kernel, measured worse here:
         // main loop 78.2k -> 81.8k cycles at K = 4608.)
-        if (kt + 3 < nk || p.clamp_tail) issue(min(kt + 3, nk - 1), st_cur);
+        issue(min(kt + 3, nk - 1), st_cur);
         if (p.prof != 2) read_frags(st_next, an, bn);   // prof == 2 / 3: DMA-only / DMA + LDS reads (bound probes, results wrong)
         if (p.prof < 2) multiply(ac, bc);
         st_cur = st_next;
@@ -1322,15 +1317,12 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
     for (int ks = 0; ks < nks; ++ks) {
         // slice ks+2 may stay in flight (4..5 DMAs per wave): <= 4 outstanding means slices ks and ks+1 have landed;
         // lgkmcnt(0): this wave's reads of slice ks-1 (and its prefetch of slice ks) are done
-        // (the last NST - 1 iterations fetch nothing: see gemm144_dma_kernel)
-        if (ks + 2 < nks || p.clamp_tail) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const S* base = smem + st * STAGE;
         const int st_next = (st == NST - 1) ? 0 : st + 1;
         const S* base_n = smem + st_next * STAGE;
         const int st_fill = (st == 0) ? NST - 1 : st - 1;                // stage of slice ks-1
         const int ks_fill = min(ks + NST - 1, nks - 1);
-        const bool fill = ks + NST - 1 < nks || p.clamp_tail;            // uniform
         V8 a[MI], b[NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) a[i] = a_n[i];
@@ -1341,7 +1333,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
         // operands swapped: accumulator = C^T (see the epilogue); the DMAs of slice ks+3 go out between the MFMA groups
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            if (j < NSLOT && fill) issue_one(ks_fill, st_fill, j);
+            if (j < NSLOT) issue_one(ks_fill, st_fill, j);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
                 acc[i][j] = SW ? T16<DT>::mfma16(b[j], a[i], acc[i][j]) : T16<DT>::mfma16(a[i], b[j], acc[i][j]);
@@ -1544,11 +1536,6 @@ static const bool g_xcd2d = [] {   // PRIMX_GEMM_XCD2D=0: whole tile rows per XC
     return !(e && e[0] == '0');
 }();
 
-static const bool g_clamp_tail = [] {   // PRIMX_GEMM_TAILDMA=1: redundant tail fetches of the LDS-DMA rings, as before (A/B measurements)
-    const char* e = getenv("PRIMX_GEMM_TAILDMA");
-    return e && e[0] == '1';
-}();
-
 static const int g_gemm_prof_mode = [] {   // PRIMX_GEMM_PROF=1: synchronous launches + timeline print; 2: without MFMAs and
     const char* e = getenv("PRIMX_GEMM_PROF");   // fragment reads (DMA-only bound probe); 3: without MFMAs
     return e ? atoi(e) : 0;
@@ -1559,7 +1546,6 @@ template <int DT, int EPI, int BIG = 0>
 void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     const dim3 grid(BIG ? ((a.M + 255) / 256) * (a.N / 288) : mt * (a.N / 144));
     GemmArgs<DT> a2 = a;
-    a2.clamp_tail = g_clamp_tail;
     if (BIG && g_xcd2d) {
         // XCD block shape: minimise (A bytes x column groups + W bytes x row groups) over the splits the tile grid allows
         const int mtb = (a.M + 255) / 256, ntb = a.N / 288;
