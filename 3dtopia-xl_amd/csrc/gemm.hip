@@ -732,6 +732,10 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const GemmArgs<DT> p) {
 // [2] entry -> tile 0 landed, [3] main loop, [4] epilogue, [5] workgroups, [6] sum of (start - min start) in 10 ns ticks
 __device__ unsigned long long g_gemm_prof[12];
 
+#ifndef PRIMX_G144_NST
+#define PRIMX_G144_NST 3
+#endif
+
 template <int DT, int EPI, int REGEPI>
 __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> p) {
     unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pc2 = 0;
@@ -748,7 +752,8 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     constexpr int RED_HALVES = BM * BN * 2;
     constexpr int RS = BN + 4;                           // fp32 row stride of the row-major epilogue staging
     constexpr int ROWMAJOR_HALVES = 2 * BM * RS * 2;     // both K halves, fp32 (151,552 B)
-    constexpr int LDS_HALVES = (3 * STAGE > ROWMAJOR_HALVES) ? 3 * STAGE : ROWMAJOR_HALVES;
+    constexpr int NST = PRIMX_G144_NST;                  // ring depth: NST - 1 tiles in flight across every barrier
+    constexpr int LDS_HALVES = (NST * STAGE > ROWMAJOR_HALVES) ? NST * STAGE : ROWMAJOR_HALVES;
     static_assert(LDS_HALVES * 2 <= 160 * 1024 && RED_HALVES <= LDS_HALVES, "LDS budget");
     __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES];
 
@@ -838,10 +843,9 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     }
 
     const int nk = p.K / BK;
-    issue(0, 0);
-    issue(min(1, nk - 1), 1);
-    issue(min(2, nk - 1), 2);
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // tile 0 landed (4..5 DMAs per tile per wave)
+#pragma unroll
+    for (int s0 = 0; s0 < NST; ++s0) issue(min(s0, nk - 1), s0);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NST - 1)) : "memory");  // tile 0 landed (4..5 DMAs per tile per wave)
     if (p.prof) pc1 = __builtin_readcyclecounter();
     V8 a0[MI], b0[NI], a1[MI], b1[NI];
     read_frags(0, a0, b0);
@@ -849,14 +853,14 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     auto step = [&](int kt, const V8 (&ac)[MI], const V8 (&bc)[NI], V8 (&an)[MI], V8 (&bn)[NI]) {
         // vmcnt(4): tile kt+1 landed for this wave (tile kt+2 may stay in flight); lgkmcnt(0): this wave's reads of
         // tile kt's stage have completed, so after the barrier that stage can be overwritten by the DMA below
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 * (NST - 2)) : "memory");
         // (Spreading these DMA issues between the MFMA groups, which pays in the 256x288 kernel, measured worse here:
         // main loop 78.2k -> 81.8k cycles at K = 4608.)
-        issue(min(kt + 3, nk - 1), st_cur);
+        issue(min(kt + NST, nk - 1), st_cur);
         if (p.prof != 2) read_frags(st_next, an, bn);   // prof == 2 / 3: DMA-only / DMA + LDS reads (bound probes, results wrong)
         if (p.prof < 2) multiply(ac, bc);
         st_cur = st_next;
-        st_next = (st_next == 2) ? 0 : st_next + 1;
+        st_next = (st_next == NST - 1) ? 0 : st_next + 1;
     };
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
