@@ -1651,8 +1651,23 @@ int ilog2_exact(int v) {
 // stream per forward at DiT-XL).  HBM-bound: a wave owns 4 output columns, streams their W rows with 16-byte loads and
 // keeps M x 4 fp32 partial sums; A (a few KB) comes from L1.  The MFMA tiles spent 180 us on it (256-row tiles with 2
 // valid rows: 1.26 GB through the L2 -> LDS path); PRIMX_GEMM_NOGEMV=1 goes back to them.
-constexpr int GEMV_ROWS = 4, GEMV_COLS = 4;
-template <int DT>
+// ROWS = 4 or 8: a row's arithmetic (k order per lane, 16-lane reduction) does not depend on ROWS or on M, so a row computed
+// alone, in a batch of 4 or in a batch of 8 is bit-identical (the per-loop modulation table of DiT.plan_timesteps relies on it).
+// A wave is four 16-lane groups; a group owns GEMV_COLS = 4 columns and its lanes split K in 16-byte chunks (K = 1152: nine
+// chunks per lane, every lane busy; the first form - 64 lanes per 4 columns - ran 2.25 iterations on 3 and then spent as many
+// instructions on 6-step wave reductions of its M x 4 sums as on the products: 310 us for 8 rows).  The reduction is four DPP
+// adds inside the group.
+constexpr int GEMV_MAX_ROWS16 = 8, GEMV_COLS = 4;
+__device__ __forceinline__ float group16_sum(float v) {
+    // xor-butterfly over the 16 lanes of a DPP row: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+    return v;
+}
+
+template <int DT, int GEMV_ROWS>
 __global__ __launch_bounds__(256) void gemv16_kernel(const typename T16<DT>::S* __restrict__ A,
                                                      const typename T16<DT>::S* __restrict__ W,
                                                      const typename T16<DT>::S* __restrict__ bias,
@@ -1660,35 +1675,40 @@ __global__ __launch_bounds__(256) void gemv16_kernel(const typename T16<DT>::S* 
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
     using V4 = typename T16<DT>::V4;
-    const int lane = threadIdx.x & 63;
-    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GEMV_COLS;
-    if (n0 >= N) return;
+    const int lane = threadIdx.x & 63, l16 = lane & 15;
+    const int n0 = (((blockIdx.x * 4 + (threadIdx.x >> 6)) << 2) + (lane >> 4)) * GEMV_COLS;
+    const bool live = n0 < N;                 // N % GEMV_COLS == 0: a group's columns are all inside or all outside
+    const int nc = live ? n0 : 0;             // dead groups stream valid addresses and store nothing
     float acc[GEMV_ROWS][GEMV_COLS] = {};
-    for (int kc = lane; kc < K / 8; kc += 64) {
+    for (int kc = l16; kc < K / 8; kc += 16) {
         V8 w[GEMV_COLS];
 #pragma unroll
         for (int c = 0; c < GEMV_COLS; ++c)   // streamed once per forward: non-temporal
-            w[c] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(W + (int64_t)(n0 + c) * K + kc * 8));
+            w[c] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(W + (int64_t)(nc + c) * K + kc * 8));
+        // rows beyond M re-read row M - 1 (results discarded): no branch in the loop, so all loads of an iteration are in
+        // flight together
+        V8 a[GEMV_ROWS];
+#pragma unroll
+        for (int m = 0; m < GEMV_ROWS; ++m) a[m] = *reinterpret_cast<const V8*>(A + (int64_t)min(m, M - 1) * K + kc * 8);
 #pragma unroll
         for (int m = 0; m < GEMV_ROWS; ++m) {
-            if (m < M) {
-                const V8 a = *reinterpret_cast<const V8*>(A + (int64_t)m * K + kc * 8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float af = (float)a[e];
+            for (int e = 0; e < 8; ++e) {
+                const float af = (float)a[m][e];
 #pragma unroll
-                    for (int c = 0; c < GEMV_COLS; ++c) acc[m][c] = fmaf(af, (float)w[c][e], acc[m][c]);
-                }
+                for (int c = 0; c < GEMV_COLS; ++c) acc[m][c] = fmaf(af, (float)w[c][e], acc[m][c]);
             }
         }
     }
+    float bf[GEMV_COLS];
+#pragma unroll
+    for (int c = 0; c < GEMV_COLS; ++c) bf[c] = bias ? (float)bias[nc + c] : 0.f;
 #pragma unroll
     for (int m = 0; m < GEMV_ROWS; ++m) {
-        if (m >= M) break;
         V4 o;
 #pragma unroll
-        for (int c = 0; c < GEMV_COLS; ++c) o[c] = (S)(wave_sum(acc[m][c]) + (bias ? (float)bias[n0 + c] : 0.f));
-        if (lane == 0) *reinterpret_cast<V4*>(out + (int64_t)m * N + n0) = o;
+        for (int c = 0; c < GEMV_COLS; ++c) o[c] = (S)(group16_sum(acc[m][c]) + bf[c]);
+        if (m < M && live && l16 == 0) *reinterpret_cast<V4*>(out + (int64_t)m * N + n0) = o;
     }
 }
 
@@ -1703,13 +1723,18 @@ extern "C" int primx_linear(const void* A, const void* W, const void* bias, void
                             int act, float out_scale, void* stream) {
     PRIMX_REQUIRE(out, "primx_linear: null output");
     PRIMX_REQUIRE(act == PRIMX_ACT_NONE || act == PRIMX_ACT_GELU_TANH || act == PRIMX_ACT_GELU_ERF, "primx_linear: bad activation code");
-    if (M > 0 && M <= GEMV_ROWS && N % GEMV_COLS == 0 && K > 0 && K % 8 == 0 && act == PRIMX_ACT_NONE &&
+    if (M > 0 && M <= GEMV_MAX_ROWS16 && N % GEMV_COLS == 0 && K > 0 && K % 8 == 0 && act == PRIMX_ACT_NONE &&
         out_scale == 1.0f && !g_no_gemv) {
         PRIMX_REQUIRE(A && W, "primx_linear: null operand");
         PRIMX_DISPATCH_16(dtype, "primx_linear", {
             using S = typename T16<DT>::S;
-            hipLaunchKernelGGL((gemv16_kernel<DT>), dim3((N / GEMV_COLS + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                               (const S*)A, (const S*)W, (const S*)bias, (S*)out, M, N, K);
+            const dim3 grid((N / GEMV_COLS + 15) / 16);   // 4 waves x 4 groups of 4 columns per workgroup
+            if (M <= 4)
+                hipLaunchKernelGGL((gemv16_kernel<DT, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const S*)A, (const S*)W,
+                                   (const S*)bias, (S*)out, M, N, K);
+            else
+                hipLaunchKernelGGL((gemv16_kernel<DT, 8>), grid, dim3(256), 0, (hipStream_t)stream, (const S*)A, (const S*)W,
+                                   (const S*)bias, (S*)out, M, N, K);
             PRIMX_CHECK_LAUNCH("primx_linear");
             return PRIMX_OK;
         });

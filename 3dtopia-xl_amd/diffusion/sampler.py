@@ -47,6 +47,9 @@ C_SQRT_ACP, C_SQRT_1M_ACP, C_SQRT_RECIP_ACP, C_SQRT_RECIPM1_ACP = 0, 1, 2, 3
 C_POST_MEAN1, C_POST_MEAN2, C_MIN_LOG, C_MAX_LOG, C_FIXED_LOGVAR = 4, 5, 6, 7, 8
 C_DDIM_X0, C_DDIM_EPS, C_DDIM_SIGMA, C_NONZERO, C_FIXED_VAR = 9, 10, 11, 12, 13
 
+# PRIMX_PLAN_TIMESTEPS=0: the sampling loops do not announce their timesteps to the model (A/B of DiT.plan_timesteps)
+PLAN_TIMESTEPS = __import__("os").environ.get("PRIMX_PLAN_TIMESTEPS", "1") != "0"
+PLAN_MAX_STEPS = 256   # 16-bit table of n x (depth * 9 + 2) * D entries: 0.6 MB per step for DiT-XL
 _MEAN_CODE = {ModelMeanType.EPSILON: 0, ModelMeanType.START_X: 1, ModelMeanType.VELOCITY: 2}
 _VAR_CODE = {
     ModelVarType.FIXED_SMALL: 0,
@@ -134,7 +137,7 @@ class GaussianDiffusion(DiffusionTables):
             return self._step_on_device(kind, model, x, i, **kw)
 
     def _step_on_device(self, kind: str, model: Callable, x: torch.Tensor, i: int, *, clip_denoised: bool,
-                        model_kwargs: Optional[dict], eta: float, coef: torch.Tensor, tmap: torch.Tensor):
+                        model_kwargs: Optional[dict], eta: float, coef: torch.Tensor, tmap: torch.Tensor, planner=None):
         from .. import ops
 
         if x.dim() != 3:
@@ -143,7 +146,13 @@ class GaussianDiffusion(DiffusionTables):
         # (B,) int64 timesteps of the ORIGINAL process (respace.py:124-129): a row of the per-loop [n, B] table (contiguous,
         # so nothing downstream has to copy it), or a broadcast view for the single-step API.  No allocation, no H2D.
         t_model = tmap[i] if tmap.dim() == 2 else tmap[i].expand(B)
-        model_output = model(x, t_model, **(model_kwargs or {}))
+        if planner is not None:
+            planner.select_planned_timestep(i)        # row i of the table announced in _loop
+        try:
+            model_output = model(x, t_model, **(model_kwargs or {}))
+        finally:
+            if planner is not None:
+                planner.select_planned_timestep(None)
         if isinstance(model_output, tuple):
             model_output = model_output[0]
         learned = self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE)
@@ -184,18 +193,31 @@ class GaussianDiffusion(DiffusionTables):
                 f"got a tensor on {img.device}"
             )
         img = img.float().contiguous()
-        coef, tmap = self._device_state(img.device, eta)
-        tmap = tmap[:, None].expand(-1, img.shape[0]).contiguous()      # [n_steps, B], built once per loop
+        coef, tmap1 = self._device_state(img.device, eta)
+        tmap = tmap1[:, None].expand(-1, img.shape[0]).contiguous()     # [n_steps, B], built once per loop
+        # The loop knows every timestep it will ask the model for.  A model that can use that (DiT.plan_timesteps: the
+        # timestep-only adaLN modulation of all steps is computed once per loop, several rows per pass over the weights,
+        # instead of one row per step) is told; the rows are selected by step index, no device read-back.  `model` is the
+        # reference's call convention: a module or a bound method such as `model.forward_with_cfg` (inference.py:306-311).
+        owner = getattr(model, "__self__", model)
+        planner = owner if (callable(getattr(owner, "plan_timesteps", None)) and PLAN_TIMESTEPS
+                            and self.num_timesteps <= PLAN_MAX_STEPS) else None
+        if planner is not None:
+            planner.plan_timesteps(tmap1)
         indices = range(self.num_timesteps - 1, -1, -1)
         if progress:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
-        for i in indices:
-            with torch.no_grad():   # scoped to the step: a generator must not hold the grad-mode context across yields
-                out = self._step(kind, model, img, i, clip_denoised=clip_denoised,
-                                 model_kwargs=model_kwargs, eta=eta, coef=coef, tmap=tmap)
-            yield out
-            img = out["sample"]
+        try:
+            for i in indices:
+                with torch.no_grad():   # scoped to the step: a generator must not hold the grad-mode context across yields
+                    out = self._step(kind, model, img, i, clip_denoised=clip_denoised,
+                                     model_kwargs=model_kwargs, eta=eta, coef=coef, tmap=tmap, planner=planner)
+                yield out
+                img = out["sample"]
+        finally:
+            if planner is not None:
+                planner.clear_timestep_plan()
 
     # ------------------------------------------------------------------ public API (reference names)
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,

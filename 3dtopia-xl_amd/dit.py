@@ -143,6 +143,7 @@ class DiT(nn.Module):
         # conditioning tensor and reused across DDIM steps.  Off by default: a step then executes the reference's full
         # algorithmic FLOPs (bench.py reports both when the flag is on).
         self.reuse_cond_kv = False
+        self._t_plan: Optional[Dict] = None   # plan_timesteps(): the coming calls' timesteps and their modulation table
 
     # ------------------------------------------------------------------ init (dit_crossattn.py:153-182)
     def initialize_weights(self):
@@ -163,6 +164,7 @@ class DiT(nn.Module):
 
     # ------------------------------------------------------------------ packed 16-bit weights
     def repack(self) -> None:
+        self._t_plan = None
         self._pack = {}
         self._heads_ws = {}
         self._cond = None
@@ -172,6 +174,7 @@ class DiT(nn.Module):
         self.__dict__["_pack"] = {}
         self.__dict__["_heads_ws"] = {}
         self.__dict__["_cond"] = None
+        self.__dict__["_t_plan"] = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
@@ -447,6 +450,44 @@ class DiT(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("DiT.forward needs HIP device tensors; there is no CPU path")
 
+    # ---- timestep plan.  The adaLN modulation of all blocks (dit_crossattn.py:40-43,54,69-75) depends on the timestep only,
+    # and a sampling loop knows its timesteps in advance: computed per step it is a 674 MB weight stream for ONE distinct input
+    # row (140 us of every 9.6 ms step at configs[1]); computed per LOOP the same rows go through the same kernel eight at a time
+    # (ceil(n / 8) streams per loop instead of n).  Every row is still computed, by the same arithmetic: the few-row kernels
+    # (`gemv_f32_kernel`, `gemv16_kernel`) give a row the same bits alone or in a batch, so planned and unplanned loops produce
+    # identical samples (tests/test_hip_dit.py).
+    _PLAN_ROWS = 8   # rows per pass of the few-row kernels (csrc/gemm.hip GEMV_MAX_ROWS16, csrc/rowops.hip GEMV_MAX_ROWS)
+
+    def plan_timesteps(self, timesteps: torch.Tensor) -> None:
+        """`timesteps`: 1-D int64 device tensor - the model timestep of each coming call, every batch entry of a call sharing
+        it.  The caller then sets `select_planned_timestep(i)` before call i (the sampler does both); a forward without a
+        selected row computes its modulation from `t` as usual."""
+        if timesteps.dim() != 1 or timesteps.dtype != torch.int64 or not timesteps.is_cuda:
+            raise RuntimeError("plan_timesteps: expected a 1-D int64 HIP device tensor")
+        self._t_plan = {"t": timesteps.contiguous(), "mod": {}, "row": None}
+
+    def select_planned_timestep(self, row: Optional[int]) -> None:
+        if self._t_plan is not None:
+            if row is not None and not (0 <= row < self._t_plan["t"].numel()):
+                raise IndexError(f"planned timestep {row} out of range")
+            self._t_plan["row"] = row
+
+    def clear_timestep_plan(self) -> None:
+        self._t_plan = None
+
+    def _modulation_table(self, plan: Dict, dt: torch.dtype, pk: Dict) -> torch.Tensor:
+        key = (dt, pk["w_ada"].data_ptr())
+        tab = plan["mod"].get(key)
+        if tab is None:
+            ts = plan["t"]
+            n, R = ts.numel(), self._PLAN_ROWS
+            tab = torch.empty(n, pk["w_ada"].shape[0], dtype=dt, device=ts.device)
+            for lo in range(0, n, R):
+                st16 = ops.silu_cast(self.t_embedder(ts[lo:lo + R]), dt)
+                ops.linear(st16, pk["w_ada"], pk["b_ada"], out=tab[lo:lo + R])
+            plan["mod"] = {key: tab}
+        return tab
+
     def _forward16(self, x, t, y, dt, null_half: bool):
         """The 16-bit autocast path.  `null_half`: classifier-free guidance - the effective batch is [x; x] with the
         second half conditioned on the null embedding (dit_crossattn.py:204-209), assembled here without materialising
@@ -463,14 +504,21 @@ class DiT(nn.Module):
         xf = x.reshape(B * N, Cin).float().contiguous()
         h = torch.empty(T, D, dtype=torch.float32, device=dev)
         self._embed_tokens(xf, h[:B * N])
-        t_emb = self.t_embedder(t)                               # [B, D]
-        st16 = torch.empty(Be, D, dtype=dt, device=dev)
-        ops.silu_cast(t_emb, dt, out=st16[:B])
         if null_half:
             self._embed_tokens(xf, h[B * N:])
-            ops.silu_cast(t_emb, dt, out=st16[B:])
-        # adaLN for every block + final layer: SiLU -> one streaming GEMM (dit_crossattn.py:40-43,54,69-75)
-        mod = ops.linear(st16, pk["w_ada"], pk["b_ada"])         # [Be, depth*9D + 2D]
+        plan = self._t_plan
+        if plan is not None and plan["row"] is not None:
+            # the sampling loop announced its timesteps (plan_timesteps): this call's modulation is a row of the per-loop
+            # table, shared by all batch entries (row stride 0)
+            mod = self._modulation_table(plan, dt, pk)[plan["row"]:plan["row"] + 1].expand(Be, -1)
+        else:
+            t_emb = self.t_embedder(t)                               # [B, D]
+            st16 = torch.empty(Be, D, dtype=dt, device=dev)
+            ops.silu_cast(t_emb, dt, out=st16[:B])
+            if null_half:
+                ops.silu_cast(t_emb, dt, out=st16[B:])
+            # adaLN for every block + final layer: SiLU -> one streaming GEMM (dit_crossattn.py:40-43,54,69-75)
+            mod = ops.linear(st16, pk["w_ada"], pk["b_ada"])         # [Be, depth*9D + 2D]
         cs = self._cond_state(y, null_half, dt)
         Lk, y16 = cs["Lk"], cs["y16"]
 

@@ -219,8 +219,8 @@ def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: 
     if out is None:
         out = torch.empty(M, N, dtype=A.dtype, device=A.device)
     tag = _gemm_tag(0, M, N, K, A.dtype)
-    if M <= 4 and N % 4 == 0 and K % 8 == 0 and act == 0 and out_scale == 1.0 and os.environ.get("PRIMX_GEMM_NOGEMV") != "1":
-        tag = f"gemv16_kernel<{dtype_code(A.dtype)}>"     # few-row streaming path (csrc/gemm.hip primx_linear)
+    if M <= 8 and N % 4 == 0 and K % 8 == 0 and act == 0 and out_scale == 1.0 and os.environ.get("PRIMX_GEMM_NOGEMV") != "1":
+        tag = f"gemv16_kernel<{dtype_code(A.dtype)}, {4 if M <= 4 else 8}>"     # few-row streaming path (csrc/gemm.hip primx_linear)
     _timed(f"{tag} {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear(
         _dev(A, "A"), _dev(W, "W"), _dev(bias, "bias", A.dtype) if bias is not None else None,
         _dev(out, "out", A.dtype), M, N, K, dtype_code(A.dtype), act, out_scale, _stream()), "primx_linear"))

@@ -134,6 +134,38 @@ def test_packed_only_model_from_checkpoint_and_from_packed_file(pkg, tmp_path):
     assert torch.equal(mapped.forward_with_cfg(x.to(DEV), t.to(DEV), y.to(DEV), 6.0, torch.float16, True), want)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_planned_and_unplanned_loops_give_identical_samples(pkg, dtype, monkeypatch):
+    """The sampler announces its timesteps (DiT.plan_timesteps: the timestep-only adaLN modulation of the whole loop goes through
+    the few-row kernel eight rows per pass instead of one pass per step).  Same kernels, same per-row arithmetic: every
+    step's sample is bit-identical to the loop that computes the modulation per step, and the plan does not outlive the loop."""
+    from importlib import import_module
+    sampler = import_module(pkg.__name__ + ".diffusion.sampler")
+    name, sd, heads, m, x, y, t = _case(pkg, 1)
+    d = pkg.create_diffusion("ddim10", noise_schedule="squaredcos_cap_v2", parameterization="v")
+    kw = dict(y=y.to(DEV), cfg_scale=6.0, precision_dtype=dtype, enable_amp=True)
+    noise = synth.tensor(5, "plan.noise", tuple(x.shape)).to(DEV)
+
+    def run():
+        return [o["sample"].clone() for o in d.ddim_sample_loop_progressive(m.forward_with_cfg, tuple(x.shape), noise=noise,
+                                                                            clip_denoised=False, model_kwargs=kw)]
+    calls = []
+    real = m.plan_timesteps
+    monkeypatch.setattr(m, "plan_timesteps", lambda ts: (calls.append(ts.clone()), real(ts))[1])
+    planned = run()
+    assert len(calls) == 1 and calls[0].tolist() == list(d.timestep_map) and m._t_plan is None
+    monkeypatch.setattr(sampler, "PLAN_TIMESTEPS", False)
+    unplanned = run()
+    assert len(calls) == 1 and len(planned) == len(unplanned) == 10
+    for a, b in zip(planned, unplanned):
+        assert torch.equal(a, b)
+    # a direct call between steps (no selected row) computes its modulation from t, whatever plan is pending
+    m.plan_timesteps(calls[0])
+    direct = m.forward_with_cfg(x.to(DEV), t[:x.shape[0]].to(DEV), y.to(DEV), 6.0, dtype, True)
+    m.clear_timestep_plan()
+    assert torch.equal(direct, m.forward_with_cfg(x.to(DEV), t[:x.shape[0]].to(DEV), y.to(DEV), 6.0, dtype, True))
+
+
 def test_full_width_block_at_baseline_shape(pkg):
     """BASELINE configs[1] shapes on ONE block: d=1152, 16 heads x 72, N_prim=2048, 1370 x 768 condition tokens, CFG 6
     (effective batch 2) - the exact GEMM tiles (128x144 LDS-DMA kernel, K = 1152 / 4608 / 768), the 2048 x 2048 and

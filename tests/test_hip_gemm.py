@@ -31,13 +31,27 @@ def _mk(seed, M, N, K, dtype):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (4096, 1152, 1152), (2, 2304, 384), (300, 136, 1152),
                                    (1370, 200, 768), (129, 129, 4608),
-                                   (1, 1152, 1152), (3, 20740, 264), (4, 4612, 1152), (5, 4612, 128)])   # M <= 4: streaming GEMV
+                                   (1, 1152, 1152), (3, 20740, 264), (4, 4612, 1152), (5, 4612, 128), (8, 4612, 1152),
+                                   (9, 4612, 128)])   # M <= 8: streaming GEMV (4- and 8-row instantiations)
 def test_linear_plain(ops, dtype, M, N, K):
     A, W, b, ref = _mk(11, M, N, K, dtype)
     got = ops.linear(A.to(DEV), W.to(DEV), b.to(DEV))
     assert got.shape == (M, N) and rel_l2(got, ref) < TOL[dtype], rel_l2(got, ref)
     got = ops.linear(A.to(DEV), W.to(DEV), None)
     assert rel_l2(got, ref - b.double()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_few_row_linear_gives_a_row_the_same_bits_alone_and_in_a_batch(ops, dtype):
+    """What DiT.plan_timesteps relies on: the streaming few-row kernel's arithmetic per row does not depend on how many
+    rows travel with it (1, 2 = the CFG pair, 4, 8)."""
+    A, W, b, _ = _mk(13, 8, 2308, 1152, dtype)
+    A, W, b = A.to(DEV), W.to(DEV), b.to(DEV)
+    full = ops.linear(A, W, b)
+    for lo, n in ((0, 1), (3, 1), (7, 1), (2, 2), (4, 4), (0, 4), (1, 7)):
+        assert torch.equal(ops.linear(A[lo:lo + n].contiguous(), W, b), full[lo:lo + n]), (lo, n)
+    twice = torch.cat([A[5:6], A[5:6]])                                  # the CFG pair: two identical rows
+    assert torch.equal(ops.linear(twice, W, b), full[5:6].expand(2, -1))
 
 
 def test_linear_detects_transposition(ops):
