@@ -505,7 +505,7 @@ class DiT(nn.Module):
         h = torch.empty(T, D, dtype=torch.float32, device=dev)
         self._embed_tokens(xf, h[:B * N])
         if null_half:
-            self._embed_tokens(xf, h[B * N:])
+            h[B * N:].copy_(h[:B * N])       # cat([x, x]) embeds to the same rows twice (dit_crossattn.py:205,191): one copy
         plan = self._t_plan
         if plan is not None and plan["row"] is not None:
             # the sampling loop announced its timesteps (plan_timesteps): this call's modulation is a row of the per-loop
