@@ -735,6 +735,9 @@ __device__ unsigned long long g_gemm_prof[12];
 #ifndef PRIMX_G144_NST
 #define PRIMX_G144_NST 3
 #endif
+#ifndef PRIMX_G144_ORDER
+#define PRIMX_G144_ORDER 0   // order of DMA issue / fragment reads / MFMAs inside a step of the 128x144 LDS-DMA kernel
+#endif
 
 template <int DT, int EPI, int REGEPI>
 __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> p) {
@@ -856,9 +859,21 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 * (NST - 2)) : "memory");
         // (Spreading these DMA issues between the MFMA groups, which pays in the 256x288 kernel, measured worse here:
         // main loop 78.2k -> 81.8k cycles at K = 4608.)
+#if PRIMX_G144_ORDER == 0
         issue(min(kt + NST, nk - 1), st_cur);
         if (p.prof != 2) read_frags(st_next, an, bn);   // prof == 2 / 3: DMA-only / DMA + LDS reads (bound probes, results wrong)
         if (p.prof < 2) multiply(ac, bc);
+#elif PRIMX_G144_ORDER == 1   // MFMAs first: a wave blocked on the DMA queue has its MFMAs in the pipe already
+        if (p.prof < 2) multiply(ac, bc);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(min(kt + NST, nk - 1), st_cur);
+        if (p.prof != 2) read_frags(st_next, an, bn);
+#else                         // fragment reads, MFMAs, then the DMA issue
+        if (p.prof != 2) read_frags(st_next, an, bn);
+        if (p.prof < 2) multiply(ac, bc);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(min(kt + NST, nk - 1), st_cur);
+#endif
         st_cur = st_next;
         st_next = (st_next == NST - 1) ? 0 : st_next + 1;
     };
