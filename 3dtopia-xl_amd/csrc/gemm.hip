@@ -1079,6 +1079,196 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The 128 x 144 LDS-DMA kernel with LOADER WAVES (PRIMX_GEMM_LOADER=0 switches it off): the dense-output epilogues and the
+// token-major heads epilogue (host-checked: tiles inside one segment, no PRIMX_HEADS_VT segment, dh >= 48, dh % 4 == 0,
+// rows_per_batch >= 128 - launch144_dma).
+// Why: in gemm144_dma_kernel every wave issues its 4-5 DMA instructions behind the step barrier and then sits in the
+// issue queue until the unit has taken them (24.5 cycles per 1 KiB instruction, 833 per k-tile for the workgroup,
+// PRIMX_GEMM_PROF=2) - its 18 MFMAs start late, and a step costs 1096 cycles instead of max(833, 576).  Here waves 8 and 9
+// do nothing but issue DMA (17 instructions per tile each) and wait for it; the eight compute waves never touch the
+// vector-memory queue inside the loop.  10 waves = 3 on two of the SIMDs: 168 VGPRs per wave.
+// Barrier protocol (all 10 waves execute every s_barrier): P (tile 0 landed) | S_kt per step (tile kt+1 landed: the loaders
+// waited for their own pieces; all fragment reads of tile kt are home: the compute waves waited lgkmcnt(0)) | D (ring
+// drained) | E (accumulators parked for the row-major walk).
+template <int DT, int EPI>
+__global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p) {
+    static_assert(EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_HEADS, "row-major epilogues only");
+    using S = typename T16<DT>::S;
+    using V8 = typename T16<DT>::V8;
+    using V4e = typename T16<DT>::V4;
+    typedef __attribute__((address_space(1))) const void GV;
+    typedef __attribute__((address_space(3))) void LV;
+    constexpr int BM = 128, BN = 144, MI = 2, NI = 9, NST = 3;
+    constexpr int ROWS = BM + BN, STAGE = ROWS * 64, NINST = ROWS / 8, NL = NINST / 2;   // 17 wave-instructions per loader per tile
+    constexpr int RS = BN + 4;
+    constexpr int ROWMAJOR_HALVES = 2 * BM * RS * 2;
+    constexpr int LDS_HALVES = (NST * STAGE > ROWMAJOR_HALVES) ? NST * STAGE : ROWMAJOR_HALVES;
+    static_assert(LDS_HALVES * 2 <= 160 * 1024 && NINST % 2 == 0, "LDS budget / loader split");
+    __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = p.N / BN, mt = (p.M + BM - 1) / BM;
+    const int id = xcd_remap(blockIdx.x, nt * mt);
+    const int m0 = (id / nt) * BM, n0 = (id % nt) * BN;
+    const int nk = p.K / BK;
+
+    if (wave >= 8) {
+        // ---------------- loader wave lw: instructions t = lw * 17 + i, rows 8t .. 8t+7 of the 272-row stage image
+        const int lw = wave - 8;
+        const S* gp[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int row = 8 * (lw * NL + i) + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            gp[i] = (row < BM) ? p.A + (int64_t)min(m0 + row, p.M - 1) * p.K + c * 8
+                               : p.W + (int64_t)(n0 + row - BM) * p.K + c * 8;
+        }
+        auto issue = [&](int kt, int stage) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i)
+                __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + kt * BK),
+                                                 (LV*)(smem + stage * STAGE + (lw * NL + i) * 512), 16, 0, 0);
+        };
+        issue(0, 0);
+        issue(min(1, nk - 1), 1);
+        issue(min(2, nk - 1), 2);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NL) : "memory");      // P
+        int st = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");     // S_kt: tile kt+1 landed, kt+2 may fly
+            issue(min(kt + NST, nk - 1), st);                                              // tile kt's stage is free now
+            st = (st == NST - 1) ? 0 : st + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                   // D
+        asm volatile("s_barrier" ::: "memory");                                          // E
+        return;
+    }
+
+    // ---------------- compute waves: the tile / wave roles of gemm144_dma_kernel
+    const int kg = wave >> 2, wm = wave & 3;
+    const int lr = lane & 15, lg = lane >> 4;
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int a_row = wm * 32 + lr;
+    const int chunk = kg * 4 + lg;
+    auto read_frags = [&](int stage, V8 (&a)[MI], V8 (&b)[NI]) {
+        const S* As = smem + stage * STAGE;
+        const S* Ws = As + BM * 64;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const V8*>(As + lds_off(a_row + i * 16, chunk));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(Ws + lds_off(lr + j * 16, chunk));
+    };
+    auto multiply = [&](const V8 (&a)[MI], const V8 (&b)[NI]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(a[i], b[j], acc[i][j]);
+    };
+    asm volatile("s_barrier" ::: "memory");                                              // P
+    V8 a0[MI], b0[NI], a1[MI], b1[NI];
+    read_frags(0, a0, b0);
+    int st_next = 1;
+    auto step = [&](const V8 (&ac)[MI], const V8 (&bc)[NI], V8 (&an)[MI], V8 (&bn)[NI]) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                 // S_kt
+        read_frags(st_next, an, bn);
+        multiply(ac, bc);
+        st_next = (st_next == NST - 1) ? 0 : st_next + 1;
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        step(a0, b0, a1, b1);
+        step(a1, b1, a0, b0);
+    }
+    if (kt < nk) step(a0, b0, a1, b1);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                     // D: the stages may be reused
+
+    // ---------------- epilogue: both K halves park their accumulators as fp32 [half][128][148]; row-major walk, 4 columns
+    // per thread, 9 row-chunks each (the form of gemm144_dma_kernel<.., REGEPI = 0>).  The residual / gate / bias vectors are
+    // requested AFTER the parking (the accumulator registers are free by then: held across it they spilled) and land under
+    // the barrier
+    constexpr int NROWCH = (BM * (BN / 4)) / 512;
+    float* red = reinterpret_cast<float*>(smem);
+    float* mine = red + kg * (BM * RS);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[(wm * 32 + mi * 16 + 4 * lg + r) * RS + ni * 16 + lr] = acc[mi][ni][r];
+    __builtin_amdgcn_sched_barrier(0);
+    // EPI_HEADS: the tile lies inside ONE (repetition, segment): everything that needs a division is tile-uniform
+    int h_hh0 = 0, h_dd0 = 0, h_bb0 = 0, h_tok0 = 0, h_rs = 0, h_seg = 0;
+    S* h_dst = nullptr;
+    if (EPI == EPI_HEADS) {
+        const int per = p.heads * p.dh;
+        const int seg_all = n0 / per, rep_i = seg_all / p.n_seg;
+        h_seg = seg_all - rep_i * p.n_seg;
+        const int w0 = n0 - seg_all * per;
+        h_hh0 = w0 / p.dh;
+        h_dd0 = w0 - h_hh0 * p.dh;
+        h_bb0 = m0 / p.rows_per_batch;
+        h_tok0 = m0 - h_bb0 * p.rows_per_batch;
+        h_rs = heads_row_stride(h_seg == 0 ? p.kind[0] : h_seg == 1 ? p.kind[1] : p.kind[2], p.DP);
+        h_dst = (h_seg == 0 ? p.dst[0] : h_seg == 1 ? p.dst[1] : p.dst[2]) +
+                rep_i * (h_seg == 0 ? p.rep_stride[0] : h_seg == 1 ? p.rep_stride[1] : p.rep_stride[2]);
+    }
+    V4e bpre[NROWCH], gpre[NROWCH];
+    f32x4 xpre[NROWCH];
+#pragma unroll
+    for (int i = 0; i < NROWCH; ++i) {
+        const int cid = tid + 512 * i;
+        const int row = cid / (BN / 4), c4 = cid - row * (BN / 4);
+        const int m = min(m0 + row, p.M - 1);
+        bpre[i] = V4e{};
+        if (p.bias) bpre[i] = *reinterpret_cast<const V4e*>(p.bias + n0 + 4 * c4);
+        if (EPI == EPI_GATE_RESIDUAL) {
+            gpre[i] = *reinterpret_cast<const V4e*>(p.gate + (int64_t)(m / p.rows_per_batch) * p.gate_stride + n0 + 4 * c4);
+            xpre[i] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.N + n0 + 4 * c4);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                     // E
+#pragma unroll
+    for (int i = 0; i < NROWCH; ++i) {
+        const int cid = tid + 512 * i;
+        const int row = cid / (BN / 4), c4 = cid - row * (BN / 4);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(red + row * RS + 4 * c4);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(red + BM * RS + row * RS + 4 * c4);
+        if (m0 + row >= p.M) continue;
+        if (EPI == EPI_HEADS) {
+            int d = h_dd0 + 4 * c4, hh = h_hh0;          // d < dh + 144 <= 4 dh
+            if (d >= p.dh) { d -= p.dh; ++hh; }
+            if (d >= p.dh) { d -= p.dh; ++hh; }
+            if (d >= p.dh) { d -= p.dh; ++hh; }
+            int tok = h_tok0 + row, bb = h_bb0;          // tok < rows_per_batch + 128 <= 2 rows_per_batch
+            if (tok >= p.rows_per_batch) { tok -= p.rows_per_batch; ++bb; }
+            const V4e bv = bpre[i];
+            V4e o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float y = rnd16<DT>(v0[j] + v1[j] + (p.bias ? (float)bv[j] : 0.f));
+                if (h_seg == 0 && p.scale0 != 1.0f) y = rnd16<DT>(p.scale0 * y);
+                o[j] = (S)y;
+            }
+            out_store(reinterpret_cast<V4e*>(h_dst + (((int64_t)bb * p.heads + hh) * p.n_pad + tok) * h_rs + d), o);
+        } else if (EPI == EPI_GATE_RESIDUAL) {
+            const V4e gv = gpre[i], bv = bpre[i];
+            f32x4 xv = xpre[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                xv[j] = xv[j] + rnd16<DT>((float)gv[j] * rnd16<DT>(v0[j] + v1[j] + (p.bias ? (float)bv[j] : 0.f)));
+            out_store(reinterpret_cast<f32x4*>(p.x + (int64_t)(m0 + row) * p.N + n0 + 4 * c4), xv);
+        } else {
+            epilogue_row4<DT, EPI>(p, m0 + row, n0 + 4 * c4, v0 + v1, bpre[i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Big tile: 256 x 288, 8 waves = 4 (M) x 2 (N), each wave 64 x 144 = 4 x 9 tiles of 16x16x32, LDS-DMA staging into a
 // 2-stage ring (2 x 69,632 B).  Made for the GEMMs that the 128x144 kernel runs as several sequential rounds per CU
 // (fc1: N = 4608 = 16 x 288 -> exactly 256 workgroups at M = 4096; qkv: 192; the batched to_k/to_v: 2464): every
@@ -1540,6 +1730,11 @@ static const int g_reg_epi = [] {
     return (e && e[0] == '1') ? 1 : 0;
 }();
 
+static const bool g_loader = [] {   // PRIMX_GEMM_LOADER=0: the 128x144 kernel without loader waves (gemm144_dma_kernel) everywhere
+    const char* e = getenv("PRIMX_GEMM_LOADER");
+    return !(e && e[0] == '0');
+}();
+
 static const bool g_big_q = [] {   // PRIMX_GEMM_BIGQ=0: 256x288 kernel with the 2-stage 64-wide ring instead of the 4-stage 32-wide one
     const char* e = getenv("PRIMX_GEMM_BIGQ");
     return !(e && e[0] == '0');
@@ -1576,9 +1771,20 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
             if (cost < best) { best = cost; a2.xcd_gm = gm; }
         }
     }
+    // loader-wave kernel: the row-major epilogues (heads: token-major segments whose tiles stay inside one segment)
+    bool loader_ok = !BIG && (EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL);
+    if (!BIG && EPI == EPI_HEADS && a.heads > 0) {
+        const int per = a.heads * a.dh;
+        loader_ok = per % 144 == 0 && a.dh >= 48 && a.dh % 4 == 0 && a.rows_per_batch >= 128;
+        for (int sgi = 0; sgi < a.n_seg; ++sgi) loader_ok = loader_ok && a.kind[sgi] != PRIMX_HEADS_VT;
+    }
     auto go = [&](const GemmArgs<DT>& x) {
         if (BIG && g_big_q && x.K % 32 == 0) hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
         else if (BIG) hipLaunchKernelGGL((gemm288_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
+        else if (g_loader && loader_ok && !g_gemm_prof_on) {   // (no timeline stamps in the loader-wave kernel)
+            if constexpr (EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_HEADS)
+                hipLaunchKernelGGL((gemm144l_dma_kernel<DT, EPI>), grid, dim3(640), 0, st, x);
+        }
         else if (g_reg_epi) hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI, 1>), grid, dim3(512), 0, st, x);
         else hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI, 0>), grid, dim3(512), 0, st, x);
     };

@@ -90,7 +90,7 @@ def _gemm_tag(epi: int, M: int, N: int, K: int, dtype, heads=None) -> str:
         return f"gemm_kernel<{dt}, {epi}, 32, 4, 1, 1, 1, 0, {int(K % 64 != 0)}>"
     if epi == 2 and heads is not None and K % 64 == 0 \
             and os.environ.get("PRIMX_GEMM_BIGQ", "1") != "0" and os.environ.get("PRIMX_GEMM_NOBIG") != "1":
-        H, dh, rows = heads       # heads epilogue on the 256x288 tile (csrc/gemm.hip launch(): whole heads, one batch entry)
+        H, dh, rows = heads[:3]   # heads epilogue on the 256x288 tile (csrc/gemm.hip launch(): whole heads, one batch entry)
         wg_min = int(os.environ.get("PRIMX_GEMM_BIGHEADS_MIN", "160"))
         if wg_min > 0 and N % 288 == 0 and (H * dh) % 288 == 0 and 288 % dh == 0 and dh % 8 == 0 and dh >= 32 and rows % 256 == 0 \
                 and (M // 256) * (N // 288) >= wg_min:
@@ -98,6 +98,14 @@ def _gemm_tag(epi: int, M: int, N: int, K: int, dtype, heads=None) -> str:
     if epi != 2 and N % 288 == 0 and K % 64 == 0 and ((M + 255) // 256) * (N // 288) >= 224:
         q = "" if os.environ.get("PRIMX_GEMM_BIGQ", "1") == "0" else "q"
         return f"gemm288{q}_dma_kernel<{dt}, {epi}>"
+    if N % 144 == 0 and K % 64 == 0 and os.environ.get("PRIMX_GEMM_LOADER", "1") != "0" and not os.environ.get("PRIMX_GEMM_PROF"):
+        ok = epi in (0, 1)                   # loader-wave kernel: row-major epilogues (csrc/gemm.hip launch144_dma)
+        if epi == 2 and heads is not None:
+            H, dh, rows = heads[:3]
+            kinds = heads[3] if len(heads) > 3 else (HEADS_VT,)
+            ok = (H * dh) % 144 == 0 and dh >= 48 and dh % 4 == 0 and rows >= 128 and all(k != HEADS_VT for k in kinds)
+        if ok:
+            return f"gemm144l_dma_kernel<{dt}, {epi}>"
     if N % 144 == 0:
         regepi = int(os.environ.get("PRIMX_GEMM_REGEPI", "0") == "1")
         return f"gemm144_dma_kernel<{dt}, {epi}, {regepi}>" if K % 64 == 0 else f"gemm144_kernel<{dt}, {epi}, 1>"
@@ -250,7 +258,7 @@ def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     n_seg = len(kinds)
     kind_arr = (C.c_int * n_seg)(*kinds)
     dst_arr = (C.c_void_p * n_seg)(*[_dev(d, "dst", A.dtype) for d in dsts])
-    _timed(f"{_gemm_tag(2, M, N, K, A.dtype, (heads, dh, rows_per_batch))} {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_heads(
+    _timed(f"{_gemm_tag(2, M, N, K, A.dtype, (heads, dh, rows_per_batch, tuple(kinds)))} {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_heads(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None, M, N, K,
         rows_per_batch, heads, dh, n_seg, kind_arr, dst_arr, n_rep, rep_batches, n_pad, scale0, dtype_code(A.dtype),
         _stream()),

@@ -5,13 +5,15 @@ launch, keyed like bench.py's per-shape kernel tags ("<kernel name as rocprofv3 
     python tools/pmc_traffic.py <fetch_csv> <write_csv> <out.json> [ddim|decode]
 
 Kernels launched with several shapes are split by their position in the (fixed) launch sequence of one DiT block:
-gemm144_dma_kernel<dt, 1, 0> runs cproj, proj (K = 1152) and fc2 (K = 4608) in that order; attn_kernel alternates
+gemm144l_dma_kernel<dt, 1> runs cproj, proj (K = 1152) and fc2 (K = 4608) in that order; attn_kernel alternates
 cross / self attention."""
 import collections, csv, json, re, sys
 
 CYCLES = {  # kernel name prefix -> shape tags in launch order within one block (BASELINE configs[1], fp16)
-    "gemm144_dma_kernel<1, 1, 0>": ["4096x1152x1152", "4096x1152x1152", "4096x1152x4608"],
+    "gemm144_dma_kernel<1, 1, 0>": ["4096x1152x1152", "4096x1152x1152", "4096x1152x4608"],   # PRIMX_GEMM_LOADER=0
     "gemm144_dma_kernel<1, 2, 0>": ["4096x1152x1152"],
+    "gemm144l_dma_kernel<1, 1>": ["4096x1152x1152", "4096x1152x1152", "4096x1152x4608"],
+    "gemm144l_dma_kernel<1, 2>": ["4096x1152x1152"],
     "gemm288q_dma_kernel<1, 0>": ["4096x4608x1152"],
     "attn_kernel<1, 5, 3, 0, 0>": ["32x2048x1370x72", "32x2048x2048x72"],
     # --config decode (2048 primitives): one shape per kernel
