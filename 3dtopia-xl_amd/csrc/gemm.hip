@@ -1868,10 +1868,10 @@ int ilog2_exact(int v) {
     return (1 << l) == v ? l : -1;
 }
 
-// Few-row Linear (M <= 4: the adaLN modulation of every block from the B_e timestep embeddings, one 669 MB weight
-// stream per forward at DiT-XL).  HBM-bound: a wave owns 4 output columns, streams their W rows with 16-byte loads and
-// keeps M x 4 fp32 partial sums; A (a few KB) comes from L1.  The MFMA tiles spent 180 us on it (256-row tiles with 2
-// valid rows: 1.26 GB through the L2 -> LDS path); PRIMX_GEMM_NOGEMV=1 goes back to them.
+// Few-row Linear (M <= 8: the adaLN modulation of every block from the timestep embeddings - B_e rows per step, or eight
+// timesteps of a planned sampling loop per pass, DiT.plan_timesteps; one 674 MB weight stream per pass at DiT-XL).  HBM-bound:
+// W rows stream with non-temporal 16-byte loads, A (a few KB) comes from L1, M x 4 fp32 partial sums per lane.  The MFMA tiles
+// spent 180 us on it (256-row tiles with 2 valid rows: 1.26 GB through the L2 -> LDS path); PRIMX_GEMM_NOGEMV=1 goes back to them.
 // ROWS = 4 or 8: a row's arithmetic (k order per lane, 16-lane reduction) does not depend on ROWS or on M, so a row computed
 // alone, in a batch of 4 or in a batch of 8 is bit-identical (the per-loop modulation table of DiT.plan_timesteps relies on it).
 // A wave is four 16-lane groups; a group owns GEMV_COLS = 4 columns and its lanes split K in 16-byte chunks (K = 1152: nine
