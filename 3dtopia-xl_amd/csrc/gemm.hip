@@ -735,6 +735,9 @@ __device__ unsigned long long g_gemm_prof[12];
 #ifndef PRIMX_G144_NST
 #define PRIMX_G144_NST 3
 #endif
+#ifndef PRIMX_G144L_EXACT_TAIL
+#define PRIMX_G144L_EXACT_TAIL 0   // loader waves fetch only the tiles that exist (no clamped re-fetch in the last steps)
+#endif
 #ifndef PRIMX_G144_ORDER
 #define PRIMX_G144_ORDER 0   // order of DMA issue / fragment reads / MFMAs inside a step of the 128x144 LDS-DMA kernel
 #endif
@@ -1130,6 +1133,26 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
                 __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + kt * BK),
                                                  (LV*)(smem + stage * STAGE + (lw * NL + i) * 512), 16, 0, 0);
         };
+#if PRIMX_G144L_EXACT_TAIL
+        // Only tiles that exist are fetched (branches are free here: this wave does nothing else).  With the clamped re-fetches
+        // of the 8-wave kernel the last step's barrier waited for one redundant tile and D for two more - about 1.3k cycles per
+        // launch in which the compute waves had nothing left to do.
+        issue(0, 0);
+        if (nk > 1) issue(1, 1);
+        if (nk > 2) issue(2, 2);
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NL) : "memory");   // P: tile 0 landed
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        int st = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            // S_kt: tile kt+1 landed; tile kt+2, if there is one, may fly
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + NST < nk) issue(kt + NST, st);                                        // tile kt's stage is free now
+            st = (st == NST - 1) ? 0 : st + 1;
+        }
+        asm volatile("s_barrier" ::: "memory");                                          // D (nothing is in flight)
+#else
         issue(0, 0);
         issue(min(1, nk - 1), 1);
         issue(min(2, nk - 1), 2);
@@ -1141,6 +1164,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
             st = (st == NST - 1) ? 0 : st + 1;
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                   // D
+#endif
         asm volatile("s_barrier" ::: "memory");                                          // E
         return;
     }
