@@ -735,6 +735,9 @@ __device__ unsigned long long g_gemm_prof[12];
 #ifndef PRIMX_G144_NST
 #define PRIMX_G144_NST 3
 #endif
+#ifndef PRIMX_G144L_XLDS
+#define PRIMX_G144L_XLDS 0   // UNTESTED build option (written at the end of round 2 without a GPU left, see the kernel's comment)
+#endif
 #ifndef PRIMX_G144L_EXACT_TAIL
 #define PRIMX_G144L_EXACT_TAIL 0   // loader waves fetch only the tiles that exist (no clamped re-fetch in the last steps)
 #endif
@@ -1108,6 +1111,13 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
     constexpr int LDS_HALVES = (NST * STAGE > ROWMAJOR_HALVES) ? NST * STAGE : ROWMAJOR_HALVES;
     static_assert(LDS_HALVES * 2 <= 160 * 1024 && NINST % 2 == 0, "LDS budget / loader split");
     __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES];
+    // PRIMX_G144L_XLDS (gate-residual, K >= 128): the loader waves also fetch NXL of the nine 16-byte residual row-chunks of every
+    // thread into the part of the allocation that lies outside the ring during the main loop (thread order: chunk i of thread
+    // tid at XOFF + i * 8 KiB + tid * 16), 7 + 7 + 6 DMA instructions per loader behind the prologue tiles and the first two
+    // steps; the compute waves read them back after D, one more barrier (X) keeps the parking of K-half 1 off that area until
+    // every wave has read.  The fp32 residual read of those chunks (55 % of 18.9 MB per launch) is then under the MFMAs.
+    constexpr int NXL = 5, XOFF_B = NST * STAGE * 2;                                      // bytes
+    static_assert(!PRIMX_G144L_XLDS || XOFF_B + NXL * 8192 <= LDS_HALVES * 2, "residual chunks must fit behind the ring");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1115,6 +1125,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
     const int id = xcd_remap(blockIdx.x, nt * mt);
     const int m0 = (id / nt) * BM, n0 = (id % nt) * BN;
     const int nk = p.K / BK;
+    [[maybe_unused]] const bool xl = PRIMX_G144L_XLDS && EPI == EPI_GATE_RESIDUAL && nk >= 2;   // workgroup-uniform
 
     if (wave >= 8) {
         // ---------------- loader wave lw: instructions t = lw * 17 + i, rows 8t .. 8t+7 of the 272-row stage image
@@ -1133,6 +1144,50 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
                 __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + kt * BK),
                                                  (LV*)(smem + stage * STAGE + (lw * NL + i) * 512), 16, 0, 0);
         };
+#if PRIMX_G144L_XLDS
+        if (xl) {
+            // residual DMA instruction u = i * 8 + w covers chunk i of threads 64 w .. 64 w + 63; loader lw owns u = lw * 20 + j
+            constexpr int NXI = NXL * 8 / 2;                                               // 20 per loader
+            const float* xp[NXI];
+#pragma unroll
+            for (int j = 0; j < NXI; ++j) {
+                const int u = lw * NXI + j;
+                const int cid = (u & 7) * 64 + lane + 512 * (u >> 3);
+                const int row = cid / (BN / 4), c4 = cid - row * (BN / 4);
+                xp[j] = p.x + (int64_t)min(m0 + row, p.M - 1) * p.N + n0 + 4 * c4;
+            }
+            auto issue_x = [&](int j0, int j1) {
+#pragma unroll
+                for (int j = 0; j < NXI; ++j)
+                    if (j >= j0 && j < j1)
+                        __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)xp[j], (LV*)(reinterpret_cast<char*>(smem) + XOFF_B + (lw * NXI + j) * 1024), 16, 0, 0);
+            };
+            // in-order queue of this wave (tile = 17 instructions; XA / XB / XC = 7 / 7 / 6):
+            //   prologue t0 t1 t2 | P: t0 landed (34 may fly) | XA | S_0: t1 landed (t2 XA = 24) | t3 XB | S_1: t2 landed
+            //   (XA t3 XB = 31) | t4 XC | S_2: t3 landed (XB t4 XC = 30) | t5 | S_3: t4 landed (XC t5 = 23) | t6 | S_kt, kt >= 4: 17
+            issue(0, 0);
+            issue(min(1, nk - 1), 1);
+            issue(min(2, nk - 1), 2);
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NL) : "memory");      // P
+            issue_x(0, 7);
+            int st = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                if (kt == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL + 7) : "memory");
+                else if (kt == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL + 14) : "memory");
+                else if (kt == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL + 13) : "memory");
+                else if (kt == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL + 6) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");
+                issue(min(kt + NST, nk - 1), st);
+                if (kt == 0) issue_x(7, 14);
+                if (kt == 1) issue_x(14, 20);
+                st = (st == NST - 1) ? 0 : st + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");               // D: ring drained, residual chunks landed
+            asm volatile("s_barrier" ::: "memory");                                      // X
+            asm volatile("s_barrier" ::: "memory");                                      // E
+            return;
+        }
+#endif
 #if PRIMX_G144L_EXACT_TAIL
         // Only tiles that exist are fetched (branches are free here: this wave does nothing else).  With the clamped re-fetches
         // of the 8-wave kernel the last step's barrier waited for one redundant tile and D for two more - about 1.3k cycles per
@@ -1218,6 +1273,15 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
     constexpr int NROWCH = (BM * (BN / 4)) / 512;
     float* red = reinterpret_cast<float*>(smem);
     float* mine = red + kg * (BM * RS);
+    f32x4 xpre[NROWCH];
+#if PRIMX_G144L_XLDS
+    if (xl) {
+#pragma unroll
+        for (int i = 0; i < NXL; ++i)
+            xpre[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(smem) + XOFF_B + i * 8192 + tid * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                 // X: every wave has its chunks, the area may be parked over
+    }
+#endif
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -1242,7 +1306,6 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
                 rep_i * (h_seg == 0 ? p.rep_stride[0] : h_seg == 1 ? p.rep_stride[1] : p.rep_stride[2]);
     }
     V4e bpre[NROWCH], gpre[NROWCH];
-    f32x4 xpre[NROWCH];
 #pragma unroll
     for (int i = 0; i < NROWCH; ++i) {
         const int cid = tid + 512 * i;
@@ -1252,7 +1315,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
         if (p.bias) bpre[i] = *reinterpret_cast<const V4e*>(p.bias + n0 + 4 * c4);
         if (EPI == EPI_GATE_RESIDUAL) {
             gpre[i] = *reinterpret_cast<const V4e*>(p.gate + (int64_t)(m / p.rows_per_batch) * p.gate_stride + n0 + 4 * c4);
-            xpre[i] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.N + n0 + 4 * c4);
+            if (!(xl && i < NXL)) xpre[i] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.N + n0 + 4 * c4);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                     // E
