@@ -77,6 +77,24 @@ __device__ __forceinline__ V8 shift_plane(const V8 v, const int mask_xp, const i
     }
 }
 
+// One 16x16x32 MFMA whose accumulator lives in the ACCUMULATOR file ("+a").  With the 128 accumulators in VGPRs the
+// kernel sat at exactly 256 registers and hipcc spilled: three accumulator quads across every channel-quarter boundary
+// (stores + reloads with s_waitcnt vmcnt(0) INSIDE the main loop, i.e. a drain of the weight DMA queue) and five address
+// registers - 72 bytes of scratch per lane, 40 MB of extra writes per launch (round-2 PMC: WRITE_SIZE 108 MB for a 67 MB
+// output).  The unified file is split per kernel: 128 AGPRs for the accumulators leave the 128 VGPRs to the activation
+// quarter (32), the weight fragments (32), the shifted plane and addresses - no spill.  FIRST = the operand `b` was just
+// written by the DPP shifts (VALU write -> MFMA read needs wait states that the compiler cannot see inside asm).
+template <int DT, bool FIRST>
+__device__ __forceinline__ void mfma16_acc(f32x4& acc, const typename T16<DT>::V8 a, const typename T16<DT>::V8 b) {
+    if constexpr (DT == PRIMX_F16) {
+        if constexpr (FIRST) asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+        else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    } else {
+        if constexpr (FIRST) asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+        else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    }
+}
+
 // PRIMX_CONV_PROF=1 timeline (sums over all waves, core cycles): [0] waves, [1] entry -> tile 0 landed, [2] main loop,
 // [3] epilogue, [4] of the main loop: parked at the per-tile wait + barrier, [5] weight-DMA issue
 __device__ unsigned long long g_conv_prof[8];
@@ -203,8 +221,9 @@ __global__ __launch_bounds__(512) void conv3_s4c256_kernel(const typename T16<DT
                         // registers alive across tiles is what this kernel has no room for)
                         asm volatile("" : "+v"(a[ksl][z]));
                         const V8 sh = shift_plane<DY, DX>(a[ksl][z], mask_xp, mask_xm);
+                        mfma16_acc<DT, true>(acc[mi][0], wf[0], sh);
 #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<DT>::mfma16(wf[ni], sh, acc[mi][ni]);
+                        for (int ni = 1; ni < NI; ++ni) mfma16_acc<DT, false>(acc[mi][ni], wf[ni], sh);
                         if (n_dma < 4) {
                             __builtin_amdgcn_sched_barrier(0);     // (keeps the DMA behind THIS plane group's MFMAs)
                             unsigned long long pi = 0;

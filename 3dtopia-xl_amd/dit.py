@@ -136,6 +136,9 @@ class DiT(nn.Module):
         self.initialize_weights()
         self._pack: Dict = {}
         self._heads_ws: Dict = {}
+        self._heads_owner: Dict = {}   # workspace key -> the shape group that allocated it (_heads_begin)
+        self._heads_lru: list = []
+        self._heads_group = None
         self._cond: Optional[Dict] = None
         self._packed_only = False   # set when only the packed blob was received / loaded, not the fp32 parameters
         # Opt-in exact-algebra shortcut: to_k(y) / to_v(y) do not depend on the timestep
@@ -166,13 +169,16 @@ class DiT(nn.Module):
     def repack(self) -> None:
         self._t_plan = None
         self._pack = {}
-        self._heads_ws = {}
+        self._heads_ws, self._heads_owner, self._heads_lru, self._heads_group = {}, {}, [], None
         self._cond = None
         self._packed_only = False
 
     def _apply(self, fn, *a, **k):
         self.__dict__["_pack"] = {}
         self.__dict__["_heads_ws"] = {}
+        self.__dict__["_heads_owner"] = {}
+        self.__dict__["_heads_lru"] = []
+        self.__dict__["_heads_group"] = None
         self.__dict__["_cond"] = None
         self.__dict__["_t_plan"] = None
         return super()._apply(fn, *a, **k)
@@ -272,7 +278,8 @@ class DiT(nn.Module):
         fp32 tensors used outside autocast (embedders, null conditioning row) are loaded into their parameters."""
         names = {id(prm): n for n, prm in self.named_parameters()}
         missing = [n for n in names.values() if n not in state_dict]
-        extra = [k for k in state_dict if k not in set(names.values())]
+        known = set(names.values()) | {n for n, _ in self.named_buffers()}      # (buffers - PointEmbed.basis - are constants)
+        extra = [k for k in state_dict if k not in known]
         if missing or extra:
             raise RuntimeError(f"pack_from_state_dict: missing keys {missing[:4]}{'...' if len(missing) > 4 else ''}, "
                                f"unexpected keys {extra[:4]}{'...' if len(extra) > 4 else ''}")
@@ -294,7 +301,7 @@ class DiT(nn.Module):
 
     def _hyper(self) -> Dict:
         proj_bias = self.depth > 0 and self.blocks[0].attn.proj.bias is not None
-        return {"seq_length": self.seq_length, "in_channels": self.in_channels, "condition_channels": self.condition_channels,
+        return {"class": type(self).__name__, "seq_length": self.seq_length, "in_channels": self.in_channels, "condition_channels": self.condition_channels,
                 "hidden_size": self.hidden_size, "depth": self.depth, "num_heads": self.num_heads,
                 "mlp_hidden": self.blocks[0].mlp.fc1.out_features if self.depth else 0, "attn_proj_bias": bool(proj_bias),
                 "cond_drop_prob_positive": self.cond_drop_prob > 0, "out_channels": self.out_channels}
@@ -382,13 +389,31 @@ class DiT(nn.Module):
         key = (tag, B, n, kind, dtype, str(device), pad_to)
         buf = self._heads_ws.get(key)
         if buf is None:
-            if len(self._heads_ws) >= 16:   # shapes changed (another batch / token count): drop the old workspaces
-                self._heads_ws = {}
-                self._cond = None           # its K / V cache pointed into them
             buf = ops.alloc_heads(B, self.num_heads, n, self.hidden_size // self.num_heads, kind, dtype, device, pad_to,
                                   role=tag[0].lower())  # "q" / "k": operand-level key-padding mask (ops.alloc_heads)
             self._heads_ws[key] = buf
+            self._heads_owner[key] = self._heads_group
         return buf
+
+    _HEADS_GROUPS = 3   # (batch, N, L, dtype, device) shapes whose attention workspaces stay allocated
+
+    def _heads_begin(self, group) -> None:
+        """Called once at the start of a forward: marks `group` most recently used and, when more than `_HEADS_GROUPS` shapes
+        are alive, frees the workspaces of the least recently used ones (never in the middle of a forward; a model that
+        alternates between a few shapes keeps all of them instead of re-allocating hundreds of MB per call)."""
+        lru = self._heads_lru
+        if group in lru:
+            lru.remove(group)
+        lru.append(group)
+        self._heads_group = group
+        while len(lru) > self._HEADS_GROUPS:
+            old = lru.pop(0)
+            dead = [k for k, g in self._heads_owner.items() if g == old]
+            for k in dead:
+                self._heads_ws.pop(k, None)
+                self._heads_owner.pop(k, None)
+            if self._cond is not None and self._cond.get("group") == old:
+                self._cond = None           # its K / V cache pointed into them
 
     # ------------------------------------------------------------------ conditioning (step-invariant inputs)
     def _cond_state(self, y: torch.Tensor, null_half: bool, dt) -> Dict:
@@ -404,10 +429,13 @@ class DiT(nn.Module):
         B, L, Dc = y.shape
         Be = 2 * B if null_half else B
         st = self._cond
-        if st is not None:
+        # (a tensor created under torch.inference_mode() tracks no version: in-place edits of it could not be detected, so such a
+        # `y` is never served from the cache - its 16-bit image is rebuilt on every call)
+        ver = None if y.is_inference() else y._version
+        if st is not None and ver is not None:
             k = st["y"]
             if (k.data_ptr() == y.data_ptr() and k.shape == y.shape and k.stride() == y.stride() and k.dtype == y.dtype
-                    and st["ver"] == y._version and st["dt"] == dt and st["null_half"] == null_half):
+                    and st["ver"] == ver and st["dt"] == dt and st["null_half"] == null_half):
                 return st
         # Conditioning rows per batch entry as the K / V projection sees them: padded with zero rows to a multiple of 256
         # when that costs <= 12.5 % (1370 -> 1536), so that GEMM tiles never straddle batch entries and the projection
@@ -424,7 +452,7 @@ class DiT(nn.Module):
         if null_half:   # y_null = null_cond_embedding.expand_as(y)  (dit_crossattn.py:207): one row, broadcast once
             null16 = ops.cast16(self.null_cond_embedding.detach().float().contiguous().to(y.device), dt)
             buf[B:, :L] = null16
-        st = {"y": y, "ver": y._version, "dt": dt, "null_half": null_half, "Lk": Lk, "y16": buf.view(Be * Lk, Dc),
+        st = {"y": y, "ver": ver, "dt": dt, "null_half": null_half, "Lk": Lk, "y16": buf.view(Be * Lk, Dc),
               "kv_valid": False}
         self._cond = st
         return st
@@ -500,6 +528,7 @@ class DiT(nn.Module):
         T = Be * N
         pk = self.packed(dt)
         dev = x.device
+        self._heads_begin((Be, N, L, dt, str(dev)))
 
         xf = x.reshape(B * N, Cin).float().contiguous()
         h = torch.empty(T, D, dtype=torch.float32, device=dev)
@@ -520,6 +549,7 @@ class DiT(nn.Module):
             # adaLN for every block + final layer: SiLU -> one streaming GEMM (dit_crossattn.py:40-43,54,69-75)
             mod = ops.linear(st16, pk["w_ada"], pk["b_ada"])         # [Be, depth*9D + 2D]
         cs = self._cond_state(y, null_half, dt)
+        cs["group"] = self._heads_group
         Lk, y16 = cs["Lk"], cs["y16"]
 
         nq_pad = ops.round_up(N, ops.BQ)
@@ -532,7 +562,7 @@ class DiT(nn.Module):
         Vc_blk = Vc.view(self.depth, Be, *Vc.shape[1:])
         if self.depth and not (self.reuse_cond_kv and cs["kv_valid"] and cs.get("kv_id") == (Kc.data_ptr(), Vc.data_ptr())):
             ops.linear_heads(y16, pk["w_kv_all"], pk["b_kv_all"], Lk, H, dh, [HEADS_KROWS, HEADS_VT], [Kc, Vc],
-                             Kc.shape[2], n_rep=self.depth, rep_batches=Be)
+                             Kc.shape[2], n_rep=self.depth, rep_batches=Be, real_rows=Be * L)
             cs["kv_valid"], cs["kv_id"] = True, (Kc.data_ptr(), Vc.data_ptr())
         Qs = self._heads("Qs", Be, N, HEADS_ROWS, dt, dev, ops.BQ)
         Ks = self._heads("Ks", Be, N, HEADS_KROWS, dt, dev, ops.BQ)
@@ -669,6 +699,10 @@ class DiTAdditivePosEmb(DiT):
         out.copy_(ops.linear_f32(xf, self.x_embedder.weight.detach(), self.x_embedder.bias.detach()) +
                   ops.linear_f32(feat, w.contiguous(), pe.mlp.bias.detach()))
         return out
+
+    def _small_fp32_params(self):
+        # the position-embedding Linear runs in fp32 next to x_embedder: it travels with the packed routes too
+        return super()._small_fp32_params() + [self.point_emb.mlp.weight, self.point_emb.mlp.bias]
 
     def forward_with_cfg(self, *args, **kwargs):
         raise AttributeError("the reference's DiTAdditivePosEmb defines no forward_with_cfg (dit_crossattn.py:215-301)")

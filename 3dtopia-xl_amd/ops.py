@@ -251,14 +251,16 @@ def linear_gate_residual(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.
 
 def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], rows_per_batch: int, heads: int,
                  dh: int, kinds: Sequence[int], dsts: Sequence[torch.Tensor], n_pad: int,
-                 scale0: float = 1.0, n_rep: int = 1, rep_batches: int = 0) -> None:
-    """n_rep > 1: the column groups repeat; repetition r fills batch entries [r*rep_batches, (r+1)*rep_batches) of dsts."""
+                 scale0: float = 1.0, n_rep: int = 1, rep_batches: int = 0, real_rows: Optional[int] = None) -> None:
+    """n_rep > 1: the column groups repeat; repetition r fills batch entries [r*rep_batches, (r+1)*rep_batches) of dsts.
+    `real_rows`: rows of A that are not zero padding (the conditioning tokens are padded 1370 -> 1536 per batch entry) -
+    only the per-kernel FLOP credit of bench.py's roofline leg uses it; the launch covers all M rows."""
     M, K = A.shape
     N = W.shape[0]
     n_seg = len(kinds)
     kind_arr = (C.c_int * n_seg)(*kinds)
     dst_arr = (C.c_void_p * n_seg)(*[_dev(d, "dst", A.dtype) for d in dsts])
-    _timed(f"{_gemm_tag(2, M, N, K, A.dtype, (heads, dh, rows_per_batch, tuple(kinds)))} {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_heads(
+    _timed(f"{_gemm_tag(2, M, N, K, A.dtype, (heads, dh, rows_per_batch, tuple(kinds)))} {M}x{N}x{K}", 2.0 * (real_rows if real_rows is not None else M) * N * K, lambda: check(_lib.load().primx_linear_heads(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None, M, N, K,
         rows_per_batch, heads, dh, n_seg, kind_arr, dst_arr, n_rep, rep_batches, n_pad, scale0, dtype_code(A.dtype),
         _stream()),

@@ -200,10 +200,14 @@ class ShardedSampler:
                                                       device=self.device)
             dec = decode(out)
         if self.world == 1:
+            if dec is None:                                    # batch == 0: an empty result, not None
+                return torch.empty(0, n_tokens, 0, dtype=torch.float32, device=self.device)
             return dec
-        # ranks without samples (batch < world size) still take part in the gather: they learn the feature width first
-        width = [int(dec.shape[-1])] if self.rank == 0 else [None]
-        dist.broadcast_object_list(width, src=0)
+        # ranks without samples (batch < world size) still take part in the gather: they learn the WHOLE per-sample shape
+        # of the decoder's output first (a `decode` may reshape, e.g. [b, N, C, S, S, S]); rank 0 holds samples whenever
+        # batch > 0 (shard_sizes gives the first ranks the larger shares)
+        tail = [tuple(int(d) for d in dec.shape[1:]) if dec is not None else None] if self.rank == 0 else [None]
+        dist.broadcast_object_list(tail, src=0)
         if dec is None:
-            dec = torch.empty(0, n_tokens, width[0], dtype=torch.float32, device=self.device)
+            dec = torch.empty(0, *(tail[0] if tail[0] is not None else (n_tokens, 0)), dtype=torch.float32, device=self.device)
         return gather_batch(dec.float().contiguous(), batch)

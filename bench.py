@@ -14,7 +14,16 @@
 
 N > 1: one process per GPU (torch.distributed / RCCL); rank 0's packed 16-bit weight blob is broadcast once, then every
 rank runs its own batch with no collective inside the loop (weak scaling).  The timed region is K steps between
-barrier + synchronize, repeated R times (median reported); MAX over ranks.
+barrier + synchronize, repeated R times (median reported); MAX over ranks.  Started WITHOUT a
+launcher (`python bench.py --gpus N`, no WORLD_SIZE in the environment) the script re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`; every rank checks that the
+process group really has N ranks and that its GPU exists, and the line reports `n_gpus: N`, per-rank min / max
+ms/step and `weight_broadcast_bytes`.  `--dry-run` stops after the rendezvous (gloo when there is no GPU: the launcher's
+CPU test).
+
+The default (ddim) line also carries the rest of the metric OUTSIDE the headline's timed region: `decode` (the VAE leg
+on this GPU: ms, samples/s, its own roofline / cpu_baseline / parity) and `samples_per_s_measured` (a whole 25-step
+DDIM loop + decode of the sample, timed end to end, median of R) - `value` stays the denoise-steps/s of K steps.
 
 Prints ONE JSON line on rank 0: the contract fields + `roofline` (dominant kernel BY SHAPE, algorithmic FLOPs /
 HIP-event launch time vs the 2.5 PFLOP/s dense fp16 MFMA peak) + `cpu_baseline` (the CPU oracle - a port of the
@@ -134,6 +143,15 @@ def timed_repeats(run_steps, steps: int, repeats: int, world: int, dist, dev):
     return out, mine
 
 
+def traffic_file() -> str:
+    """The newest committed PMC traffic table (profiles/r<round>_traffic.json)."""
+    import glob
+    import re
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")),
+                key=lambda f: int(re.search(r"r(\d+)_traffic", f).group(1)))
+    return fs[-1] if fs else os.path.join(ROOT, "profiles", "none")
+
+
 def kernel_report(prof, steps: int, traffic_file: str):
     agg = {}
     for tag, fl, s, e in prof:
@@ -163,6 +181,61 @@ def kernel_report(prof, steps: int, traffic_file: str):
     return roof, kernels
 
 
+def workload_name(B: int, N: int, dtype: str, schedule: str) -> str:
+    """Name the BASELINE.json configuration the (batch, N_prim, dtype) of this run corresponds to."""
+    base = f"DiT-XL d=1152 depth=28 heads=16x72, N_prim={N}, L_cond={L_COND}x768, CFG 6 (eff. batch {2 * B}/GPU), batch {B}/GPU, {dtype}, {schedule}"
+    if (B, N, dtype) == (1, 2048, "fp16"):
+        return "BASELINE configs[1]: " + base
+    if (B, N) == (8, 2048):
+        return "BASELINE configs[2] per-GPU shape (batch 64 over 8 GPUs -> 8 per GPU): " + base
+    if (B, N, dtype) == (4, 4096, "bf16"):
+        return "BASELINE configs[4] per-GPU shape (batch 16 over 4 GPUs -> 4 per GPU): " + base
+    return "not a BASELINE configuration (custom --batch / --n-prim / --dtype): " + base
+
+
+def self_launch(n: int) -> None:
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def rendezvous(args):
+    """(world, rank, local, dev, dist) with the process group up for world > 1; loud failures instead of a silent 1-rank run."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    have_gpu = torch.cuda.is_available()
+    if not have_gpu and not args.dry_run:
+        raise SystemExit("bench.py: no HIP device visible (only --dry-run works without one)")
+    if have_gpu and torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} are visible")
+    dev = torch.device("cuda", local) if have_gpu else torch.device("cpu")
+    if have_gpu:
+        torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if have_gpu:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        seen = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(seen)
+        if int(seen.item()) != args.gpus or dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: the process group has {int(seen.item())} ranks, --gpus asked for {args.gpus}")
+    return world, rank, local, dev, dist
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,19 +251,23 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline leg)")
+    ap.add_argument("--no-decode-leg", action="store_true", help="ddim: skip the decode sub-record and the measured 25-step samples/s")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous only: print the ranks that met (launcher check; gloo without a GPU)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
+    world, rank, local, dev, dist = rendezvous(args)
+    if args.dry_run:
+        ranks = [None] * world
+        if world > 1:
+            dist.all_gather_object(ranks, (rank, local, str(dev)))
+            dist.destroy_process_group()
+        else:
+            ranks = [(rank, local, str(dev))]
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": ranks}), flush=True)
+        return
 
     import __graft_entry__
     if rank == 0:
@@ -217,7 +294,8 @@ def main() -> None:
             load_synth_weights(model, 28)
         model.reuse_cond_kv = bool(args.reuse_cond_kv)
         wbytes = broadcast_packed_(model, dt, 0)                  # RCCL: the packed 16-bit blob (N > 1)
-    if args.config in ("decode", "c4"):
+    decode_leg = args.config == "ddim" and not args.no_decode_leg
+    if args.config in ("decode", "c4") or decode_leg:
         from oracle import synth
         with torch.device(dev):
             vae = pkg.VAE(**VAE_CFG).eval()
@@ -297,6 +375,45 @@ def main() -> None:
                          "(models/attention.py:106-107 do not depend on t); identical samples (tests/test_hip_fullconfig.py); "
                          "NOT the headline value - that one executes the reference's full algorithmic FLOPs"}
 
+    # ddim: the rest of the metric (SURVEY.md section 8d metric (2)), outside the headline's timed region: the VAE leg on
+    # this GPU, and ONE whole sampling job - the 25-step DDIM loop (plan + 25 x forward_with_cfg + update) followed by the
+    # decode of its sample - timed end to end like inference.py:306-348 runs it.
+    dleg = None
+    if decode_leg:
+        R = max(1, args.repeats)
+        sample = last["out"]["sample"]
+
+        def run_decode(k):
+            for _ in range(k):
+                last["dec"] = pipeline.latents_to_primitives(sample, vae, mean, std)
+
+        def run_job(k):
+            for _ in range(k):
+                s25 = diffusion.ddim_sample_loop(model.forward_with_cfg, tuple(x.shape), noise=x, clip_denoised=False,
+                                                 model_kwargs=kw, device=dev)
+                last["job"] = pipeline.latents_to_primitives(s25, vae, mean, std)
+
+        run_decode(2)
+        KD = 5
+        d_all, _ = timed_repeats(run_decode, KD, R, world, dist, dev)
+        j_all, _ = timed_repeats(run_job, 1, R, world, dist, dev)
+        assert last["dec"].shape == (B, N, 3076) and torch.isfinite(last["dec"]).all() and torch.isfinite(last["job"]).all()
+        d_s, j_s = statistics.median(d_all) / KD, statistics.median(j_all)
+        dleg = {"decode": {"ms": 1e3 * d_s, "samples_per_s": world * B / d_s, "repeats_ms": [1e3 * e / KD for e in d_all],
+                           "workload": f"latents_to_primitives of {B} sample(s) x {N} primitives (latent de-normalise + vae3d_dib "
+                                       f"decode 1x4^3 -> 6x8^3 + inverse normalisation), {args.dtype} MFMA inputs / fp32 accumulation",
+                           "algorithmic_tflops": B * N * VAE_FLOPS_PER_PRIM / 1e12,
+                           "frac_of_mfma_peak": B * N * VAE_FLOPS_PER_PRIM / d_s / 1e12 / PEAK_TFLOPS},
+                "samples_per_s_measured": world * B / j_s, "job_ms": 1e3 * j_s, "job_repeats_ms": [1e3 * e for e in j_all],
+                "job": "one whole 25-step DDIM loop (timestep plan, 25 x forward_with_cfg + fused update) + decode of the "
+                       "sample, barrier + synchronize on both sides, median of R, MAX over ranks"}
+        if not args.no_kernel_events and rank == 0:
+            ops.PROFILE = []
+            run_decode(3)
+            torch.cuda.synchronize()
+            dprof, ops.PROFILE = ops.PROFILE, None
+            dleg["decode"]["roofline"], dleg["decode"]["kernels"] = kernel_report(dprof, 3, traffic_file())
+
     # c4: the decode leg, timed separately (median of R)
     decode_s = None
     if args.config == "c4":
@@ -326,8 +443,7 @@ def main() -> None:
             res.update({
                 "metric": "DiT denoise-steps/sec (N_prim=2048) + samples/sec @25-step DDIM",
                 "value": steps_per_s, "unit": "denoise-steps/s",
-                "config": {"workload": f"BASELINE configs[1]: DiT-XL d=1152 depth=28 heads=16x72, N_prim={N}, "
-                                       f"L_cond={L_COND}x768, CFG 6 (eff. batch {2 * B}/GPU), batch {B}/GPU, ddim25",
+                "config": {"workload": workload_name(B, N, args.dtype, "ddim25"),
                            "parallelism": par, "weight_broadcast_bytes": wbytes, "reuse_cond_kv": bool(args.reuse_cond_kv)},
                 "samples_per_s_at_25_steps": steps_per_s / 25.0,
                 "algorithmic_tflops_per_step": flops_step / 1e12,
@@ -358,8 +474,11 @@ def main() -> None:
         if reuse:
             res["with_reuse_cond_kv"] = reuse
         if prof:
-            tf = os.path.join(ROOT, "profiles", "r2_traffic.json")
-            res["roofline"], res["kernels"] = kernel_report(prof, args.steps, tf)
+            res["roofline"], res["kernels"] = kernel_report(prof, args.steps, traffic_file())
+        if dleg:
+            res["decode"] = dleg["decode"]
+            res["samples_per_s_measured"] = dleg["samples_per_s_measured"]
+            res["measured_job"] = {k: dleg[k] for k in ("job_ms", "job_repeats_ms", "job")}
 
         # ------------------------------------------------------------------ parity of the benchmarked model + CPU baseline
         if world == 1 and args.config == "ddim" and not args.no_parity and N == 2048:
@@ -389,11 +508,19 @@ def main() -> None:
                         "rel_l2_vs_fp32_oracle": float((got - ref).norm() / ref.norm()), "blocks": nb,
                         "oracle": "the cpu_baseline leg's own fp32 forward (oracle/dit_ref.py) of the first 14 blocks + final layer"})
                     del m14
+                if dleg:
+                    rec, ref, z = cpu_baseline_decode(vae_sd, n_prims=512)
+                    got = vae.decode(z.to(dev)).float().cpu()
+                    res["decode"]["cpu_baseline"] = rec
+                    res["decode"]["parity"] = {"max_abs_vs_fp32_oracle": float((got - ref).abs().max()),
+                                               "rel_l2_vs_fp32_oracle": float((got - ref).norm() / ref.norm()),
+                                               "primitives": int(z.shape[0]), "ref_abs_max": float(ref.abs().max())}
             elif args.config == "decode":
                 rec, ref, z = cpu_baseline_decode(vae_sd)
                 res["cpu_baseline"] = rec
                 got = vae.decode(z.to(dev)).float().cpu()
-                res["parity"] = {"max_abs_vs_fp32_oracle": float((got - ref).abs().max()), "primitives": int(z.shape[0]),
+                res["parity"] = {"max_abs_vs_fp32_oracle": float((got - ref).abs().max()),
+                                 "rel_l2_vs_fp32_oracle": float((got - ref).norm() / ref.norm()), "primitives": int(z.shape[0]),
                                  "ref_abs_max": float(ref.abs().max())}
         print(json.dumps(res), flush=True)
     if world > 1:
