@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PRIMX_LIB") or os.path.join(_HERE, "csrc", "libprimx_
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
 HEADS_ROWS, HEADS_VT, HEADS_KROWS = 0, 1, 2
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -23,6 +23,7 @@ _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "primx_abi_version": [],
     "primx_last_error": [],
+    "primx_last_gemm_kernel": [],
     "primx_padded_head_dim": [_i],
     "primx_layernorm_modulate": [_p, _p, _p, _l, _p, _i, _i, _i, _i, _f, _p],
     "primx_timestep_embedding": [_p, _p, _p, _i, _i, _p],
@@ -62,7 +63,10 @@ SIGNATURES = {
     "primx_layernorm_modulate_f32": [_p, _p, _p, _l, _p, _i, _i, _i, _f, _p],
     "primx_silu_f32": [_p, _p, _l, _p],
 }
-_RESTYPES = {"primx_last_error": C.c_char_p}
+_RESTYPES = {"primx_last_error": C.c_char_p, "primx_last_gemm_kernel": C.c_char_p}
+# an alternate build named by PRIMX_LIB (same-box A/B against an older library) may predate these additive entry points
+_OPTIONAL_IN_AB_BUILDS = {"primx_last_gemm_kernel"}
+_AB_ABI_VERSIONS = (18,)
 
 _lib: Optional[C.CDLL] = None
 
@@ -98,12 +102,15 @@ def load(path: Optional[str] = None) -> C.CDLL:
     except Exception:  # pragma: no cover - symbol-table checks work without torch
         pass
     lib = C.CDLL(path)
+    ab = bool(os.environ.get("PRIMX_LIB"))
     for name, argtypes in SIGNATURES.items():
+        if ab and name in _OPTIONAL_IN_AB_BUILDS and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     got = lib.primx_abi_version()
-    if got != ABI_VERSION:
+    if got != ABI_VERSION and not (ab and got in _AB_ABI_VERSIONS):
         raise RuntimeError(f"libprimx_hip.so ABI {got} != expected {ABI_VERSION}; rebuild it")
     if path == LIB_PATH:
         _lib = lib

@@ -629,412 +629,14 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     }
 }
 
-// =====================================================================================================================
-// Version 2: ONE wave per SIMD, 64 query rows per wave (two 32-row blocks), workgroup = 4 waves = 256 query rows.
-//
-// What version 1 leaves on the table (profiles/r1_attn_ablation.txt): with two waves per SIMD running half a
-// step apart behind workgroup barriers, a step costs ~2 x (matrix segment ~1015 + barrier ~370) cycles for 2 x 704 cycles
-// of MFMA pipe time - the pipe is ~50 % busy - and every K / V^T fragment read from LDS feeds ONE 32-row block.  Here a
-// wave owns the whole register file of its SIMD and ping-pongs its OWN two query blocks:
-//
-//   MFMA stream per tile t :  PV_0(t)        QK_0(t+1)      PV_1(t)           QK_1(t+1)         (12 + 10 + 12 + 10 MFMAs)
-//   VALU stream in its shadow: max_1(t), exp_1(t)   ....    max_0(t+1)        exp_0(t+1)
-//
-// Block 0 runs half a tile ahead of block 1, so each block's score tile is single-buffered (64 VGPRs for both), every
-// K / V^T fragment read feeds both blocks (22 ds_read_b128 per 44 MFMAs; 4 waves at ONE barrier per tile), and the
-// exponentials of one block always have the other block's matrix work to hide under.  Per tile and wave: 1408 MFMA pipe
-// cycles against ~1100 VALU issue cycles.
-// Register plan (the reason for the inline-asm PV MFMA): the output accumulators O (2 x 3 x 16 = 96 registers) are only
-// ever touched by the PV MFMAs, so they live in the ACCUMULATOR file ("+a" operands); the scores are produced by builtin
-// MFMAs in VGPR form (attention.hip is compiled with -amdgpu-mfma-vgpr-form, csrc/build.py) because every score is read
-// by VALU code (max, exp) and would otherwise cost a v_accvgpr_read per use (144 per tile in the first build).
-// Tiles: stage t % 3 holds {K(t), V^T(t)}; iteration t reads V^T(t) and K(t+1); the DMA of tile t+2 is issued at its top.
-// Same operand layouts, masks-in-operands and denominator-from-the-MFMA as version 1 (dh < DP only: dh = 72).
-// RTZ = 1: probabilities are packed to 16 bits with round-toward-zero (v_cvt_pkrtz_f16_f32 / a byte permute for bf16:
-// full-rate instructions, the round-to-nearest pack is quarter rate).  The systematic half-ulp bias cancels in the
-// normalisation because the denominator is accumulated from the SAME rounded probabilities (the all-ones row of V^T).
-template <int DT>
-__device__ __forceinline__ void mfma_acc(f32x16& acc, const typename T16<DT>::V8& a, const typename T16<DT>::V8& b) {
-    // s_nop 1: the B operand may have been written by the VALU instruction right in front (cdna4 hazard table: VALU write
-    // -> MFMA source read needs 2 wait states; the compiler does not pad inside or in front of an asm statement)
-    if constexpr (DT == PRIMX_F16)
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-    else
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
-
-template <int DT, int KSTEPS, int DTILES, int RTZ, int PROF = 0>
-__global__ __launch_bounds__(256, 1) void attn2_kernel(const typename T16<DT>::S* __restrict__ Qp,
-                                                        const typename T16<DT>::S* __restrict__ Kp,
-                                                        const typename T16<DT>::S* __restrict__ Vt,
-                                                        typename T16<DT>::S* __restrict__ out, int H, int nq, int nq_pad,
-                                                        int nkv, int nkv_pad, int dh, float c /* scale * log2(e) */) {
-    using S = typename T16<DT>::S;
-    using V8 = typename T16<DT>::V8;
-    using V4 = typename T16<DT>::V4;
-    typedef __attribute__((address_space(1))) const void GV;
-    typedef __attribute__((address_space(3))) void LV;
-    constexpr int DP = 16 * KSTEPS, KROW = DP + 8, VR = 32 * DTILES;
-    constexpr int KT = BKV * KROW, VT_ = VR * 64, BUF = KT + VT_;
-    constexpr int NK = KT / 512, NV = DP / 8, NPC = NK + NV;      // 1 KiB DMA pieces per tile: 11 + 10
-    constexpr int NWV = 4, NSLOT = (NPC + NWV - 1) / NWV, NS = 3;
-    static_assert(KT % 512 == 0, "K tile must be whole 1 KiB pieces");
-    constexpr int QL = 64 * NWV * KROW;                           // the workgroup's pre-scaled Q rows, row stride KROW (conflict-free)
-    __shared__ __attribute__((aligned(16))) S smem[NS * BUF + QL];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int bh = blockIdx.x;
-    const int q0 = blockIdx.y * (64 * NWV) + wave * 64;
-    const S* Kbase = Kp + (int64_t)bh * nkv_pad * KROW;
-    const S* Vbase = Vt + (int64_t)bh * DP * nkv_pad;
-
-    if (VR > DP) {   // V^T rows >= DP of every stage: zero once (they only feed discarded output rows)
-        for (int i = tid; i < (VR - DP) * 64; i += 64 * NWV) {
-#pragma unroll
-            for (int stg = 0; stg < NS; ++stg) smem[stg * BUF + KT + DP * 64 + i] = (S)0.f;
-        }
-    }
-    // Q^T B-operand fragments of both query blocks live in LDS (each wave's 64 rows are private to it; in registers they
-    // would push the V^T fragments into the accumulator file), PRE-SCALED by c = scale * log2(e) (one 16-bit rounding,
-    // 2^-11 relative, like the rounding q already carries) so that the MFMA delivers exp2-domain logits.  Lane (q = l31,
-    // hi) reads d = 16 s + 8 hi .. +7 of its row.  The spare padded columns are put to work (K holds the matching
-    // constants, ops.alloc_heads): column dh = 1 against K's key-padding mask (-30000 on pad rows), columns dh+1 / dh+2 =
-    // -m_hi / -m_lo against K's ones: the MFMA itself subtracts the running row max m (split into two 16-bit halves, exact
-    // products, fp32 accumulation), so a probability is ONE v_exp_f32 of an accumulator register - no VALU subtract.
-    S* qlds = smem + NS * BUF + (wave * 64 + l31) * KROW;          // + b * 32 * KROW: this lane's row of block b
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const S* qrow = Qp + ((int64_t)bh * nq_pad + min(q0 + b * 32 + l31, nq_pad - 1)) * DP + hi * 8;
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            V8 qv = ldg16<V8>(qrow + s * 16);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qv[e] = (S)((float)qv[e] * c);
-            *reinterpret_cast<V8*>(qlds + b * 32 * KROW + s * 16 + hi * 8) = qv;
-        }
-    }
-    auto set_q_cols = [&](int b, float m) {             // columns dh .. dh+3 of block b's Q row: 1, -m_hi, -m_lo, 0 (one 8-byte store)
-        const S mh = (S)(-m);
-        const S ml = (S)(-m - (float)mh);
-        V4 v;
-        v[0] = (S)1.0f; v[1] = mh; v[2] = ml; v[3] = (S)0.f;
-        *reinterpret_cast<V4*>(qlds + b * 32 * KROW + dh) = v;   // both half-waves hold the same m: identical stores
-    };
-
-    // ---- DMA: piece t < NK = 1 KiB piece t of the contiguous K tile; else V^T rows 8 (t - NK) .. +7 (source chunk swizzled).
-    // Wave w owns pieces w * NSLOT ..; a wave with fewer re-issues its last piece, so every wave issues NSLOT per tile.
-    const int ntiles = (nkv + BKV - 1) / BKV;
-    const S* gp[NSLOT];
-    int tstride[NSLOT], ldst[NSLOT];
-    {
-        const int v_lrow = lane >> 3, v_lc = lane & 7;
-#pragma unroll
-        for (int i = 0; i < NSLOT; ++i) {
-            const int pc = min(wave * NSLOT + i, NPC - 1);        // wave-uniform
-            if (pc < NK) {
-                gp[i] = Kbase + pc * 512 + lane * 8;
-                tstride[i] = KT;
-            } else {
-                const int row = 8 * (pc - NK) + v_lrow;
-                gp[i] = Vbase + (int64_t)row * nkv_pad + ((v_lc ^ ((row >> 1) & 7)) * 8);
-                tstride[i] = BKV;
-            }
-            ldst[i] = pc * 512;
-        }
-    }
-    // Staging is REGISTER staging here (global_load_dwordx4 early, ds_write_b128 a whole iteration later), not LDS-DMA: one
-    // global_load_lds costs its wave ~130 issue cycles (780 of ~3000 cycles per tile with 6 pieces per wave, PRIMX_ATTN_PROF=3
-    // - version 1 hides that in the partner wave's matrix segment, a lone wave per SIMD cannot), a global load + ds_write
-    // pair ~20.  The LDS image is the same (piece pc at stage + pc KiB, lane-linear; V^T swizzled on the source address).
-    auto gload = [&](int tile, V8 (&stg)[NSLOT]) {
-        const int tl = min(tile, ntiles - 1);
-#pragma unroll
-        for (int i = 0; i < NSLOT; ++i) stg[i] = ldg16<V8>(gp[i] + (int64_t)tl * tstride[i]);
-    };
-    auto lwrite = [&](int stage, const V8 (&stg)[NSLOT]) {
-#pragma unroll
-        for (int i = 0; i < NSLOT; ++i) *reinterpret_cast<V8*>(smem + stage * BUF + ldst[i] + lane * 8) = stg[i];
-    };
-    auto read_v = [&](int stage, V8 (&vf)[4][DTILES]) {          // [16-key step ks = 2 * half + k2][d tile]
-        const S* vb = smem + stage * BUF + KT + l31 * 64;
-        const int sw = (l31 >> 1) & 7;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int t = 0; t < DTILES; ++t)
-                vf[ks][t] = *reinterpret_cast<const V8*>(vb + t * 32 * 64 + (((2 * ks + hi) ^ sw) * 8));
-    };
-    f32x16 zero16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
-    // S_b^T of the tile in `stage`: 10 MFMAs (VGPR form), 15 fragment reads.  The fragments of the first PRE k-steps are read
-    // a phase EARLIER (qk_pre, placed among the PV MFMAs of the preceding phase): read right in front of their MFMAs, the
-    // LDS latency of every k-step was exposed (C: 680 cycles for 10 MFMAs = 320, PRIMX_ATTN_PROF=3).
-    constexpr int PRE = 2;
-    auto qk_pre = [&](int stage, int b, V8 (&kfp)[PRE][2], V8 (&qfp)[PRE]) {
-        const S* kb = smem + stage * BUF + l31 * KROW + hi * 8;
-        const S* qb = qlds + b * 32 * KROW + hi * 8;
-#pragma unroll
-        for (int s = 0; s < PRE; ++s) {
-            qfp[s] = *reinterpret_cast<const V8*>(qb + s * 16);
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) kfp[s][kt] = *reinterpret_cast<const V8*>(kb + kt * 32 * KROW + s * 16);
-        }
-    };
-    auto qk = [&](int stage, int b, const V8 (&kfp)[PRE][2], const V8 (&qfp)[PRE], f32x16 (&sc)[2]) {
-        const S* kb = smem + stage * BUF + l31 * KROW + hi * 8;
-        const S* qb = qlds + b * 32 * KROW + hi * 8;
-        V8 kf[KSTEPS][2], q[KSTEPS];
-#pragma unroll
-        for (int s = PRE; s < KSTEPS; ++s) {          // the remaining fragments go out first, under the MFMAs of steps 0 .. PRE-1
-            q[s] = *reinterpret_cast<const V8*>(qb + s * 16);
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) kf[s][kt] = *reinterpret_cast<const V8*>(kb + kt * 32 * KROW + s * 16);
-        }
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-                sc[kt] = T16<DT>::mfma32(s < PRE ? kfp[s][kt] : kf[s][kt], s < PRE ? qfp[s] : q[s], s == 0 ? zero16 : sc[kt]);
-    };
-    // One "filler group" of the softmax: the two probabilities (g & 3) * 2, +1 of 16-key step g >> 2 of one query block
-    // = 2 v_exp + 1 pack: what fits in the shadow of ONE 32x32x16 MFMA (8 issue cycles, 32 pipe cycles).
-    auto prob_pair = [&](const f32x16 (&sc)[2], int g, V8 (&pb)[4]) {
-        const int ks = g >> 2, half = ks >> 1, k2 = ks & 1, e = (g & 3) * 2;
-        const float p0 = __builtin_amdgcn_exp2f(sc[half][8 * k2 + e]);
-        const float p1 = __builtin_amdgcn_exp2f(sc[half][8 * k2 + e + 1]);
-        if constexpr (RTZ && DT == PRIMX_F16) {
-            const auto h2 = __builtin_amdgcn_cvt_pkrtz(p0, p1);
-            pb[ks][e] = h2[0];
-            pb[ks][e + 1] = h2[1];
-        } else if constexpr (RTZ) {   // bf16 by truncation: the two high halves in one v_perm_b32
-            const unsigned u = __builtin_amdgcn_perm(__float_as_uint(p1), __float_as_uint(p0), 0x07060302u);
-            typedef S S2 __attribute__((ext_vector_type(2)));
-            const S2 h2 = __builtin_bit_cast(S2, u);
-            pb[ks][e] = h2[0];
-            pb[ks][e + 1] = h2[1];
-        } else {
-            pb[ks][e] = (S)p0;
-            pb[ks][e + 1] = (S)p1;
-        }
-        // anchor: without a use at this point LLVM's IR-level sinking moves the whole group into the block of its first
-        // consumer (the PV MFMAs behind the next rare-rescale branch) - out of the MFMA shadow it was placed in
-        asm volatile("" : "+v"(pb[ks]));
-    };
-
-    f32x16 o[2][DTILES];                              // accumulator file (only the asm PV MFMAs touch them in the loop)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int t = 0; t < DTILES; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[b][t][r] = 0.f;
-    float m_run[2] = {0.f, 0.f};                      // running row max (exp2 domain) the Q columns currently subtract
-    // Row max of a fresh score tile (already relative to m_run: the MFMA subtracted it), as FOUR filler groups of four
-    // v_max3_f32 (a dependent chain: in one piece it ran ~150 cycles with nothing but one MFMA under it) + the decision.
-    // Deferred rescale (cdna_hip_programming.md T13): the running max is only raised - O rescaled, the tile at hand
-    // re-based, the Q columns rewritten - when some row's tile max exceeds it by more than RESCALE_THR; until then the
-    // probabilities are bounded by 2^RESCALE_THR = 256 (finite in fp16 / bf16, fp32 accumulation; the denominator is
-    // accumulated from the same values, so the result is unchanged up to rounding).  With the exact rule ("rescale
-    // whenever any of the wave's 32 rows has a new max") the branch fires on most tiles of random data: P(some row's max
-    // moves at tile j) = 1 - (1 - 1/(j+1))^32 = 64 % even at j = 31.  `force`: first tile (m_run = 0 is no max yet).
-    auto max_part = [&](const f32x16 (&sc)[2], int part, float& mx) {
-#pragma unroll
-        for (int r = 4 * part; r < 4 * part + 4; ++r) {
-            if (r == 0) mx = fmaxf(sc[0][0], sc[1][0]);
-            else mx = fmaxf(fmaxf(mx, sc[0][r]), sc[1][r]);   // -> v_max3_f32
-        }
-        asm volatile("" : "+v"(mx));                         // anchor (see prob_pair)
-    };
-    auto max_decide = [&](f32x16 (&sc)[2], int b, float mx, bool force) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        if (force || !__all(mx <= RESCALE_THR)) {
-            const float delta = force ? mx : fmaxf(mx, 0.f);
-            const float alpha = __builtin_amdgcn_exp2f(-delta);
-            m_run[b] += delta;
-            set_q_cols(b, m_run[b]);
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sc[kt][r] -= delta;         // the tile at hand was formed against the old max
-            // MFMA result -> VALU read distance, independent of placement; the "+a" operands also keep the accumulator-file
-            // reads of the rescale INSIDE this rare branch (hipcc hoisted all 48 v_accvgpr_read above it, executed every tile)
-            static_assert(DTILES == 3, "operand list of the asm below");
-            asm volatile("s_nop 7\n\ts_nop 7" : "+a"(o[b][0]), "+a"(o[b][1]), "+a"(o[b][2]));
-#pragma unroll
-            for (int t = 0; t < DTILES; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[b][t][r] *= alpha;
-        }
-    };
-    auto fold_max = [&](f32x16 (&sc)[2], int b, bool force) {   // un-interleaved form (prologue)
-        float mx = 0.f;
-#pragma unroll
-        for (int part = 0; part < 4; ++part) max_part(sc, part, mx);
-        max_decide(sc, b, mx, force);
-    };
-
-    // ---- prologue: tiles 0 and 1 staged; S_0(0), S_1(0); block 0 is taken half a tile ahead: max_0(0), exp_0(0)
-    set_q_cols(0, 0.f);
-    set_q_cols(1, 0.f);
-    {
-        V8 stg0[NSLOT], stg1[NSLOT];
-        gload(0, stg0);
-        gload(1, stg1);
-        lwrite(0, stg0);
-        lwrite(1, stg1);
-    }
-    __syncthreads();
-    f32x16 s0[2], s1[2];
-    V8 pb0[4], pb1[4];
-    {
-        V8 kfp[PRE][2], qfp[PRE];
-        qk_pre(0, 0, kfp, qfp);
-        qk(0, 0, kfp, qfp, s0);
-        qk_pre(0, 1, kfp, qfp);
-        qk(0, 1, kfp, qfp, s1);
-    }
-    fold_max(s0, 0, true);
-#pragma unroll
-    for (int g = 0; g < 16; ++g) prob_pair(s0, g, pb0);
-
-    // iteration t: entry state = {s1 = S_1(t) raw, pb0 = P_0(t)}; LAST: no tile t+1.
-    // The order of the MFMAs and of their fillers is PINNED with sched_barrier(0): the asm MFMAs have no latency in
-    // hipcc's machine model, left alone it clusters them and moves the fillers next to the builtin MFMAs (ISA of the
-    // first build: "MnMnMnM..." runs with the 8-cycle issue + 24-cycle pipe wait of every PV MFMA exposed).
-#define PRIMX_PIN() __builtin_amdgcn_sched_barrier(0)
-    unsigned long long pt = 0, pacc[6] = {0, 0, 0, 0, 0, 0};      // PROF: cycles in {-, barrier wait, K reads, B, C, D + E}
-    auto stamp = [&](int k) {
-        if (PROF) {
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long now = __builtin_readcyclecounter();
-            pacc[k] += now - pt;
-            pt = now;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    if (PROF) pt = __builtin_readcyclecounter();
-    // stages: tile t lives in stage t % 3
-    auto iter = [&](int t, int st_v, int st_k, int st_fill, bool first, auto last_tag) {
-        constexpr bool LAST = decltype(last_tag)::value;
-        // V^T(t) fragments: its tile landed an iteration ago, so the reads go out BEFORE the barrier and their latency
-        // overlaps the barrier wait.  (Loop-carried - read during the previous iteration - the allocator parked all 48
-        // registers in the accumulator file and copied them back at every loop top.)
-        V8 vf[4][DTILES];
-        read_v(st_v, vf);
-        // the previous iteration's ds_writes of tile t+1 are done (lgkmcnt(0) covers this wave's; the V^T reads above ride
-        // along) and visible after the barrier
-        PRIMX_PIN();
-        __builtin_amdgcn_s_waitcnt(WAITCNT_LGKM0);
-        asm volatile("s_barrier" ::: "memory");
-        PRIMX_PIN();
-        V8 stg[NSLOT];
-        if (!LAST) gload(t + 2, stg);                 // tile t+2: in flight for the whole iteration, written to LDS at its end
-        stamp(1);
-        // B: PV_0(t).  Fillers behind its 12 MFMAs: the four parts of max_1(t), its decision, then exp_1(t) groups 0..5;
-        // the first fragments of QK_0(t+1) are read here.
-        V8 kfp[PRE][2], qfp[PRE];
-        float mx1 = 0.f, mx0 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4 * DTILES; ++i) {
-            mfma_acc<DT>(o[0][i % DTILES], vf[i / DTILES][i % DTILES], pb0[i / DTILES]);
-            PRIMX_PIN();
-            if (i < 4) max_part(s1, i, mx1);
-            if (i == 4) max_decide(s1, 1, mx1, first);
-            if (i == 5 && !LAST) qk_pre(st_k, 0, kfp, qfp);
-            if (i >= 6) prob_pair(s1, i - 6, pb1);
-            PRIMX_PIN();
-        }
-        stamp(3);
-        // C: QK_0(t+1) with exp_1(t) groups 6..15 (compiler-scheduled: builtin MFMAs carry their latency)
-        if (!LAST) qk(st_k, 0, kfp, qfp, s0);
-#pragma unroll
-        for (int g = 6; g < 16; ++g) prob_pair(s1, g, pb1);
-        PRIMX_PIN();
-        stamp(4);
-        // D: PV_1(t).  Fillers: max_0(t+1), its decision, exp_0(t+1) groups 0..5; first fragments of QK_1(t+1)
-#pragma unroll
-        for (int i = 0; i < 4 * DTILES; ++i) {
-            mfma_acc<DT>(o[1][i % DTILES], vf[i / DTILES][i % DTILES], pb1[i / DTILES]);
-            PRIMX_PIN();
-            if (!LAST) {
-                if (i < 4) max_part(s0, i, mx0);
-                if (i == 4) max_decide(s0, 0, mx0, false);
-                if (i == 5) qk_pre(st_k, 1, kfp, qfp);
-                if (i >= 6) prob_pair(s0, i - 6, pb0);
-            }
-            PRIMX_PIN();
-        }
-        // E: QK_1(t+1) with exp_0(t+1) groups 6..15
-        if (!LAST) {
-            qk(st_k, 1, kfp, qfp, s1);
-#pragma unroll
-            for (int g = 6; g < 16; ++g) prob_pair(s0, g, pb0);
-            lwrite(st_fill, stg);                     // tile t+2 -> the stage tile t-1 occupied (last read an iteration ago)
-        }
-        PRIMX_PIN();
-        stamp(5);
-    };
-#undef PRIMX_PIN
-    {
-        int st0 = 0, st1 = 1, st2 = 2;               // stages of tiles t, t+1, t+2
-        for (int t = 0; t + 1 < ntiles; ++t) {
-            iter(t, st0, st1, st2, t == 0, std::false_type{});
-            const int tmp = st0; st0 = st1; st1 = st2; st2 = tmp;
-        }
-        iter(ntiles - 1, st0, st1, st2, ntiles == 1, std::true_type{});
-    }
-    if (PROF && lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&g_attn_prof[k], pacc[k]);
-        atomicAdd(&g_attn_prof[6], (unsigned long long)ntiles);
-    }
-
-    // ---- epilogue: denominator = output row d = dh (all-ones row of V^T), normalise, store out[b, q, h*dh + d]
-    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-    const int rr = dh & 31;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        float lsum = 0.f;
-#pragma unroll
-        for (int t = 0; t < DTILES; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (t == (dh >> 5) && r == ((rr & 3) + 4 * (rr >> 3))) lsum = o[b][t][r];
-        const float inv = 1.0f / __shfl(lsum, l31 + 32 * ((rr >> 2) & 1));
-        const int q = q0 + b * 32 + l31;
-        if (q < nq) {
-            const int bb = bh / H, h = bh - bb * H;
-            S* orow = out + ((int64_t)bb * nq + q) * ((int64_t)H * dh) + (int64_t)h * dh;
-#pragma unroll
-            for (int t = 0; t < DTILES; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d = t * 32 + 8 * g + 4 * hi;
-                    if (d < dh) {
-                        V4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = (S)(o[b][t][4 * g + e] * inv);
-                        *reinterpret_cast<V4*>(orow + d) = v;
-                    }
-                }
-        }
-    }
-}
+// (Round 2 also built a ONE-wave-per-SIMD variant - 64 query rows per wave, O in the accumulator file, register-staged K / V^T,
+// hand-placed VALU fillers between MFMAs - and measured it slower.  A single wave per SIMD issues one VALU instruction per
+// ~4 cycles, half the rate two waves reach, and this kernel is bound by VALU issue (exp, pack, max), not by the matrix pipe.
+// Removed in round 3; the measurements are in DESIGN.md section 5.)
 
 // PRIMX_ATTN_PROF=1|2: run the instrumented variant (dh 72, fp16) synchronously and print the per-segment cycle profile
 static const int g_attn_prof_on = [] {
     const char* e = getenv("PRIMX_ATTN_PROF");
-    return e ? atoi(e) : 0;
-}();
-
-// PRIMX_ATTN_V2 = 0 (default): version 1 (8 waves, ping-pong); 1 / 2: the experimental one-wave-per-SIMD version 2 with
-// round-to-nearest / round-toward-zero probabilities (correct, measured SLOWER: see its header)
-static const int g_attn_v2 = [] {
-    const char* e = getenv("PRIMX_ATTN_V2");
     return e ? atoi(e) : 0;
 }();
 
@@ -1077,28 +679,7 @@ extern "C" int primx_attention(const void* Qp, const void* Kp, const void* Vt, v
     const float c = scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
     PRIMX_DISPATCH_16(dtype, "primx_attention", {
-        if (dh == 72 && g_attn_v2 && (!g_attn_prof_on || g_attn_prof_on == 3) && nq_pad % 256 == 0) {
-            using S = typename T16<DT>::S;
-            dim3 grid(B * H, nq_pad / 256);
-            if (g_attn_prof_on == 3) {
-                unsigned long long z[8] = {0}, r[8];
-                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), z, sizeof(z));
-                hipLaunchKernelGGL((attn2_kernel<DT, 5, 3, 1, 1>), grid, dim3(256), 0, st, (const S*)Qp, (const S*)Kp,
-                                   (const S*)Vt, (S*)out, H, nq, nq_pad, nkv, nkv_pad, dh, c);
-                (void)hipStreamSynchronize(st);
-                (void)hipMemcpyFromSymbol(r, HIP_SYMBOL(g_attn_prof), sizeof(r));
-                const double n = r[6] ? (double)r[6] : 1.0;
-                fprintf(stderr, "attn2 profile (cycles per tile per wave, %llu wave-tiles): max_1 %.0f | barrier wait %.0f | DMA issue + "
-                                "fragment reads %.0f | B (PV_0 + exp_1) %.0f | C (QK_0) %.0f | D + E (PV_1, max_0, exp_0, QK_1) %.0f | "
-                                "total %.0f\n", r[6], r[0] / n, r[1] / n, r[2] / n, r[3] / n, r[4] / n, r[5] / n,
-                        (r[0] + r[1] + r[2] + r[3] + r[4] + r[5]) / n);
-            } else if (g_attn_v2 == 2)
-                hipLaunchKernelGGL((attn2_kernel<DT, 5, 3, 1>), grid, dim3(256), 0, st, (const S*)Qp, (const S*)Kp,
-                                   (const S*)Vt, (S*)out, H, nq, nq_pad, nkv, nkv_pad, dh, c);
-            else
-                hipLaunchKernelGGL((attn2_kernel<DT, 5, 3, 0>), grid, dim3(256), 0, st, (const S*)Qp, (const S*)Kp,
-                                   (const S*)Vt, (S*)out, H, nq, nq_pad, nkv, nkv_pad, dh, c);
-        } else if (dh == 72) launch_attn<DT, 5, 3, 0>(Qp, Kp, Vt, out, B, H, nq, nq_pad, nkv, nkv_pad, dh, c, st);
+        if (dh == 72) launch_attn<DT, 5, 3, 0>(Qp, Kp, Vt, out, B, H, nq, nq_pad, nkv, nkv_pad, dh, c, st);
         else if (dh == 64) launch_attn<DT, 4, 2, 1>(Qp, Kp, Vt, out, B, H, nq, nq_pad, nkv, nkv_pad, dh, c, st);
         else if (dh == 32) launch_attn<DT, 2, 1, 1>(Qp, Kp, Vt, out, B, H, nq, nq_pad, nkv, nkv_pad, dh, c, st);
         else {

@@ -25,10 +25,8 @@ HEADERS = ["common.h", os.path.join("..", "..", "include", "primx_hip.h")]
 LIB = os.path.join(HERE, "libprimx_hip.so")
 MANIFEST = os.path.join(HERE, "build_manifest.json")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
-# Per-file additions.  attention.hip: the one-wave-per-SIMD kernel (attn2_kernel) may use > 256 registers, for which hipcc
-# selects the accumulator-file form of EVERY MFMA and then pays a v_accvgpr_read for each VALU use of a score (144 per
-# tile, measured in the ISA); with the VGPR form as the default the allocator moves only what does not fit.
-EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# Per-file additions (none at present; the hook stays for per-kernel codegen options).
+EXTRA_FLAGS: dict = {}
 
 
 def _hipcc() -> str:

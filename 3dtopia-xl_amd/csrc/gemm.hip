@@ -732,20 +732,11 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const GemmArgs<DT> p) {
 // [2] entry -> tile 0 landed, [3] main loop, [4] epilogue, [5] workgroups, [6] sum of (start - min start) in 10 ns ticks
 __device__ unsigned long long g_gemm_prof[12];
 
-#ifndef PRIMX_G144_NST
-#define PRIMX_G144_NST 3
-#endif
 #ifndef PRIMX_G144L_XLDS
 #define PRIMX_G144L_XLDS 0   // UNTESTED build option (written at the end of round 2 without a GPU left, see the kernel's comment)
 #endif
-#ifndef PRIMX_G144L_EXACT_TAIL
-#define PRIMX_G144L_EXACT_TAIL 0   // loader waves fetch only the tiles that exist (no clamped re-fetch in the last steps)
-#endif
-#ifndef PRIMX_G144_ORDER
-#define PRIMX_G144_ORDER 0   // order of DMA issue / fragment reads / MFMAs inside a step of the 128x144 LDS-DMA kernel
-#endif
 
-template <int DT, int EPI, int REGEPI>
+template <int DT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> p) {
     unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pc2 = 0;
     if (p.prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
@@ -761,7 +752,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     constexpr int RED_HALVES = BM * BN * 2;
     constexpr int RS = BN + 4;                           // fp32 row stride of the row-major epilogue staging
     constexpr int ROWMAJOR_HALVES = 2 * BM * RS * 2;     // both K halves, fp32 (151,552 B)
-    constexpr int NST = PRIMX_G144_NST;                  // ring depth: NST - 1 tiles in flight across every barrier
+    constexpr int NST = 3;                               // ring depth: NST - 1 tiles in flight across every barrier (4 stages measured the same)
     constexpr int LDS_HALVES = (NST * STAGE > ROWMAJOR_HALVES) ? NST * STAGE : ROWMAJOR_HALVES;
     static_assert(LDS_HALVES * 2 <= 160 * 1024 && RED_HALVES <= LDS_HALVES, "LDS budget");
     __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES];
@@ -803,15 +794,13 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // Epilogue form (tile-uniform).  quad_form: column tiles of a PRIMX_HEADS_VT segment (4 consecutive TOKENS per lane is
-    // what that layout wants) or tiles straddling two head segments.  Otherwise `sw`: the MFMA operands are SWAPPED, the
-    // accumulator holds C^T and lane (lr, lg) owns row m = .. + lr and FOUR CONSECUTIVE columns n = .. + 4 lg + r, so the
-    // epilogue works straight from registers with 8 / 16-byte row-major accesses (PRIMX_GEMM_REGEPI=0: LDS row-major walk).
+    // what that layout wants) or tiles straddling two head segments; otherwise the LDS row-major walk below.  (A register
+    // epilogue with swapped MFMA operands - what the 256x288 kernel uses - measured no better here and was removed in round 3.)
     bool quad_form = false;
     if (EPI == EPI_HEADS) {
         const int per = p.heads * p.dh;
         quad_form = (per % BN != 0) || p.kind[(n0 / per) % p.n_seg] == PRIMX_HEADS_VT;
     }
-    const bool sw = REGEPI && !quad_form;   // compile-time true outside the heads epilogue
 
     const int a_row = wm * 32 + lr;
     const int chunk = kg * 4 + lg;
@@ -831,7 +820,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-                acc[i][j] = sw ? T16<DT>::mfma16(b[j], a[i], acc[i][j]) : T16<DT>::mfma16(a[i], b[j], acc[i][j]);
+                acc[i][j] = T16<DT>::mfma16(a[i], b[j], acc[i][j]);
     };
 
     // Ring: tile j lives in stage j % 3.  Step kt: [tile kt+1 landed, everyone done reading tile kt] ->
@@ -840,8 +829,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     // (9 x 16 bytes per thread); they land during the main loop, so the epilogue only has to add and write.
     constexpr int NROWCH = (BM * (BN / 4)) / 512;
     f32x4 xpre[NROWCH];
-    const int m_own = m0 + wm * 32 + kg * 16 + lr;      // sw epilogue: K-half kg finalises M sub-tile mi = kg, all 9 column tiles
-    if (EPI == EPI_GATE_RESIDUAL && !REGEPI) {   // (register epilogue: the residual chunks are loaded after the main loop - 36 VGPRs less in it)
+    if (EPI == EPI_GATE_RESIDUAL) {
 #pragma unroll
         for (int i = 0; i < NROWCH; ++i) {
             const int cid = tid + 512 * i;
@@ -865,21 +853,9 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 * (NST - 2)) : "memory");
         // (Spreading these DMA issues between the MFMA groups, which pays in the 256x288 kernel, measured worse here:
         // main loop 78.2k -> 81.8k cycles at K = 4608.)
-#if PRIMX_G144_ORDER == 0
         issue(min(kt + NST, nk - 1), st_cur);
-        if (p.prof != 2) read_frags(st_next, an, bn);   // prof == 2 / 3: DMA-only / DMA + LDS reads (bound probes, results wrong)
-        if (p.prof < 2) multiply(ac, bc);
-#elif PRIMX_G144_ORDER == 1   // MFMAs first: a wave blocked on the DMA queue has its MFMAs in the pipe already
-        if (p.prof < 2) multiply(ac, bc);
-        __builtin_amdgcn_sched_barrier(0);
-        issue(min(kt + NST, nk - 1), st_cur);
-        if (p.prof != 2) read_frags(st_next, an, bn);
-#else                         // fragment reads, MFMAs, then the DMA issue
-        if (p.prof != 2) read_frags(st_next, an, bn);
-        if (p.prof < 2) multiply(ac, bc);
-        __builtin_amdgcn_sched_barrier(0);
-        issue(min(kt + NST, nk - 1), st_cur);
-#endif
+        read_frags(st_next, an, bn);
+        multiply(ac, bc);
         st_cur = st_next;
         st_next = (st_next == NST - 1) ? 0 : st_next + 1;
     };
@@ -932,64 +908,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
         h_dst = (h_seg == 0 ? p.dst[0] : h_seg == 1 ? p.dst[1] : p.dst[2]) +
                 rep_i * (h_seg == 0 ? p.rep_stride[0] : h_seg == 1 ? p.rep_stride[1] : p.rep_stride[2]);
     }
-    if (sw) {
-        // ---- register epilogue: the two K halves swap one M sub-tile each through LDS (16 bytes per lane per tile, lane-
-        // linear: 72 KB of ds_write_b128 instead of 147 KB of ds_write_b32), then every lane finishes 9 row-chunks
-        using V4e = typename T16<DT>::V4;
-        static_assert(NROWCH == NI, "xpre doubles as the 9 residual chunks of the register epilogue");
-        f32x4* red4 = reinterpret_cast<f32x4*>(smem);
-        const int nb = n0 + 4 * lg;
-        V4e bpre[NI], gpre[NI];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            bpre[j] = V4e{};
-            if (p.bias && EPI != EPI_CONVT) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + nb + j * 16);
-            if (EPI == EPI_GATE_RESIDUAL) {
-                gpre[j] = *reinterpret_cast<const V4e*>(p.gate + (int64_t)(min(m_own, p.M - 1) / p.rows_per_batch) * p.gate_stride + nb + j * 16);
-                xpre[j] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)min(m_own, p.M - 1) * p.N + nb + j * 16);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j) red4[((wm * 2 + (1 - kg)) * NI + j) * 64 + lane] = kg ? acc[0][j] : acc[1][j];
-        __syncthreads();
-        if (p.prof) pc_stg = __builtin_readcyclecounter();
-        f32x4 v[NI];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) v[j] = (kg ? acc[1][j] : acc[0][j]) + red4[((wm * 2 + kg) * NI + j) * 64 + lane];
-        if (m_own < p.M) {
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int n = nb + j * 16;
-                if (EPI == EPI_HEADS && h_fast) {
-                    int d = h_dd0 + 4 * lg + j * 16, hh = h_hh0;
-                    if (d >= p.dh) { d -= p.dh; ++hh; }
-                    if (d >= p.dh) { d -= p.dh; ++hh; }
-                    if (d >= p.dh) { d -= p.dh; ++hh; }
-                    int tok = h_tok0 + (m_own - m0), bb = h_bb0;
-                    if (tok >= p.rows_per_batch) { tok -= p.rows_per_batch; ++bb; }
-                    V4e o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float y = rnd16<DT>(v[j][r] + (p.bias ? (float)bpre[j][r] : 0.f));
-                        if (h_seg == 0 && p.scale0 != 1.0f) y = rnd16<DT>(p.scale0 * y);
-                        o[r] = (S)y;
-                    }
-                    *reinterpret_cast<V4e*>(h_dst + (((int64_t)bb * p.heads + hh) * p.n_pad + tok) * h_rs + d) = o;
-                } else if (EPI == EPI_GATE_RESIDUAL) {
-                    f32x4 xv = xpre[j];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        xv[r] += rnd16<DT>((float)gpre[j][r] * rnd16<DT>(v[j][r] + (p.bias ? (float)bpre[j][r] : 0.f)));
-                    *reinterpret_cast<f32x4*>(p.x + (int64_t)m_own * p.N + n) = xv;
-                } else {
-                    epilogue_row4<DT, EPI>(p, m_own, n, v[j], bpre[j]);
-                }
-            }
-        }
-        prof_end();
-        return;
-    }
-    if (!REGEPI && !quad_form) {
+    if (!quad_form) {
         // bias / gate vectors of this thread's 9 row-chunks: loaded now, they land under the LDS staging below
         using V4e = typename T16<DT>::V4;
         V4e bpre[NROWCH], gpre[NROWCH];
@@ -1188,26 +1107,6 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
             return;
         }
 #endif
-#if PRIMX_G144L_EXACT_TAIL
-        // Only tiles that exist are fetched (branches are free here: this wave does nothing else).  With the clamped re-fetches
-        // of the 8-wave kernel the last step's barrier waited for one redundant tile and D for two more - about 1.3k cycles per
-        // launch in which the compute waves had nothing left to do.
-        issue(0, 0);
-        if (nk > 1) issue(1, 1);
-        if (nk > 2) issue(2, 2);
-        if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NL) : "memory");   // P: tile 0 landed
-        else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        int st = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            // S_kt: tile kt+1 landed; tile kt+2, if there is one, may fly
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            if (kt + NST < nk) issue(kt + NST, st);                                        // tile kt's stage is free now
-            st = (st == NST - 1) ? 0 : st + 1;
-        }
-        asm volatile("s_barrier" ::: "memory");                                          // D (nothing is in flight)
-#else
         issue(0, 0);
         issue(min(1, nk - 1), 1);
         issue(min(2, nk - 1), 2);
@@ -1219,7 +1118,6 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
             st = (st == NST - 1) ? 0 : st + 1;
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                   // D
-#endif
         asm volatile("s_barrier" ::: "memory");                                          // E
         return;
     }
@@ -1267,7 +1165,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                     // D: the stages may be reused
 
     // ---------------- epilogue: both K halves park their accumulators as fp32 [half][128][148]; row-major walk, 4 columns
-    // per thread, 9 row-chunks each (the form of gemm144_dma_kernel<.., REGEPI = 0>).  The residual / gate / bias vectors are
+    // per thread, 9 row-chunks each (the form of gemm144_dma_kernel).  The residual / gate / bias vectors are
     // requested AFTER the parking (the accumulator registers are free by then: held across it they spilled) and land under
     // the barrier
     constexpr int NROWCH = (BM * (BN / 4)) / 512;
@@ -1356,165 +1254,16 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Big tile: 256 x 288, 8 waves = 4 (M) x 2 (N), each wave 64 x 144 = 4 x 9 tiles of 16x16x32, LDS-DMA staging into a
-// 2-stage ring (2 x 69,632 B).  Made for the GEMMs that the 128x144 kernel runs as several sequential rounds per CU
-// (fc1: N = 4608 = 16 x 288 -> exactly 256 workgroups at M = 4096; qkv: 192; the batched to_k/to_v: 2464): every
-// round pays ~5 us of un-overlapped prologue + epilogue (tools/gemm_ksweep.py), while here one barrier interval
-// carries 72 MFMAs per wave (4x), 13 LDS fragment reads per 36 MFMAs (vs 11 per 18) and half the staged bytes
-// per FLOP.  Two barriers per k-tile (landed / consumed); the DMA of tile kt+2 flies during the MFMAs of tile kt+1.
-// Epilogue: four 64-row slabs are staged through LDS as fp32 and walked row-major (or column-quad-wise for
-// PRIMX_HEADS_VT segments) with the same per-unit functions as the 128x144 kernel.
-template <int DT, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm288_dma_kernel(const GemmArgs<DT> p) {
-    unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pc2 = 0;
-    if (p.prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
-    using S = typename T16<DT>::S;
-    using V8 = typename T16<DT>::V8;
-    typedef __attribute__((address_space(1))) const void GV;
-    typedef __attribute__((address_space(3))) void LV;
-    constexpr int BM = 256, BN = 288, MI = 4, NI = 9;
-    constexpr int ROWS = BM + BN;            // 544 rows of 128 bytes per stage
-    constexpr int STAGE = ROWS * 64;         // halves
-    constexpr int NINST = ROWS / 8;          // 68 wave-instructions per stage
-    constexpr int NSLOT = (NINST + 7) / 8;   // 9 (waves 0..3), 8 for waves 4..7
-    __shared__ __attribute__((aligned(16))) S smem[2 * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 15, lg = lane >> 4;
-
-    const int nt = p.N / BN, mt = (p.M + BM - 1) / BM;
-    const int id = xcd_remap(blockIdx.x, nt * mt);
-    const int m0 = (id / nt) * BM, n0 = (id % nt) * BN;
-
-    const S* gp[NSLOT];
-#pragma unroll
-    for (int i = 0; i < NSLOT; ++i) {
-        const int t = min(wave + 8 * i, NINST - 1);
-        const int row = 8 * t + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        gp[i] = (row < BM) ? p.A + (int64_t)min(m0 + row, p.M - 1) * p.K + c * 8
-                           : p.W + (int64_t)(n0 + row - BM) * p.K + c * 8;
-    }
-    const bool last_slot = wave + 8 * (NSLOT - 1) < NINST;  // wave-uniform (waves 0..3)
-    auto issue = [&](int kt, int stage) {
-        S* base = smem + stage * STAGE + wave * 512;
-#pragma unroll
-        for (int i = 0; i < NSLOT; ++i) {
-            if (i < NSLOT - 1 || last_slot)
-                __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + kt * BK), (LV*)(base + i * 8 * 512), 16, 0, 0);
-        }
-    };
-
-    f32x4 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int a_row = wm * 64 + lr, w_row = wn * 144 + lr;
-    auto compute = [&](int stage) {
-        const S* As = smem + stage * STAGE;
-        const S* Ws = As + BM * 64;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int chunk = s * 4 + lg;
-            V8 a[MI], b[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const V8*>(As + lds_off(a_row + i * 16, chunk));
-#pragma unroll
-            for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(Ws + lds_off(w_row + j * 16, chunk));
-            // operands SWAPPED (W fragment as A, activation fragment as B): the accumulator holds C^T, i.e. lane
-            // (lr, lg) owns row m = .. + lr and the FOUR CONSECUTIVE columns n = .. + 4 lg + r - the epilogue then works
-            // straight from registers with 8 / 16-byte row-major accesses and no LDS round trip
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(b[j], a[i], acc[i][j]);
-        }
-    };
-
-    const int nk = p.K / BK;
-    unsigned long long pq[4] = {0, 0, 0, 0};
-    issue(0, 0);
-    issue(min(1, nk - 1), 1);
-    for (int kt = 0; kt < nk; ++kt) {
-        // 8..9 DMAs per tile per wave: <= 8 outstanding means tile kt has landed (tile kt+1 may still fly)
-        unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-        if (p.prof) q0 = __builtin_readcyclecounter();
-        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-        if (p.prof && kt == 0) pc1 = __builtin_readcyclecounter();
-        if (p.prof) q1 = __builtin_readcyclecounter();
-        compute(kt & 1);
-        if (p.prof) { __builtin_amdgcn_sched_barrier(0); q2 = __builtin_readcyclecounter(); }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone is done reading this stage
-        if (p.prof) q3 = __builtin_readcyclecounter();
-        issue(min(kt + 2, nk - 1), kt & 1);
-        if (p.prof) { pq[0] += q1 - q0; pq[1] += q2 - q1; pq[2] += q3 - q2; pq[3] += __builtin_readcyclecounter() - q3; }
-    }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (p.prof) pc2 = __builtin_readcyclecounter();
-
-    // ---- epilogue from registers: acc[i][j][r] = C[m0 + wm*64 + i*16 + lr][n0 + wn*144 + j*16 + 4*lg + r].
-    // Everything the store loop needs from memory (bias, gate, fp32 residual) is loaded BEFORE it, one M-group (9 column
-    // tiles) at a time: a load between stores cannot be hoisted (the output may alias it) and would cost a round trip.
-    using V4e = typename T16<DT>::V4;
-    const int nb = n0 + wn * 144 + 4 * lg;
-    V4e bpre[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        bpre[j] = V4e{};
-        if (p.bias && EPI != EPI_CONVT) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + nb + j * 16);
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + lr;
-        const bool ok = m < p.M;
-        const int mc = ok ? m : p.M - 1;
-        if (EPI == EPI_GATE_RESIDUAL) {
-            const S* grow = p.gate + (int64_t)(mc / p.rows_per_batch) * p.gate_stride + nb;
-            float* xrow = p.x + (int64_t)mc * p.N + nb;
-            V4e gv[NI];
-            f32x4 xv[NI];
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                gv[j] = *reinterpret_cast<const V4e*>(grow + j * 16);
-                xv[j] = *reinterpret_cast<const f32x4*>(xrow + j * 16);
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    xv[j][r] += rnd16<DT>((float)gv[j][r] * rnd16<DT>(acc[i][j][r] + (p.bias ? (float)bpre[j][r] : 0.f)));
-                if (ok) out_store(reinterpret_cast<f32x4*>(xrow + j * 16), xv[j]);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-                if (ok) epilogue_row4<DT, EPI>(p, m, nb + j * 16, acc[i][j], bpre[j]);
-        }
-    }
-    if (p.prof) {
-        __builtin_amdgcn_s_waitcnt(0);
-        const unsigned long long pc3 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
-        if (threadIdx.x == 0) {
-            atomicMin(&g_gemm_prof[0], pr0); atomicMax(&g_gemm_prof[1], pr1);
-            atomicAdd(&g_gemm_prof[2], pc1 - pc0); atomicAdd(&g_gemm_prof[3], pc2 - pc1);
-            atomicAdd(&g_gemm_prof[4], pc3 - pc2); atomicAdd(&g_gemm_prof[5], 1ull); atomicAdd(&g_gemm_prof[6], pr0);
-            const unsigned long long nkk = p.K / BK;
-            atomicAdd(&g_gemm_prof[8], pq[0] / nkk); atomicAdd(&g_gemm_prof[9], pq[1] / nkk);
-            atomicAdd(&g_gemm_prof[10], pq[2] / nkk); atomicAdd(&g_gemm_prof[11], pq[3] / nkk);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Big tile, second pipeline: the same 256 x 288 tile and register epilogue, but the k dimension is staged in 32-wide
-// slices through a 4-stage ring (4 x 34,816 B) with ONE barrier per slice.  The 2-stage 64-wide ring above needs two
-// barriers per tile and issues the next tile's DMAs only after the MFMAs (profile: 754 + 562 cycles per k-tile of DMA
-// wait + issue serial with 2304 MFMA cycles); here the DMAs of slice h+3 are spread between the MFMAs of slice h and
-// have two slices of MFMA time to land.
+// Big tile: 256 x 288, 8 waves = 4 (M) x 2 (N), each wave 64 x 144 = 4 x 9 tiles of 16x16x32.  Made for the GEMMs that the
+// 128x144 kernel runs as several sequential rounds per CU (fc1: N = 4608 = 16 x 288 -> exactly 256 workgroups at M = 4096;
+// qkv: 192; the batched to_k/to_v: 2464): every round pays ~5 us of un-overlapped prologue + epilogue (tools/gemm_ksweep.py),
+// while here one barrier interval carries 4x the MFMAs per LDS byte and half the staged bytes per FLOP.
+// Pipeline: the k dimension is staged in 32-wide slices through a 4-stage LDS-DMA ring (4 x 34,816 B) with ONE barrier per
+// slice; the DMAs of slice h+3 are spread between the MFMAs of slice h and have two slices of MFMA time to land.  (The first
+// form - a 2-stage ring of 64-wide tiles, two barriers per tile, DMAs issued behind the MFMAs - measured 754 + 562 cycles per
+// k-tile of DMA wait + issue serial with the 2304 MFMA cycles and was removed in round 3.)
+// Epilogue: MFMA operands swapped (accumulator = C^T: a lane owns one row and four consecutive columns), so the dense-output
+// epilogues run straight from registers; the heads epilogue parks the tile in LDS and walks it in destination order.
 // LDS rows are 64 bytes (4 chunks of 16 B); chunk' = chunk ^ 2*((row>>3)&1) makes the ds_read_b128 lane groups
 // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) hit 16 distinct 16-byte slots (rows r&3 pick the 64-byte quarter of a
 // 256-byte bank window, the XOR separates rows 0-7 from 8-15 which the groups pair with chunk c and c+1).
@@ -1798,32 +1547,13 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
     prof_end();
 }
 
-// PRIMX_GEMM_REGSTAGE=1 selects the register-staged T144 kernel instead of the LDS-DMA one (A/B measurements)
-static const bool g_force_regstage = [] {
-    const char* e = getenv("PRIMX_GEMM_REGSTAGE");
-    return e && e[0] == '1';
-}();
-
 static const bool g_no_big = [] {   // PRIMX_GEMM_NOBIG=1 disables the 256x288 tile (A/B measurements)
     const char* e = getenv("PRIMX_GEMM_NOBIG");
     return e && e[0] == '1';
 }();
 
-// PRIMX_GEMM_REGEPI=1: register epilogue (swapped MFMA operands) in the 128x144 kernel.  Measured same-box: no gain
-// over the LDS row-major walk (configs[1] 12.00 vs 11.87 ms/step; 64-byte vs 576-byte runs per row), so it stays off;
-// the 256x288 kernel, which has no K split to exchange, always uses it (fc1 epilogue 22k -> 13.8k cycles).
-static const int g_reg_epi = [] {
-    const char* e = getenv("PRIMX_GEMM_REGEPI");
-    return (e && e[0] == '1') ? 1 : 0;
-}();
-
 static const bool g_loader = [] {   // PRIMX_GEMM_LOADER=0: the 128x144 kernel without loader waves (gemm144_dma_kernel) everywhere
     const char* e = getenv("PRIMX_GEMM_LOADER");
-    return !(e && e[0] == '0');
-}();
-
-static const bool g_big_q = [] {   // PRIMX_GEMM_BIGQ=0: 256x288 kernel with the 2-stage 64-wide ring instead of the 4-stage 32-wide one
-    const char* e = getenv("PRIMX_GEMM_BIGQ");
     return !(e && e[0] == '0');
 }();
 
@@ -1837,11 +1567,16 @@ static const bool g_xcd2d = [] {   // PRIMX_GEMM_XCD2D=0: whole tile rows per XC
     return !(e && e[0] == '0');
 }();
 
-static const int g_gemm_prof_mode = [] {   // PRIMX_GEMM_PROF=1: synchronous launches + timeline print; 2: without MFMAs and
-    const char* e = getenv("PRIMX_GEMM_PROF");   // fragment reads (DMA-only bound probe); 3: without MFMAs
-    return e ? atoi(e) : 0;
+static const bool g_gemm_prof_on = [] {   // PRIMX_GEMM_PROF=1: synchronous launches + per-workgroup timeline print (8-wave kernels)
+    const char* e = getenv("PRIMX_GEMM_PROF");
+    return e && atoi(e) != 0;
 }();
-static const bool g_gemm_prof_on = g_gemm_prof_mode != 0;
+
+// The kernel instantiation the last GEMM entry point called on this thread selected, spelled as rocprofv3 prints it
+// (primx_last_gemm_kernel(), include/primx_hip.h): bench.py tags its per-launch timings with what the C side actually
+// launched instead of a Python restatement of the dispatch rules below.
+thread_local char g_last_gemm_kernel[112] = "";
+#define PRIMX_NOTE_KERNEL(...) snprintf(g_last_gemm_kernel, sizeof(g_last_gemm_kernel), __VA_ARGS__)
 
 template <int DT, int EPI, int BIG = 0>
 void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
@@ -1866,21 +1601,25 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
         for (int sgi = 0; sgi < a.n_seg; ++sgi) loader_ok = loader_ok && a.kind[sgi] != PRIMX_HEADS_VT;
     }
     auto go = [&](const GemmArgs<DT>& x) {
-        if (BIG && g_big_q && x.K % 32 == 0) hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
-        else if (BIG) hipLaunchKernelGGL((gemm288_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
-        else if (g_loader && loader_ok && !g_gemm_prof_on) {   // (no timeline stamps in the loader-wave kernel)
-            if constexpr (EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_HEADS)
+        if (BIG) {
+            PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d>", DT, EPI);
+            hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
+        } else if (g_loader && loader_ok && !g_gemm_prof_on) {   // (no timeline stamps in the loader-wave kernel)
+            if constexpr (EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_HEADS) {
+                PRIMX_NOTE_KERNEL("gemm144l_dma_kernel<%d, %d>", DT, EPI);
                 hipLaunchKernelGGL((gemm144l_dma_kernel<DT, EPI>), grid, dim3(640), 0, st, x);
+            }
+        } else {
+            PRIMX_NOTE_KERNEL("gemm144_dma_kernel<%d, %d>", DT, EPI);
+            hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
         }
-        else if (g_reg_epi) hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI, 1>), grid, dim3(512), 0, st, x);
-        else hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI, 0>), grid, dim3(512), 0, st, x);
     };
     if (!g_gemm_prof_on) {
         go(a2);
         return;
     }
     GemmArgs<DT> b = a2;
-    b.prof = g_gemm_prof_mode;
+    b.prof = 1;
     unsigned long long z[12] = {~0ull, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, r[12];
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof(z));
     hipEvent_t e0, e1;
@@ -1895,12 +1634,9 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     const double n = r[5] ? (double)r[5] : 1.0;
     fprintf(stderr, "%s<%d,%d> M=%d N=%d K=%d: %llu workgroups, events %.1f us, first start -> last end %.1f us, mean start offset "
                     "%.1f us; per workgroup (core cycles): entry->tile0 %.0f | main loop %.0f | epilogue %.0f (LDS staging %.0f, read+store issue %.0f)\n",
-            BIG ? (g_big_q ? "gemm288q_dma" : "gemm288_dma") : "gemm144_dma", DT, EPI, a.M, a.N, a.K,
+            BIG ? "gemm288q_dma" : "gemm144_dma", DT, EPI, a.M, a.N, a.K,
             r[5], ms * 1e3, (r[1] - r[0]) * 0.01, (r[6] / n - (double)r[0]) * 0.01, r[2] / n, r[3] / n, r[4] / n, (r[7] >> 32) / n,
             (r[7] & 0xffffffffull) / n);
-    if (BIG && !g_big_q)
-        fprintf(stderr, "   per k-tile (wave 0 of each workgroup, core cycles): wait DMA + barrier %.0f | reads + 72 MFMAs %.0f | lgkm + barrier %.0f | DMA issue %.0f\n",
-                r[8] / n, r[9] / n, r[10] / n, r[11] / n);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 }
 
@@ -1919,7 +1655,7 @@ int launch(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
     // Heads epilogue on the 256x288 tile (LDS-staged scatter, gemm288q only): tiles must cover whole heads of one
     // segment and one batch entry.  It already pays at 192 workgroups (qkv at T = 4096: 75 % of the CUs, one round
     // instead of three rounds of 128x144 tiles); PRIMX_GEMM_BIGHEADS_MIN moves the threshold (0 = never).
-    if (EPI == EPI_HEADS && !g_no_big && g_big_q && g_big_heads_min > 0 && a.heads > 0) {
+    if (EPI == EPI_HEADS && !g_no_big && g_big_heads_min > 0 && a.heads > 0) {
         const int per = a.heads * a.dh;
         // (dh >= 32: the epilogue finds the head of a column with at most 8 compare-subtract steps, 288 / dh <= 9 heads per tile)
         use_big = a.N % 288 == 0 && per % 288 == 0 && 288 % a.dh == 0 && a.dh % 8 == 0 && a.dh >= 32 && a.rows_per_batch % 256 == 0 &&
@@ -1928,16 +1664,20 @@ int launch(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
 #define PRIMX_GEMM_LAUNCH(KT)                                                                                         \
     do {                                                                                                              \
         if (a.N <= 32) {                                                                                              \
+            PRIMX_NOTE_KERNEL("gemm_kernel<%d, %d, 32, 4, 1, 1, 1, %d, %d>", DT, EPI, GATHER, KT);                    \
             hipLaunchKernelGGL((gemm_kernel<DT, EPI, 32, 4, 1, 1, 1, GATHER, KT>), dim3(mt * ((a.N + 31) / 32)),      \
                                dim3(256), 0, st, a);                                                                  \
         } else if (use_big && KT == 0 && !GATHER) {                                                                   \
             launch144_dma<DT, EPI, 1>(a, mt, st);                                                                     \
         } else if (a.N % 144 == 0 && !GATHER) {                                                                       \
-            if (KT == 0 && !g_force_regstage)                                                                        \
+            if (KT == 0) {                                                                                            \
                 launch144_dma<DT, EPI>(a, mt, st);                                                                    \
-            else                                                                                                      \
+            } else {                                                                                                  \
+                PRIMX_NOTE_KERNEL("gemm144_kernel<%d, %d, %d>", DT, EPI, KT);                                         \
                 hipLaunchKernelGGL((gemm144_kernel<DT, EPI, KT>), dim3(mt * (a.N / 144)), dim3(512), 0, st, a);       \
+            }                                                                                                         \
         } else {                                                                                                      \
+            PRIMX_NOTE_KERNEL("gemm_kernel<%d, %d, 32, 2, 2, 2, 2, %d, %d>", DT, EPI, GATHER, KT);                    \
             hipLaunchKernelGGL((gemm_kernel<DT, EPI, 32, 2, 2, 2, 2, GATHER, KT>), dim3(mt * ((a.N + 127) / 128)),    \
                                dim3(256), 0, st, a);                                                                  \
         }                                                                                                             \
@@ -2027,6 +1767,8 @@ static const bool g_no_gemv = [] {
 
 }  // namespace
 
+extern "C" const char* primx_last_gemm_kernel(void) { return g_last_gemm_kernel; }
+
 extern "C" int primx_linear(const void* A, const void* W, const void* bias, void* out, int M, int N, int K, int dtype,
                             int act, float out_scale, void* stream) {
     PRIMX_REQUIRE(out, "primx_linear: null output");
@@ -2037,6 +1779,7 @@ extern "C" int primx_linear(const void* A, const void* W, const void* bias, void
         PRIMX_DISPATCH_16(dtype, "primx_linear", {
             using S = typename T16<DT>::S;
             const dim3 grid((N / GEMV_COLS + 15) / 16);   // 4 waves x 4 groups of 4 columns per workgroup
+            PRIMX_NOTE_KERNEL("gemv16_kernel<%d, %d>", DT, M <= 4 ? 4 : 8);
             if (M <= 4)
                 hipLaunchKernelGGL((gemv16_kernel<DT, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const S*)A, (const S*)W,
                                    (const S*)bias, (S*)out, M, N, K);

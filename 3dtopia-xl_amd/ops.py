@@ -82,36 +82,6 @@ def on_input_device(fn):
 PROFILE = None
 
 
-def _gemm_tag(epi: int, M: int, N: int, K: int, dtype, heads=None) -> str:
-    """Name of the kernel instantiation the C side selects (csrc/gemm.hip launch()), spelled as rocprofv3 prints
-    it, so bench.py's per-kernel numbers can be matched against profiles/*kernel_trace_summary.txt."""
-    dt = dtype_code(dtype)
-    if N <= 32:
-        return f"gemm_kernel<{dt}, {epi}, 32, 4, 1, 1, 1, 0, {int(K % 64 != 0)}>"
-    if epi == 2 and heads is not None and K % 64 == 0 \
-            and os.environ.get("PRIMX_GEMM_BIGQ", "1") != "0" and os.environ.get("PRIMX_GEMM_NOBIG") != "1":
-        H, dh, rows = heads[:3]   # heads epilogue on the 256x288 tile (csrc/gemm.hip launch(): whole heads, one batch entry)
-        wg_min = int(os.environ.get("PRIMX_GEMM_BIGHEADS_MIN", "160"))
-        if wg_min > 0 and N % 288 == 0 and (H * dh) % 288 == 0 and 288 % dh == 0 and dh % 8 == 0 and dh >= 32 and rows % 256 == 0 \
-                and (M // 256) * (N // 288) >= wg_min:
-            return f"gemm288q_dma_kernel<{dt}, {epi}>"
-    if epi != 2 and N % 288 == 0 and K % 64 == 0 and ((M + 255) // 256) * (N // 288) >= 224:
-        q = "" if os.environ.get("PRIMX_GEMM_BIGQ", "1") == "0" else "q"
-        return f"gemm288{q}_dma_kernel<{dt}, {epi}>"
-    if N % 144 == 0 and K % 64 == 0 and os.environ.get("PRIMX_GEMM_LOADER", "1") != "0" and not os.environ.get("PRIMX_GEMM_PROF"):
-        ok = epi in (0, 1)                   # loader-wave kernel: row-major epilogues (csrc/gemm.hip launch144_dma)
-        if epi == 2 and heads is not None:
-            H, dh, rows = heads[:3]
-            kinds = heads[3] if len(heads) > 3 else (HEADS_VT,)
-            ok = (H * dh) % 144 == 0 and dh >= 48 and dh % 4 == 0 and rows >= 128 and all(k != HEADS_VT for k in kinds)
-        if ok:
-            return f"gemm144l_dma_kernel<{dt}, {epi}>"
-    if N % 144 == 0:
-        regepi = int(os.environ.get("PRIMX_GEMM_REGEPI", "0") == "1")
-        return f"gemm144_dma_kernel<{dt}, {epi}, {regepi}>" if K % 64 == 0 else f"gemm144_kernel<{dt}, {epi}, 1>"
-    return f"gemm_kernel<{dt}, {epi}, 32, 2, 2, 2, 2, 0, {int(K % 64 != 0)}>"
-
-
 def _timed(tag: str, flops: float, fn):
     if PROFILE is None:
         return fn()
@@ -119,6 +89,11 @@ def _timed(tag: str, flops: float, fn):
     s.record()
     r = fn()
     e.record()
+    if tag.startswith("None "):      # a GEMM entry point ("None MxNxK"): ask the library which instantiation it launched -
+        # the tag is the name the C side reports (primx_last_gemm_kernel), not a Python restatement of its dispatch rules
+        lib = _lib.load()
+        name = lib.primx_last_gemm_kernel().decode() if hasattr(lib, "primx_last_gemm_kernel") else "gemm(unreported)"
+        tag = name + tag[4:]
     PROFILE.append((tag, flops, s, e))
     return r
 
@@ -226,10 +201,7 @@ def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: 
         raise RuntimeError("linear: operand mismatch")
     if out is None:
         out = torch.empty(M, N, dtype=A.dtype, device=A.device)
-    tag = _gemm_tag(0, M, N, K, A.dtype)
-    if M <= 8 and N % 4 == 0 and K % 8 == 0 and act == 0 and out_scale == 1.0 and os.environ.get("PRIMX_GEMM_NOGEMV") != "1":
-        tag = f"gemv16_kernel<{dtype_code(A.dtype)}, {4 if M <= 4 else 8}>"     # few-row streaming path (csrc/gemm.hip primx_linear)
-    _timed(f"{tag} {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear(
+    _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear(
         _dev(A, "A"), _dev(W, "W"), _dev(bias, "bias", A.dtype) if bias is not None else None,
         _dev(out, "out", A.dtype), M, N, K, dtype_code(A.dtype), act, out_scale, _stream()), "primx_linear"))
     return out
@@ -242,7 +214,7 @@ def linear_gate_residual(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.
     N = W.shape[0]
     if gate.stride(-1) != 1 or gate.dtype != A.dtype or not gate.is_cuda:
         raise RuntimeError("gate must be a last-dim-contiguous 16-bit device view")
-    _timed(f"{_gemm_tag(1, M, N, K, A.dtype)} {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_gate_residual(
+    _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_gate_residual(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None,
         gate.data_ptr(), gate.stride(0), _dev(x, "x", torch.float32), M, N, K, rows_per_batch,
         dtype_code(A.dtype), _stream()), "primx_linear_gate_residual"))
@@ -260,7 +232,7 @@ def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     n_seg = len(kinds)
     kind_arr = (C.c_int * n_seg)(*kinds)
     dst_arr = (C.c_void_p * n_seg)(*[_dev(d, "dst", A.dtype) for d in dsts])
-    _timed(f"{_gemm_tag(2, M, N, K, A.dtype, (heads, dh, rows_per_batch, tuple(kinds)))} {M}x{N}x{K}", 2.0 * (real_rows if real_rows is not None else M) * N * K, lambda: check(_lib.load().primx_linear_heads(
+    _timed(f"None {M}x{N}x{K}", 2.0 * (real_rows if real_rows is not None else M) * N * K, lambda: check(_lib.load().primx_linear_heads(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None, M, N, K,
         rows_per_batch, heads, dh, n_seg, kind_arr, dst_arr, n_rep, rep_batches, n_pad, scale0, dtype_code(A.dtype),
         _stream()),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 18
+#define PRIMX_ABI_VERSION 19
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -53,6 +53,11 @@ extern "C" {
 
 int primx_abi_version(void);
 const char* primx_last_error(void);
+/* Name of the GEMM kernel instantiation that the last primx_linear / primx_linear_gate_residual / primx_linear_heads /
+ * primx_linear_residual / primx_conv3d_k3 / primx_convtranspose_k2s2 call on THIS thread launched, spelled as rocprofv3
+ * prints it (e.g. "gemm144l_dma_kernel<1, 1>"); "" before the first call.  Measurement plumbing only (bench.py tags its
+ * per-launch HIP-event timings with it): no counterpart in the reference.  ABI 19. */
+const char* primx_last_gemm_kernel(void);
 
 /* Padded head dim used by the attention layouts: smallest multiple of 16 >= dh (72 -> 80). */
 int primx_padded_head_dim(int dh);

@@ -75,19 +75,6 @@ def test_deferred_rescale_ramp(ops):
     assert rel_l2(got, ref) < TOL[torch.float16], rel_l2(got, ref)
 
 
-def test_alternative_kernels_stay_correct():
-    """The experimental one-wave-per-SIMD kernel (PRIMX_ATTN_V2=2; correct, slower - csrc/attention.hip) runs the same
-    accuracy tests in a child process (the switch is read once at library load)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, PRIMX_ATTN_V2="2")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k",
-                        "float64 or spike or ramp or strided or properties"], env=env, capture_output=True, text=True,
-                       timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-
-
 def test_properties_at_full_size(ops):
     """N_prim = 2048, 16 heads x 72 (BASELINE config 2 shape), checked through properties that need
     no O(N^2) reference: (1) V = const -> output = const (softmax rows sum to 1); (2) linearity in V;

@@ -171,25 +171,3 @@ def test_load_checkpoints_takes_the_packed_routes(pkg, tmp_path):
     mapped = pkg.DiT(**_SMALL_DIT)
     pipeline.load_checkpoints(model=mapped, dit_checkpoint_path=pk_path)
     assert torch.equal(want, mapped._pack[(torch.float16, torch.device("cpu"))]["_flat"].view(torch.int16))
-
-
-def test_kernel_tags_of_the_headline_shapes(pkg, monkeypatch):
-    """bench.py's per-kernel lines and profiles/r2_traffic.json are keyed by the kernel name ops._gemm_tag predicts for a
-    launch (the C side's selection rules, csrc/gemm.hip launch() / launch144_dma, restated): the BASELINE configs[1] shapes."""
-    from importlib import import_module
-    ops = import_module(pkg.__name__ + ".ops")
-    for var in ("PRIMX_GEMM_LOADER", "PRIMX_GEMM_PROF", "PRIMX_GEMM_BIGQ", "PRIMX_GEMM_NOBIG", "PRIMX_GEMM_REGEPI", "PRIMX_GEMM_BIGHEADS_MIN"):
-        monkeypatch.delenv(var, raising=False)
-    f16, T, D = torch.float16, 4096, 1152
-    lib = import_module(pkg.__name__ + "._lib")
-    assert ops._gemm_tag(1, T, D, D, f16) == "gemm144l_dma_kernel<1, 1>"                       # proj / cproj
-    assert ops._gemm_tag(1, T, D, 4 * D, f16) == "gemm144l_dma_kernel<1, 1>"                   # fc2
-    assert ops._gemm_tag(0, T, 4 * D, D, f16) == "gemm288q_dma_kernel<1, 0>"                   # fc1: 256 workgroups of 256 x 288
-    assert ops._gemm_tag(2, T, D, D, f16, (16, 72, 2048, (lib.HEADS_ROWS,))) == "gemm144l_dma_kernel<1, 2>"          # to_q
-    assert ops._gemm_tag(2, T, 3 * D, D, f16, (16, 72, 2048, (lib.HEADS_ROWS, lib.HEADS_KROWS, lib.HEADS_VT))) == "gemm288q_dma_kernel<1, 2>"   # qkv
-    assert ops._gemm_tag(0, T, 136, D, f16).startswith("gemm_kernel<1, 0, 32, 2, 2, 2, 2")   # final layer
-    monkeypatch.setenv("PRIMX_GEMM_LOADER", "0")
-    assert ops._gemm_tag(1, T, D, D, f16) == "gemm144_dma_kernel<1, 1, 0>"
-    # a V^T segment keeps the 8-wave kernel's quad-form epilogue
-    monkeypatch.delenv("PRIMX_GEMM_LOADER")
-    assert ops._gemm_tag(2, 1370, 2 * D, 768, f16, (16, 72, 1370, (lib.HEADS_KROWS, lib.HEADS_VT))) == "gemm144_dma_kernel<1, 2, 0>"

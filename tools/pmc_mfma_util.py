@@ -1,0 +1,77 @@
+"""Per-(kernel, shape) MFMA utilisation from ONE rocprofv3 pass of bench.py:
+
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU \\
+              GRBM_GUI_ACTIVE --output-format csv -d DIR -o NAME -- python bench.py ...
+    python tools/pmc_mfma_util.py DIR/**/NAME_counter_collection.csv <DIR/**/NAME_kernel_trace.csv | -> out.txt
+
+MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE): busy cycles are summed over the chip's
+SIMDs, GUI_ACTIVE counts the clock while the dispatch is on the GPU, so the ratio is clock-independent.  The effective
+shader clock = GRBM_GUI_ACTIVE / kernel duration (profiled passes clock lower than free runs, MI355X_MICROARCH.md DVFS
+note).  "frac of 2.5 PF" = algorithmic FLOPs / duration of THIS (profiled) pass / peak."""
+import collections
+import csv
+import re
+import sys
+
+sys.argv += [None] * 5
+cfile, tfile, out, mode = sys.argv[1], sys.argv[2], sys.argv[3], (sys.argv[4] or "ddim")
+from pmc_traffic import CYCLES, short   # the launch-order -> shape tables  # noqa: E402
+
+FLOPS = {"4096x1152x1152": 2 * 4096 * 1152 * 1152, "4096x1152x4608": 2 * 4096 * 1152 * 4608, "4096x4608x1152": 2 * 4096 * 4608 * 1152,
+         "4096x3456x1152": 2 * 4096 * 3456 * 1152, "3072x64512x768": 2 * 2740 * 64512 * 768,
+         "32x2048x2048x72": 4 * 32 * 2048 * 2048 * 72, "32x2048x1370x72": 4 * 32 * 2048 * 1370 * 72,
+         "256->256 @4^3 x2048": 2 * 2048 * 64 * 256 * 27 * 256}
+
+
+def tag_of(kname, grid, seen):
+    k = short(kname)
+    cyc = CYCLES.get(k)
+    if k.startswith("gemm288q_dma_kernel<1, 2>"):
+        return k + (" 3072x64512x768" if grid > 512 * 400 else " 4096x3456x1152")
+    if cyc:
+        t = f"{k} {cyc[seen[k] % len(cyc)]}"
+        seen[k] += 1
+        return t
+    return k
+
+
+dur = {}
+if tfile and tfile != "-":
+    for r in csv.DictReader(open(tfile)):
+        dur[int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+rows = collections.defaultdict(dict)
+meta = {}
+for r in csv.DictReader(open(cfile)):
+    d = int(r["Dispatch_Id"])
+    rows[d][r["Counter_Name"]] = float(r["Counter_Value"])
+    meta[d] = (r["Kernel_Name"], int(r.get("Grid_Size", 0)))
+    if d not in dur and r.get("End_Timestamp"):      # the counter csv carries the dispatch's own timestamps too
+        dur[d] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+seen = collections.Counter()
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in sorted(rows):
+    tag = tag_of(meta[d][0], meta[d][1], seen)
+    for c, v in rows[d].items():
+        agg[tag][c].append(v)
+    if d in dur:
+        agg[tag]["us"].append(dur[d])
+mean = lambda v: sum(v) / len(v) if v else float("nan")
+lines = ["# per (kernel, shape): means over the launches of one profiled bench pass; MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE)",
+         f"{'launches':>8} {'us':>8} {'clk GHz':>8} {'MFMA util':>9} {'MFMA insts':>11} {'VALU act/wave-cyc':>17} {'TF/s':>7} {'of 2.5PF':>8}  kernel"]
+for tag in sorted(agg, key=lambda t: -sum(agg[t]["us"])):
+    a = agg[tag]
+    if not any(s in tag for s in ("gemm", "attn", "conv", "ln_modulate", "gemv", "groupnorm")):
+        continue
+    us, gui, busy = mean(a["us"]), mean(a["GRBM_GUI_ACTIVE"]), mean(a["SQ_VALU_MFMA_BUSY_CYCLES"])
+    clk = gui / us / 1e3 if us else float("nan")
+    div = 8.0 if clk > 4.0 else 1.0        # some rocprofv3 builds sum GUI_ACTIVE over the 8 XCDs
+    gui /= div
+    clk /= div
+    util = busy / (1024.0 * gui) if gui else float("nan")
+    shape = tag.split("> ")[-1] if "> " in tag else ""
+    fl = FLOPS.get(shape)
+    tf = fl / us / 1e6 if fl and us else float("nan")
+    valu = mean(a["SQ_ACTIVE_INST_VALU"]) / mean(a["SQ_WAVE_CYCLES"]) if a["SQ_WAVE_CYCLES"] else float("nan")
+    lines.append(f"{len(a['us']):8d} {us:8.2f} {clk:8.2f} {util:9.3f} {mean(a['SQ_INSTS_MFMA']):11.4g} {valu:17.3f} {tf:7.0f} {tf / 2500.0:8.3f}  {tag}")
+open(out, "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))

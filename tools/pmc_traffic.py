@@ -49,15 +49,20 @@ def load(path, counter):
     return acc
 
 
-f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in sorted(set(f) | set(w)):
-    if not any(s in k for s in ("gemm", "attn", "ln_modulate", "gemv", "conv", "groupnorm")):
-        continue
-    fk = sum(f.get(k, [0])) / max(len(f.get(k, [])), 1)
-    wk = sum(w.get(k, [0])) / max(len(w.get(k, [])), 1)
-    out[k] = {"launches_sampled": len(f.get(k, [])), "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
-              "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-for k, v in out.items():
-    print(f"{v['hbm_bytes_per_launch']/1e6:10.1f} MB/launch  fetch {v['FETCH_SIZE_KiB']:12.0f} KiB  write {v['WRITE_SIZE_KiB']:12.0f} KiB  n={v['launches_sampled']:5d}  {k}")
+def main():
+    f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(f) | set(w)):
+        if not any(s in k for s in ("gemm", "attn", "ln_modulate", "gemv", "conv", "groupnorm")):
+            continue
+        fk = sum(f.get(k, [0])) / max(len(f.get(k, [])), 1)
+        wk = sum(w.get(k, [0])) / max(len(w.get(k, [])), 1)
+        out[k] = {"launches_sampled": len(f.get(k, [])), "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
+                  "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    for k, v in out.items():
+        print(f"{v['hbm_bytes_per_launch']/1e6:10.1f} MB/launch  fetch {v['FETCH_SIZE_KiB']:12.0f} KiB  write {v['WRITE_SIZE_KiB']:12.0f} KiB  n={v['launches_sampled']:5d}  {k}")
+
+
+if __name__ == "__main__":
+    main()
