@@ -729,12 +729,9 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const GemmArgs<DT> p) {
 // (cdna_hip_programming.md rule 21).  Sync per k-tile: s_waitcnt vmcnt(4) (this wave's DMAs of tile kt have
 // landed, tile kt+1's stay in flight) + raw s_barrier; __syncthreads() would drain the ring.
 // timeline profile (PRIMX_GEMM_PROF=1): [0] min start, [1] max end (s_memrealtime, 100 MHz), sums of core-clock cycles:
-// [2] entry -> tile 0 landed, [3] main loop, [4] epilogue, [5] workgroups, [6] sum of (start - min start) in 10 ns ticks
+// [2] entry -> tile 0 landed, [3] main loop, [4] epilogue, [5] workgroups, [6] sum of (start - min start) in 10 ns ticks,
+// [8] / [9] sums of each workgroup's lifetime in 10 ns ticks / in core cycles (their ratio = the shader clock under this kernel)
 __device__ unsigned long long g_gemm_prof[12];
-
-#ifndef PRIMX_G144L_XLDS
-#define PRIMX_G144L_XLDS 0   // UNTESTED build option (written at the end of round 2 without a GPU left, see the kernel's comment)
-#endif
 
 template <int DT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> p) {
@@ -878,6 +875,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
                 atomicMin(&g_gemm_prof[0], pr0); atomicMax(&g_gemm_prof[1], pr1);
                 atomicAdd(&g_gemm_prof[2], pc1 - pc0); atomicAdd(&g_gemm_prof[3], pc2 - pc1);
                 atomicAdd(&g_gemm_prof[4], pc3 - pc2); atomicAdd(&g_gemm_prof[5], 1ull); atomicAdd(&g_gemm_prof[6], pr0);
+                atomicAdd(&g_gemm_prof[8], pr1 - pr0); atomicAdd(&g_gemm_prof[9], pc3 - pc0);   // -> the shader clock while this kernel runs
             }
         }
     };
@@ -1030,21 +1028,22 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
     constexpr int LDS_HALVES = (NST * STAGE > ROWMAJOR_HALVES) ? NST * STAGE : ROWMAJOR_HALVES;
     static_assert(LDS_HALVES * 2 <= 160 * 1024 && NINST % 2 == 0, "LDS budget / loader split");
     __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES];
-    // PRIMX_G144L_XLDS (gate-residual, K >= 128): the loader waves also fetch NXL of the nine 16-byte residual row-chunks of every
-    // thread into the part of the allocation that lies outside the ring during the main loop (thread order: chunk i of thread
-    // tid at XOFF + i * 8 KiB + tid * 16), 7 + 7 + 6 DMA instructions per loader behind the prologue tiles and the first two
-    // steps; the compute waves read them back after D, one more barrier (X) keeps the parking of K-half 1 off that area until
-    // every wave has read.  The fp32 residual read of those chunks (55 % of 18.9 MB per launch) is then under the MFMAs.
-    constexpr int NXL = 5, XOFF_B = NST * STAGE * 2;                                      // bytes
-    static_assert(!PRIMX_G144L_XLDS || XOFF_B + NXL * 8192 <= LDS_HALVES * 2, "residual chunks must fit behind the ring");
-
+    // (Round 2 left an untested option here - the LOADER waves fetching 5 of the 9 fp32 residual row-chunks of every thread by
+    // LDS-DMA into the 47 KB behind the ring.  Measured in round 3, same box: gate-residual 19.3 / 19.5 vs 19.2 / 18.4 us at
+    // K = 1152, 49.6 / 47.8 vs 46.6 / 49.3 us at K = 4608, the configs[1] step 9.23 - 9.27 vs 9.12 - 9.17 ms: slower.  vmcnt is ONE
+    // in-order counter per wave: the residual rows come from MALL / HBM, the tiles from L2, and every counted "tile landed" wait
+    // of the loader also waited for the slower loads queued before it.  The same rows requested by the COMPUTE waves before the
+    // main loop (their vmcnt queue is never waited on in the loop; 4 / 6 / 8 of the 9 chunks in 16 / 24 / 32 more VGPRs, 32-bit
+    // offsets, no scratch) measured no better either: gate-residual 19.9 - 20.8 vs 19.8 - 20.3 us at K = 1152, the step 9.23 - 9.26 /
+    // 9.30 - 9.34 / 9.30 - 9.33 vs 9.19 - 9.24 ms (tools/gpu/r3_s2.sh).  The epilogue does not wait for the residual READ: the
+    // timeline of the Linear epilogue, which reads nothing, already shows it - 2.6k cycles of parking, 4.1k of store issue and
+    // 4.7k until the last store is acknowledged, i.e. the 256 workgroups' simultaneous WRITE burst.  Both options removed.)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = p.N / BN, mt = (p.M + BM - 1) / BM;
     const int id = xcd_remap(blockIdx.x, nt * mt);
     const int m0 = (id / nt) * BM, n0 = (id % nt) * BN;
     const int nk = p.K / BK;
-    [[maybe_unused]] const bool xl = PRIMX_G144L_XLDS && EPI == EPI_GATE_RESIDUAL && nk >= 2;   // workgroup-uniform
 
     if (wave >= 8) {
         // ---------------- loader wave lw: instructions t = lw * 17 + i, rows 8t .. 8t+7 of the 272-row stage image
@@ -1063,50 +1062,6 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
                 __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + kt * BK),
                                                  (LV*)(smem + stage * STAGE + (lw * NL + i) * 512), 16, 0, 0);
         };
-#if PRIMX_G144L_XLDS
-        if (xl) {
-            // residual DMA instruction u = i * 8 + w covers chunk i of threads 64 w .. 64 w + 63; loader lw owns u = lw * 20 + j
-            constexpr int NXI = NXL * 8 / 2;                                               // 20 per loader
-            const float* xp[NXI];
-#pragma unroll
-            for (int j = 0; j < NXI; ++j) {
-                const int u = lw * NXI + j;
-                const int cid = (u & 7) * 64 + lane + 512 * (u >> 3);
-                const int row = cid / (BN / 4), c4 = cid - row * (BN / 4);
-                xp[j] = p.x + (int64_t)min(m0 + row, p.M - 1) * p.N + n0 + 4 * c4;
-            }
-            auto issue_x = [&](int j0, int j1) {
-#pragma unroll
-                for (int j = 0; j < NXI; ++j)
-                    if (j >= j0 && j < j1)
-                        __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)xp[j], (LV*)(reinterpret_cast<char*>(smem) + XOFF_B + (lw * NXI + j) * 1024), 16, 0, 0);
-            };
-            // in-order queue of this wave (tile = 17 instructions; XA / XB / XC = 7 / 7 / 6):
-            //   prologue t0 t1 t2 | P: t0 landed (34 may fly) | XA | S_0: t1 landed (t2 XA = 24) | t3 XB | S_1: t2 landed
-            //   (XA t3 XB = 31) | t4 XC | S_2: t3 landed (XB t4 XC = 30) | t5 | S_3: t4 landed (XC t5 = 23) | t6 | S_kt, kt >= 4: 17
-            issue(0, 0);
-            issue(min(1, nk - 1), 1);
-            issue(min(2, nk - 1), 2);
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NL) : "memory");      // P
-            issue_x(0, 7);
-            int st = 0;
-            for (int kt = 0; kt < nk; ++kt) {
-                if (kt == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL + 7) : "memory");
-                else if (kt == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL + 14) : "memory");
-                else if (kt == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL + 13) : "memory");
-                else if (kt == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL + 6) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");
-                issue(min(kt + NST, nk - 1), st);
-                if (kt == 0) issue_x(7, 14);
-                if (kt == 1) issue_x(14, 20);
-                st = (st == NST - 1) ? 0 : st + 1;
-            }
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");               // D: ring drained, residual chunks landed
-            asm volatile("s_barrier" ::: "memory");                                      // X
-            asm volatile("s_barrier" ::: "memory");                                      // E
-            return;
-        }
-#endif
         issue(0, 0);
         issue(min(1, nk - 1), 1);
         issue(min(2, nk - 1), 2);
@@ -1146,6 +1101,8 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(a[i], b[j], acc[i][j]);
     };
+    constexpr int NROWCH = (BM * (BN / 4)) / 512;
+    f32x4 xpre[NROWCH];
     asm volatile("s_barrier" ::: "memory");                                              // P
     V8 a0[MI], b0[NI], a1[MI], b1[NI];
     read_frags(0, a0, b0);
@@ -1168,18 +1125,8 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
     // per thread, 9 row-chunks each (the form of gemm144_dma_kernel).  The residual / gate / bias vectors are
     // requested AFTER the parking (the accumulator registers are free by then: held across it they spilled) and land under
     // the barrier
-    constexpr int NROWCH = (BM * (BN / 4)) / 512;
     float* red = reinterpret_cast<float*>(smem);
     float* mine = red + kg * (BM * RS);
-    f32x4 xpre[NROWCH];
-#if PRIMX_G144L_XLDS
-    if (xl) {
-#pragma unroll
-        for (int i = 0; i < NXL; ++i)
-            xpre[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(smem) + XOFF_B + i * 8192 + tid * 16);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                 // X: every wave has its chunks, the area may be parked over
-    }
-#endif
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -1213,7 +1160,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
         if (p.bias) bpre[i] = *reinterpret_cast<const V4e*>(p.bias + n0 + 4 * c4);
         if (EPI == EPI_GATE_RESIDUAL) {
             gpre[i] = *reinterpret_cast<const V4e*>(p.gate + (int64_t)(m / p.rows_per_batch) * p.gate_stride + n0 + 4 * c4);
-            if (!(xl && i < NXL)) xpre[i] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.N + n0 + 4 * c4);
+            xpre[i] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.N + n0 + 4 * c4);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                     // E
@@ -1404,6 +1351,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
                 atomicMin(&g_gemm_prof[0], pr0); atomicMax(&g_gemm_prof[1], pr1);
                 atomicAdd(&g_gemm_prof[2], pc1 - pc0); atomicAdd(&g_gemm_prof[3], pc2 - pc1);
                 atomicAdd(&g_gemm_prof[4], pc3 - pc2); atomicAdd(&g_gemm_prof[5], 1ull); atomicAdd(&g_gemm_prof[6], pr0);
+                atomicAdd(&g_gemm_prof[8], pr1 - pr0); atomicAdd(&g_gemm_prof[9], pc3 - pc0);   // -> the shader clock while this kernel runs
             }
         }
     };
@@ -1633,9 +1581,11 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     (void)hipMemcpyFromSymbol(r, HIP_SYMBOL(g_gemm_prof), sizeof(r));
     const double n = r[5] ? (double)r[5] : 1.0;
     fprintf(stderr, "%s<%d,%d> M=%d N=%d K=%d: %llu workgroups, events %.1f us, first start -> last end %.1f us, mean start offset "
-                    "%.1f us; per workgroup (core cycles): entry->tile0 %.0f | main loop %.0f | epilogue %.0f (LDS staging %.0f, read+store issue %.0f)\n",
+                    "%.1f us, shader clock %.2f GHz (core cycles / 100 MHz ticks per workgroup); per workgroup (core cycles): entry->tile0 %.0f | main loop "
+                    "%.0f | epilogue %.0f (LDS staging %.0f, read+store issue %.0f)\n",
             BIG ? "gemm288q_dma" : "gemm144_dma", DT, EPI, a.M, a.N, a.K,
-            r[5], ms * 1e3, (r[1] - r[0]) * 0.01, (r[6] / n - (double)r[0]) * 0.01, r[2] / n, r[3] / n, r[4] / n, (r[7] >> 32) / n,
+            r[5], ms * 1e3, (r[1] - r[0]) * 0.01, (r[6] / n - (double)r[0]) * 0.01, r[8] ? (double)r[9] / (double)r[8] * 0.1 : 0.0,
+            r[2] / n, r[3] / n, r[4] / n, (r[7] >> 32) / n,
             (r[7] & 0xffffffffull) / n);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 }

@@ -148,11 +148,13 @@ def test_loader_wave_kernel_edges(ops, dtype, M, K):
     gate-residual epilogue with batch boundaries inside a tile, and the token-major heads epilogue (two segments, batch
     boundary inside a tile, q scale on segment 0)."""
     from topia_xl_amd._lib import HEADS_KROWS, HEADS_ROWS
+    from topia_xl_amd import _lib
+    launched = lambda: _lib.load().primx_last_gemm_kernel().decode()      # what the library reports it launched
     N = 288
-    assert ops._gemm_tag(0, M, N, K, dtype).startswith("gemm144l_dma_kernel")
     A, W, b, ref = _mk(31, M, N, K, dtype)
     r = lambda t: t.to(dtype).double()
     assert rel_l2(ops.linear(A.to(DEV), W.to(DEV), b.to(DEV)), ref) < TOL[dtype]
+    assert launched().startswith("gemm144l_dma_kernel"), launched()
     assert rel_l2(ops.linear(A.to(DEV), W.to(DEV), None), ref - b.double()) < TOL[dtype]
     got = ops.linear(A.to(DEV), W.to(DEV), b.to(DEV), act=1)                              # tanh GELU
     assert rel_l2(got, r(F.gelu(r(ref).float(), approximate="tanh"))) < 2 * TOL[dtype]
@@ -163,13 +165,14 @@ def test_loader_wave_kernel_edges(ops, dtype, M, K):
     want = x.double() + r(gate.double().repeat_interleave(rows, 0) * r(ref))
     xd = x.to(DEV)
     ops.linear_gate_residual(A.to(DEV), W.to(DEV), b.to(DEV), gate.to(DEV), xd, rows)
+    assert launched().startswith("gemm144l_dma_kernel"), launched()
     assert rel_l2(xd - x.to(DEV), want - x.double()) < 2 * TOL[dtype] and max_abs(xd, want) < 5e-2
     # heads: N = 2 segments x (H = 2) x (dh = 72); both token-major, so the tile (one segment) takes the loader kernel
     H, dh = 2, 72
-    assert ops._gemm_tag(2, M, N, K, dtype, (H, dh, rows, (HEADS_ROWS, HEADS_KROWS))).startswith("gemm144l_dma_kernel")
     Q = ops.alloc_heads(Bn, H, rows, dh, HEADS_ROWS, dtype, DEV, 128)
     Kb = ops.alloc_heads(Bn, H, rows, dh, HEADS_KROWS, dtype, DEV, 128)
     ops.linear_heads(A.to(DEV), W.to(DEV), b.to(DEV), rows, H, dh, [HEADS_ROWS, HEADS_KROWS], [Q, Kb], Q.shape[2], scale0=0.25)
+    assert launched().startswith("gemm144l_dma_kernel"), launched()
     qk = ref.to(dtype).view(Bn, rows, 2, H, dh)
     assert rel_l2(unpack_rows(Q, rows, dh), (0.25 * qk[:, :, 0].float()).to(dtype)) < 2 * TOL[dtype]
     assert rel_l2(unpack_rows(Kb, rows, dh), qk[:, :, 1]) < 2 * TOL[dtype]
