@@ -98,12 +98,26 @@ struct GemmArgs {
         }                                                    \
     } while (0)
 
-// Output stores of the epilogues.  PRIMX_NT_STORES: non-temporal (streaming) policy - experiment on whether the
-// end-of-kernel write-back of dirty L2 lines is what the epilogues wait for.
+// Output stores of the epilogues.  PRIMX_STORE_POLICY (build-time experiment): 0 = plain (write-back: the lines stay dirty in
+// the XCD's L2 until evicted or until the end-of-kernel release), 1 = non-temporal (`nt`), 2 = write-through (`sc0 sc1`,
+// MI355X_MICROARCH.md "stores of each flavour": the line leaves L2 with the store).
+#ifndef PRIMX_STORE_POLICY
+#define PRIMX_STORE_POLICY 0
+#endif
 template <typename T>
 __device__ __forceinline__ void out_store(T* ptr, const T v) {
-#ifdef PRIMX_NT_STORES
+#if PRIMX_STORE_POLICY == 1
     __builtin_nontemporal_store(v, ptr);
+#elif PRIMX_STORE_POLICY == 2
+    if constexpr (sizeof(T) == 8) {
+        const u32x2 w = __builtin_bit_cast(u32x2, v);
+        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(w) : "memory");
+    } else if constexpr (sizeof(T) == 16) {
+        const u32x4 w = __builtin_bit_cast(u32x4, v);
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(w) : "memory");
+    } else {
+        *ptr = v;
+    }
 #else
     *ptr = v;
 #endif
@@ -732,6 +746,9 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const GemmArgs<DT> p) {
 // [2] entry -> tile 0 landed, [3] main loop, [4] epilogue, [5] workgroups, [6] sum of (start - min start) in 10 ns ticks,
 // [8] / [9] sums of each workgroup's lifetime in 10 ns ticks / in core cycles (their ratio = the shader clock under this kernel)
 __device__ unsigned long long g_gemm_prof[12];
+// per-workgroup records of the same launch (first 4096 workgroups): {start tick - launch minimum is taken on the host, lifetime
+// in ticks, lifetime in core cycles, (XCC id << 32) | epilogue cycles} - the kernel ends with its SLOWEST workgroup
+__device__ unsigned long long g_gemm_wg[4096][4];
 
 template <int DT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> p) {
@@ -876,6 +893,12 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
                 atomicAdd(&g_gemm_prof[2], pc1 - pc0); atomicAdd(&g_gemm_prof[3], pc2 - pc1);
                 atomicAdd(&g_gemm_prof[4], pc3 - pc2); atomicAdd(&g_gemm_prof[5], 1ull); atomicAdd(&g_gemm_prof[6], pr0);
                 atomicAdd(&g_gemm_prof[8], pr1 - pr0); atomicAdd(&g_gemm_prof[9], pc3 - pc0);   // -> the shader clock while this kernel runs
+                if (blockIdx.x < 4096) {
+                    unsigned xcc;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                    g_gemm_wg[blockIdx.x][0] = pr0; g_gemm_wg[blockIdx.x][1] = pr1 - pr0; g_gemm_wg[blockIdx.x][2] = pc3 - pc0;
+                    g_gemm_wg[blockIdx.x][3] = ((unsigned long long)(xcc & 15) << 32) | (unsigned)(pc3 - pc2);
+                }
             }
         }
     };
@@ -1262,6 +1285,8 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
     }
     const bool last_slot = wave + 8 * (NSLOT - 1) < NINST;  // wave-uniform (waves 0,1)
     auto issue_one = [&](int ks, int stage, int i) {        // slot i of this wave for k-slice ks
+        // (non-temporal policy on the weight rows - do the streamed weights flush the Infinity Cache? - measured in round 3: every
+        // GEMM slower, the step 9.05 -> 10.16 ms; the 16 - 32 workgroups of an XCD that share a weight panel then miss in L2)
         if (i < NSLOT - 1 || last_slot)
             __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + ks * KS),
                                              (LV*)(smem + stage * STAGE + (wave + 8 * i) * 512), 16, 0, 0);
@@ -1352,6 +1377,12 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
                 atomicAdd(&g_gemm_prof[2], pc1 - pc0); atomicAdd(&g_gemm_prof[3], pc2 - pc1);
                 atomicAdd(&g_gemm_prof[4], pc3 - pc2); atomicAdd(&g_gemm_prof[5], 1ull); atomicAdd(&g_gemm_prof[6], pr0);
                 atomicAdd(&g_gemm_prof[8], pr1 - pr0); atomicAdd(&g_gemm_prof[9], pc3 - pc0);   // -> the shader clock while this kernel runs
+                if (blockIdx.x < 4096) {
+                    unsigned xcc;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                    g_gemm_wg[blockIdx.x][0] = pr0; g_gemm_wg[blockIdx.x][1] = pr1 - pr0; g_gemm_wg[blockIdx.x][2] = pc3 - pc0;
+                    g_gemm_wg[blockIdx.x][3] = ((unsigned long long)(xcc & 15) << 32) | (unsigned)(pc3 - pc2);
+                }
             }
         }
     };
@@ -1467,7 +1498,11 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * 64 + i * 16 + lr;
+#ifdef PRIMX_PROBE_SKIPSTORE   // measurement builds only: 1 = odd tile columns store nothing, 2 = nobody stores (results invalid)
+        const bool ok = m < p.M && !(PRIMX_PROBE_SKIPSTORE == 2 || (ni_t & 1));
+#else
         const bool ok = m < p.M;
+#endif
         const int mc = ok ? m : p.M - 1;
         if (EPI == EPI_GATE_RESIDUAL) {
             const S* grow = p.gate + (int64_t)(mc / p.rows_per_batch) * p.gate_stride + nb;
@@ -1486,6 +1521,27 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
                     xv[j][r] += rnd16<DT>((float)gv[j][r] * rnd16<DT>(acc[i][j][r] + (p.bias ? (float)bpre[j][r] : 0.f)));
                 if (ok) out_store(reinterpret_cast<f32x4*>(xrow + j * 16), xv[j]);
             }
+        } else if (EPI == EPI_LINEAR) {
+            // 16-bit outputs.  Stored straight from the accumulator layout a lane writes 8 bytes and an instruction touches 16 rows
+            // x 32 bytes; the store path of a CU then needs ~21k cycles for the tile's 147 KB (tools/probe/write_burst.hip: "fc1
+            // regs 8B") - MORE than the GELU arithmetic, so the fc1 epilogue was bound by its store REQUESTS.  One
+            // v_permlane16_swap per dword makes the lane groups of a row trade halves of two neighbouring 16-column tiles: lane
+            // group g then owns 8 consecutive columns of tile j + (g & 1) - 16 bytes per lane, 64 bytes per row and instruction,
+            // half the instructions (probe "fc1 regs 16B": 12k cycles).  The ninth tile has no partner and keeps the 8-byte form.
+            typedef unsigned int u32;
+            S* orow = p.out + (int64_t)mc * p.N + n0 + wn * 144;
+#pragma unroll
+            for (int j = 0; j + 1 < NI; j += 2) {
+                const u32x2 a = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j], bpre[j]));
+                const u32x2 b = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j + 1], bpre[j + 1]));
+                // odd 16-lane rows of the first operand <-> even rows of the second: (g1, g3)'s tile-j halves go to (g0, g2), their
+                // tile-(j+1) halves come back
+                const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
+                if (ok) out_store(reinterpret_cast<u32x4*>(orow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
+            }
+            if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), linear_out4<DT>(p, acc[i][NI - 1], bpre[NI - 1]));
         } else {
 #pragma unroll
             for (int j = 0; j < NI; ++j)
@@ -1503,6 +1559,11 @@ static const bool g_no_big = [] {   // PRIMX_GEMM_NOBIG=1 disables the 256x288 t
 static const bool g_loader = [] {   // PRIMX_GEMM_LOADER=0: the 128x144 kernel without loader waves (gemm144_dma_kernel) everywhere
     const char* e = getenv("PRIMX_GEMM_LOADER");
     return !(e && e[0] == '0');
+}();
+
+static const int g_big_min = [] {   // PRIMX_GEMM_BIG_MIN: fewest 256x288 workgroups for which the dense-output epilogues take the big tile
+    const char* e = getenv("PRIMX_GEMM_BIG_MIN");   // (224: one launch fills the chip; 112 when two half-batch streams run side by side)
+    return e ? atoi(e) : 224;
 }();
 
 static const int g_big_heads_min = [] {   // fewest 256x288 workgroups for which the heads epilogue takes the big tile
@@ -1587,6 +1648,27 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
             r[5], ms * 1e3, (r[1] - r[0]) * 0.01, (r[6] / n - (double)r[0]) * 0.01, r[8] ? (double)r[9] / (double)r[8] * 0.1 : 0.0,
             r[2] / n, r[3] / n, r[4] / n, (r[7] >> 32) / n,
             (r[7] & 0xffffffffull) / n);
+    {   // distribution over the workgroups: the kernel is as long as its slowest one
+        static unsigned long long wg[4096][4];
+        const int nw = (int)(r[5] < 4096 ? r[5] : 4096);
+        (void)hipMemcpyFromSymbol(wg, HIP_SYMBOL(g_gemm_wg), sizeof(unsigned long long) * 4 * nw);
+        double life[4096], xs[8] = {0}, xe[8] = {0}, xend[8] = {0};
+        int xn[8] = {0};
+        for (int i = 0; i < nw; ++i) {
+            life[i] = wg[i][1] * 0.01;
+            const int x = (int)(wg[i][3] >> 32) & 7;
+            xs[x] += life[i]; xe[x] += (double)(wg[i][3] & 0xffffffffull); ++xn[x];
+            const double end = (wg[i][0] + wg[i][1] - r[0]) * 0.01;
+            if (end > xend[x]) xend[x] = end;
+        }
+        double srt[4096];
+        for (int i = 0; i < nw; ++i) srt[i] = life[i];
+        for (int i = 1; i < nw; ++i) { double v = srt[i]; int j = i; while (j > 0 && srt[j - 1] > v) { srt[j] = srt[j - 1]; --j; } srt[j] = v; }
+        fprintf(stderr, "   workgroup lifetimes (us): min %.1f | median %.1f | p90 %.1f | max %.1f;  per XCD mean lifetime / mean epilogue cycles / last end:",
+                srt[0], srt[nw / 2], srt[nw * 9 / 10], srt[nw - 1]);
+        for (int x = 0; x < 8; ++x) if (xn[x]) fprintf(stderr, "  [%d] %.1f / %.0f / %.1f", x, xs[x] / xn[x], xe[x] / xn[x], xend[x]);
+        fprintf(stderr, "\n");
+    }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 }
 
@@ -1600,7 +1682,7 @@ int launch(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
     // 256x288 tile: only where same-box A/B showed a win - the dense-output epilogues with enough workgroups to fill
     // the chip (fc1 at T = 4096: exactly 256; every large-batch GEMM).  The heads epilogue stays on the 128x144 kernel
     // (qkv would be 192 workgroups = 75 % of the CUs, and the scatter epilogue spilled at this tile's register budget).
-    bool use_big = !g_no_big && a.N % 288 == 0 && ((a.M + 255) / 256) * (a.N / 288) >= 224 &&
+    bool use_big = !g_no_big && a.N % 288 == 0 && ((a.M + 255) / 256) * (a.N / 288) >= g_big_min &&
                    (EPI == EPI_LINEAR || EPI == EPI_RES || EPI == EPI_GATE_RESIDUAL);
     // Heads epilogue on the 256x288 tile (LDS-staged scatter, gemm288q only): tiles must cover whole heads of one
     // segment and one batch entry.  It already pays at 192 workgroups (qkv at T = 4096: 75 % of the CUs, one round

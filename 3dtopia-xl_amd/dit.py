@@ -26,6 +26,7 @@ Two numeric routes, selected exactly as the reference selects them (dit_crossatt
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -146,6 +147,10 @@ class DiT(nn.Module):
         # conditioning tensor and reused across DDIM steps.  Off by default: a step then executes the reference's full
         # algorithmic FLOPs (bench.py reports both when the flag is on).
         self.reuse_cond_kv = False
+        # Opt-in: run the two classifier-free-guidance halves of `forward_with_cfg` as two concurrent HIP streams
+        # (_forward16); identical kernels and results per row.  PRIMX_CFG_STREAMS=1 turns it on for every model.
+        self.cfg_streams = os.environ.get("PRIMX_CFG_STREAMS") == "1"
+        self._side: Dict = {}
         self._t_plan: Optional[Dict] = None   # plan_timesteps(): the coming calls' timesteps and their modulation table
 
     # ------------------------------------------------------------------ init (dit_crossattn.py:153-182)
@@ -415,6 +420,12 @@ class DiT(nn.Module):
             if self._cond is not None and self._cond.get("group") == old:
                 self._cond = None           # its K / V cache pointed into them
 
+    def _side_stream(self, dev) -> "torch.cuda.Stream":
+        key = str(dev)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=dev)
+        return self._side[key]
+
     # ------------------------------------------------------------------ conditioning (step-invariant inputs)
     def _cond_state(self, y: torch.Tensor, null_half: bool, dt) -> Dict:
         """16-bit image of the conditioning tokens as the K / V projection reads them, cached per conditioning tensor.
@@ -572,24 +583,50 @@ class DiT(nn.Module):
         hid = torch.empty(T, pk["blocks"][0]["w_fc1"].shape[0], dtype=dt, device=dev) if self.depth else None
         scale = dh ** -0.5
 
-        for i, w in enumerate(pk["blocks"]):
-            m = mod[:, i * 9 * D:(i + 1) * 9 * D]
+        def block(i, w, b0, b1, hook=None):
+            """DiTBlock i on batch entries [b0, b1) (dit_crossattn.py:51-58): 11 launches on the current stream."""
+            r0, r1 = b0 * N, b1 * N
+            hh, xh, ah = h[r0:r1], xn[r0:r1], att[b0:b1]
+            Th = r1 - r0
+            m = mod[b0:b1, i * 9 * D:(i + 1) * 9 * D]
             ch = [m[:, j * D:(j + 1) * D] for j in range(9)]  # shift/scale/gate x (mca, msa, mlp)
             # ---- cross-attention to the image tokens (dit_crossattn.py:55, attention.py:96-114)
-            ops.layernorm_modulate(h, ch[0], ch[1], N, xn, self.LN_EPS)
-            ops.linear_heads(xn, w["w_q"], w["b_q"], N, H, dh, [HEADS_ROWS], [Qc], nq_pad, scale0=scale)
-            ops.attention(Qc, Kc_blk[i], Vc_blk[i], N, L, dh, scale, out=att)
-            ops.linear_gate_residual(att.view(T, D), w["w_cproj"], w["b_cproj"], ch[2], h, N)
+            ops.layernorm_modulate(hh, ch[0], ch[1], N, xh, self.LN_EPS)
+            ops.linear_heads(xh, w["w_q"], w["b_q"], N, H, dh, [HEADS_ROWS], [Qc[b0:b1]], nq_pad, scale0=scale)
+            ops.attention(Qc[b0:b1], Kc_blk[i][b0:b1], Vc_blk[i][b0:b1], N, L, dh, scale, out=ah)
+            if hook is not None:
+                hook()
+            ops.linear_gate_residual(ah.view(Th, D), w["w_cproj"], w["b_cproj"], ch[2], hh, N)
             # ---- self-attention over the primitive tokens (dit_crossattn.py:56, attention.py:48-59)
-            ops.layernorm_modulate(h, ch[3], ch[4], N, xn, self.LN_EPS)
-            ops.linear_heads(xn, w["w_qkv"], w["b_qkv"], N, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT], [Qs, Ks, Vs],
-                             nq_pad)
-            ops.attention(Qs, Ks, Vs, N, N, dh, scale, out=att)
-            ops.linear_gate_residual(att.view(T, D), w["w_proj"], w["b_proj"], ch[5], h, N)
+            ops.layernorm_modulate(hh, ch[3], ch[4], N, xh, self.LN_EPS)
+            ops.linear_heads(xh, w["w_qkv"], w["b_qkv"], N, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT],
+                             [Qs[b0:b1], Ks[b0:b1], Vs[b0:b1]], nq_pad)
+            ops.attention(Qs[b0:b1], Ks[b0:b1], Vs[b0:b1], N, N, dh, scale, out=ah)
+            ops.linear_gate_residual(ah.view(Th, D), w["w_proj"], w["b_proj"], ch[5], hh, N)
             # ---- MLP (dit_crossattn.py:57, models/utils.py:94-101)
-            ops.layernorm_modulate(h, ch[6], ch[7], N, xn, self.LN_EPS)
-            ops.linear(xn, w["w_fc1"], w["b_fc1"], out=hid, act=ACT_GELU_TANH)
-            ops.linear_gate_residual(hid, w["w_fc2"], w["b_fc2"], ch[8], h, N)
+            ops.layernorm_modulate(hh, ch[6], ch[7], N, xh, self.LN_EPS)
+            ops.linear(xh, w["w_fc1"], w["b_fc1"], out=hid[r0:r1], act=ACT_GELU_TANH)
+            ops.linear_gate_residual(hid[r0:r1], w["w_fc2"], w["b_fc2"], ch[8], hh, N)
+
+        if self.cfg_streams and null_half and self.depth and ops.PROFILE is None:
+            # Two HIP streams, one per CFG half (the conditional and the unconditional rows are independent chains of
+            # kernels): every GEMM of this path ends with a write burst that nothing of ITS OWN kernel can overlap
+            # (DESIGN.md section 4); with the second chain a few kernels behind the first, one chain's burst drains
+            # under the other chain's matrix phase.  Same kernels, same arithmetic per row.
+            main = torch.cuda.current_stream()
+            side = self._side_stream(dev)
+            side.wait_stream(main)                       # embeddings, modulation and the K / V projection come first
+            lag = torch.cuda.Event()
+            for i, w in enumerate(pk["blocks"]):
+                block(i, w, 0, B, hook=(lambda: lag.record(main)) if i == 0 else None)
+                with torch.cuda.stream(side):
+                    if i == 0:
+                        side.wait_event(lag)             # the side chain starts when the main one is three kernels in
+                    block(i, w, B, Be)
+            main.wait_stream(side)
+        else:
+            for i, w in enumerate(pk["blocks"]):
+                block(i, w, 0, Be)
 
         # ---- final layer (dit_crossattn.py:74-78)
         base = self.depth * 9 * D
