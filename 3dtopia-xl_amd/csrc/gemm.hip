@@ -1551,6 +1551,175 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
     prof_end();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Two-pass big tile for the Linear epilogue (fc1 + GELU): a workgroup owns a 256 x 288 output tile like gemm288q, but computes
+// it as TWO passes of 256 x 144 with the wave roles of the loader-wave kernel (8 compute waves = 8 row groups of 32 rows x
+// 144 columns over the full K, 72 accumulators each; waves 8 and 9 only issue LDS-DMA).
+// Why (round 3, PRIMX_GEMM_PROF timelines + tools/probe/write_burst.hip): inside the DDIM step the fc1 kernel spent 32k of its
+// 97k cycles per workgroup behind its last MFMA - GELU arithmetic and, mostly, waiting for the 37.7 MB of output that all 256
+// workgroups store at once (2.2 TB/s) - and without the stores its main loop ran in 49.5k cycles at a HIGHER clock (26 us for
+// the whole kernel against 53).  A one-tile-per-CU kernel cannot hide that: nothing is left to compute when the stores start.
+// Here the first pass's stores drain while the second pass multiplies (the compute waves never wait on vmcnt in the loop), the
+// loader waves run ahead across the pass boundary (the ring holds the second pass's first tiles when the first epilogue
+// ends), and only the second half of the output is exposed.  The price is bytes per FLOP - (256 + 144) x 128 B per 64-wide
+// k-tile = 50 DMA instructions x 24.5 cycles = 1225 against 1152 cycles of MFMA per SIMD: the loop sits at the DMA unit's rate,
+// which the loader waves reach where the 8-wave 256 x 288 loop measured 3100 per (twice as large) k-tile.
+// Pipeline: the unit is a 32-wide k-step (18 MFMAs per wave).  Fragments of step u + 1 are read while step u multiplies; the
+// ONE barrier per k-tile sits between its two steps: B_g = "reads of tile g are home (its stage may be refilled), tile g + 1 has
+// landed" - the same two-tiles-of-flight ring protocol as gemm144l_dma_kernel, all ten waves execute every barrier.
+template <int DT>
+__global__ __launch_bounds__(640) void gemm288p_dma_kernel(const GemmArgs<DT> p) {
+    unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pc2 = 0;   // PRIMX_GEMM_PROF=1 timeline (see g_gemm_prof)
+    if (p.prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
+    using S = typename T16<DT>::S;
+    using V8 = typename T16<DT>::V8;
+    using V4e = typename T16<DT>::V4;
+    typedef __attribute__((address_space(1))) const void GV;
+    typedef __attribute__((address_space(3))) void LV;
+    constexpr int BM = 256, BN = 144, MI = 2, NI = 9, NST = 3, NPASS = 2;
+    constexpr int ROWS = BM + BN, STAGE = ROWS * 64, NINST = ROWS / 8, NL = NINST / 2;   // 50 wave-instructions per tile, 25 per loader
+    static_assert(NST * STAGE * 2 <= 160 * 1024 && NINST % 2 == 0 && BM % 8 == 0, "LDS budget / loader split");
+    __shared__ __attribute__((aligned(16))) S smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = p.N / (NPASS * BN), mt = (p.M + BM - 1) / BM;
+    int mi_t, ni_t;
+    if (p.xcd_gm > 0 && p.xcd_gm < 8) {
+        xcd_tile2d(blockIdx.x, mt, nt, p.xcd_gm, mi_t, ni_t);
+    } else {
+        const int id = xcd_remap(blockIdx.x, nt * mt);
+        mi_t = id / nt;
+        ni_t = id - mi_t * nt;
+    }
+    const int m0 = mi_t * BM, n00 = ni_t * NPASS * BN;
+    const int nk = p.K / BK, total = NPASS * nk;
+
+    if (wave >= 8) {
+        // ---------------- loader wave lw: instructions t = lw * 25 + i, rows 8 t .. 8 t + 7 of the 400-row stage image (rows
+        // < 256: activations, the same for both passes; the rest: the pass's 144 weight rows)
+        const int lw = wave - 8;
+        const S* gp[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int row = 8 * (lw * NL + i) + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            gp[i] = (row < BM) ? p.A + (int64_t)min(m0 + row, p.M - 1) * p.K + c * 8 : p.W + (int64_t)(n00 + row - BM) * p.K + c * 8;
+        }
+        auto issue = [&](int g, int stage) {  // global tile g = pass * nk + kt
+            const int pass = g >= nk ? 1 : 0, kt = g - pass * nk;
+            const int64_t wpass = (int64_t)pass * BN * p.K;                                // pass 1: the next 144 weight rows
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int64_t adv = ((lw * NL + i) * 8 >= BM ? wpass : 0) + kt * BK;      // (wave-uniform: an instruction is all activation or all weight rows)
+                __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + adv), (LV*)(smem + stage * STAGE + (lw * NL + i) * 512), 16, 0, 0);
+            }
+        };
+        issue(0, 0);
+        issue(min(1, total - 1), 1);
+        issue(min(2, total - 1), 2);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NL) : "memory");      // P: tile 0 landed
+        int st = 0;
+        for (int g = 0; g < total; ++g) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");     // B_g: tile g + 1 landed, g + 2 may fly
+            issue(min(g + NST, total - 1), st);                                            // tile g's stage is free now
+            st = (st == NST - 1) ? 0 : st + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 // the clamped tail must not outlive the LDS
+        return;
+    }
+
+    // ---------------- compute wave w: rows 32 w .. 32 w + 31 of the tile, all 144 columns of the pass, the whole K
+    const int lr = lane & 15, lg = lane >> 4;
+    const int a_row = wave * 32 + lr;
+    auto read_frags = [&](int stage, int ks, V8 (&a)[MI], V8 (&b)[NI]) {
+        const S* As = smem + stage * STAGE;
+        const S* Ws = As + BM * 64;
+        const int chunk = ks * 4 + lg;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const V8*>(As + lds_off(a_row + i * 16, chunk));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(Ws + lds_off(lr + j * 16, chunk));
+    };
+    f32x4 acc[MI][NI];
+    // operands swapped (A = weight rows, B = activation rows): the accumulator holds C^T, a lane owns ONE row and four
+    // consecutive columns - acc[i][j][r] = C[m0 + 32 w + 16 i + lr][n0 + 16 j + 4 lg + r] - and the epilogue needs no LDS
+    auto multiply = [&](const V8 (&a)[MI], const V8 (&b)[NI]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(b[j], a[i], acc[i][j]);
+    };
+    asm volatile("s_barrier" ::: "memory");                                              // P
+    if (p.prof) pc1 = __builtin_readcyclecounter();
+    int st = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        V8 a0[MI], b0[NI], a1[MI], b1[NI];
+        read_frags(st, 0, a0, b0);                 // (tile pass * nk has landed: P, or B of the previous pass's last tile)
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            const int st_next = (st == NST - 1) ? 0 : st + 1;
+            read_frags(st, 1, a1, b1);
+            multiply(a0, b0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // B_g
+            // (unconditional: behind the pass's last tile the stage holds the next pass's first tile - or the clamped re-fetch of
+            // the very last one - and the values are simply not used; a conditional read kept both fragment sets live through the loop)
+            read_frags(st_next, 0, a0, b0);
+            multiply(a1, b1);
+            st = st_next;
+        }
+        if (p.prof && pass == NPASS - 1) pc2 = __builtin_readcyclecounter();
+        // ---- epilogue of the pass, from registers: bias, rounding, activation, 16-byte stores (the lane groups of a row trade
+        // halves of neighbouring 16-column tiles with v_permlane16_swap, see gemm288q_dma_kernel).  Nothing below waits for the
+        // stores: the next pass's fragments and MFMAs follow immediately.
+        const int n0 = n00 + pass * BN;
+        V4e bpre[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            bpre[j] = V4e{};
+            if (p.bias) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + n0 + j * 16 + 4 * lg);
+        }
+        typedef unsigned int u32;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wave * 32 + i * 16 + lr;
+            const bool ok = m < p.M;
+            S* orow = p.out + (int64_t)(ok ? m : p.M - 1) * p.N + n0;
+#pragma unroll
+            for (int j = 0; j + 1 < NI; j += 2) {
+                const u32x2 a = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j], bpre[j]));
+                const u32x2 b = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j + 1], bpre[j + 1]));
+                const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
+                if (ok) out_store(reinterpret_cast<u32x4*>(orow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
+            }
+            if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), linear_out4<DT>(p, acc[i][NI - 1], bpre[NI - 1]));
+        }
+    }
+    if (p.prof) {
+        __builtin_amdgcn_s_waitcnt(0);   // the stores have been acknowledged
+        const unsigned long long pc3 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            atomicMin(&g_gemm_prof[0], pr0); atomicMax(&g_gemm_prof[1], pr1);
+            atomicAdd(&g_gemm_prof[2], pc1 - pc0); atomicAdd(&g_gemm_prof[3], pc2 - pc1);
+            atomicAdd(&g_gemm_prof[4], pc3 - pc2); atomicAdd(&g_gemm_prof[5], 1ull); atomicAdd(&g_gemm_prof[6], pr0);
+            atomicAdd(&g_gemm_prof[8], pr1 - pr0); atomicAdd(&g_gemm_prof[9], pc3 - pc0);
+            if (blockIdx.x < 4096) {
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                g_gemm_wg[blockIdx.x][0] = pr0; g_gemm_wg[blockIdx.x][1] = pr1 - pr0; g_gemm_wg[blockIdx.x][2] = pc3 - pc0;
+                g_gemm_wg[blockIdx.x][3] = ((unsigned long long)(xcc & 15) << 32) | (unsigned)(pc3 - pc2);
+            }
+        }
+    }
+}
+
 static const bool g_no_big = [] {   // PRIMX_GEMM_NOBIG=1 disables the 256x288 tile (A/B measurements)
     const char* e = getenv("PRIMX_GEMM_NOBIG");
     return e && e[0] == '1';
@@ -1569,6 +1738,11 @@ static const int g_big_min = [] {   // PRIMX_GEMM_BIG_MIN: fewest 256x288 workgr
 static const int g_big_heads_min = [] {   // fewest 256x288 workgroups for which the heads epilogue takes the big tile
     const char* e = getenv("PRIMX_GEMM_BIGHEADS_MIN");
     return e ? atoi(e) : 160;
+}();
+
+static const bool g_two_pass = [] {   // PRIMX_GEMM_P2=0: the Linear epilogue's big tile on the one-pass 8-wave kernel (gemm288q) instead of gemm288p
+    const char* e = getenv("PRIMX_GEMM_P2");
+    return !(e && e[0] == '0');
 }();
 
 static const bool g_xcd2d = [] {   // PRIMX_GEMM_XCD2D=0: whole tile rows per XCD in the 256x288 kernel (A/B measurements)
@@ -1610,7 +1784,13 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
         for (int sgi = 0; sgi < a.n_seg; ++sgi) loader_ok = loader_ok && a.kind[sgi] != PRIMX_HEADS_VT;
     }
     auto go = [&](const GemmArgs<DT>& x) {
-        if (BIG) {
+        // two passes only when the launch is ONE round of workgroups (fc1 at T = 4096: exactly 256): there the first pass's stores
+        // drain under the second pass (the step 8.97 -> 8.92 ms same box); with several rounds per CU the next workgroup already
+        // overlaps the previous one's drain and the one-pass tile's fewer bytes per FLOP win (T = 32768: 428 vs 451 us)
+        if (BIG && EPI == EPI_LINEAR && g_two_pass && (int)grid.x <= 256) {
+            PRIMX_NOTE_KERNEL("gemm288p_dma_kernel<%d>", DT);
+            hipLaunchKernelGGL((gemm288p_dma_kernel<DT>), grid, dim3(640), 0, st, x);
+        } else if (BIG) {
             PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d>", DT, EPI);
             hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
         } else if (g_loader && loader_ok && !g_gemm_prof_on) {   // (no timeline stamps in the loader-wave kernel)
@@ -1644,7 +1824,7 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     fprintf(stderr, "%s<%d,%d> M=%d N=%d K=%d: %llu workgroups, events %.1f us, first start -> last end %.1f us, mean start offset "
                     "%.1f us, shader clock %.2f GHz (core cycles / 100 MHz ticks per workgroup); per workgroup (core cycles): entry->tile0 %.0f | main loop "
                     "%.0f | epilogue %.0f (LDS staging %.0f, read+store issue %.0f)\n",
-            BIG ? "gemm288q_dma" : "gemm144_dma", DT, EPI, a.M, a.N, a.K,
+            BIG ? (EPI == EPI_LINEAR && g_two_pass && (int)grid.x <= 256 ? "gemm288p_dma" : "gemm288q_dma") : "gemm144_dma", DT, EPI, a.M, a.N, a.K,
             r[5], ms * 1e3, (r[1] - r[0]) * 0.01, (r[6] / n - (double)r[0]) * 0.01, r[8] ? (double)r[9] / (double)r[8] * 0.1 : 0.0,
             r[2] / n, r[3] / n, r[4] / n, (r[7] >> 32) / n,
             (r[7] & 0xffffffffull) / n);

@@ -15,6 +15,7 @@ CYCLES = {  # kernel name prefix -> shape tags in launch order within one block 
     "gemm144l_dma_kernel<1, 1>": ["4096x1152x1152", "4096x1152x1152", "4096x1152x4608"],
     "gemm144l_dma_kernel<1, 2>": ["4096x1152x1152"],
     "gemm288q_dma_kernel<1, 0>": ["4096x4608x1152"],
+    "gemm288p_dma_kernel<1>": ["4096x4608x1152"],
     "attn_kernel<1, 5, 3, 0, 0>": ["32x2048x1370x72", "32x2048x2048x72"],
     # --config decode (2048 primitives): one shape per kernel
     "conv3_s4c256_kernel<1, 0>": ["256->256 @4^3 x2048"],
