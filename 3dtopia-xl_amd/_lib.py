@@ -32,6 +32,8 @@ SIGNATURES = {
     "primx_primsdf_query": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "primx_vit_tokens": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "primx_point_features": [_p, _l, _p, _p, _l, _i, _i, _p],
+    "primx_prefetch": [_p, _l, _p],
+    "primx_prefetch_hint": [_p, _l],
     "primx_silu_cast": [_p, _p, _i, _l, _p],
     "primx_cast16": [_p, _p, _i, _l, _p],
     "primx_linear_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
@@ -65,7 +67,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"primx_last_error": C.c_char_p, "primx_last_gemm_kernel": C.c_char_p}
 # an alternate build named by PRIMX_LIB (same-box A/B against an older library) may predate these additive entry points
-_OPTIONAL_IN_AB_BUILDS = {"primx_last_gemm_kernel"}
+_OPTIONAL_IN_AB_BUILDS = {"primx_last_gemm_kernel", "primx_prefetch", "primx_prefetch_hint"}
 _AB_ABI_VERSIONS = (18,)
 
 _lib: Optional[C.CDLL] = None

@@ -1036,6 +1036,9 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
 // Barrier protocol (all 10 waves execute every s_barrier): P (tile 0 landed) | S_kt per step (tile kt+1 landed: the loaders
 // waited for their own pieces; all fragment reads of tile kt are home: the compute waves waited lgkmcnt(0)) | D (ring
 // drained) | E (accumulators parked for the row-major walk).
+#ifndef PRIMX_G144L_NST
+#define PRIMX_G144L_NST 3   // ring depth of the loader-wave kernel (4 x 34,816 B still fit beside nothing: the epilogue's parking area is larger)
+#endif
 template <int DT, int EPI>
 __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p) {
     static_assert(EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_HEADS, "row-major epilogues only");
@@ -1044,8 +1047,9 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
     using V4e = typename T16<DT>::V4;
     typedef __attribute__((address_space(1))) const void GV;
     typedef __attribute__((address_space(3))) void LV;
-    constexpr int BM = 128, BN = 144, MI = 2, NI = 9, NST = 3;
+    constexpr int BM = 128, BN = 144, MI = 2, NI = 9, NST = PRIMX_G144L_NST;
     constexpr int ROWS = BM + BN, STAGE = ROWS * 64, NINST = ROWS / 8, NL = NINST / 2;   // 17 wave-instructions per loader per tile
+    static_assert((NST - 1) * NL <= 63, "vmcnt is a 6-bit counter");
     constexpr int RS = BN + 4;
     constexpr int ROWMAJOR_HALVES = 2 * BM * RS * 2;
     constexpr int LDS_HALVES = (NST * STAGE > ROWMAJOR_HALVES) ? NST * STAGE : ROWMAJOR_HALVES;
@@ -1085,13 +1089,12 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
                 __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + kt * BK),
                                                  (LV*)(smem + stage * STAGE + (lw * NL + i) * 512), 16, 0, 0);
         };
-        issue(0, 0);
-        issue(min(1, nk - 1), 1);
-        issue(min(2, nk - 1), 2);
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NL) : "memory");      // P
+#pragma unroll
+        for (int s0 = 0; s0 < NST; ++s0) issue(min(s0, nk - 1), s0);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST - 1) * NL) : "memory");   // P: tile 0 landed
         int st = 0;
         for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");     // S_kt: tile kt+1 landed, kt+2 may fly
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST - 2) * NL) : "memory");   // S_kt: tile kt+1 landed, NST - 2 newer ones may fly
             issue(min(kt + NST, nk - 1), st);                                              // tile kt's stage is free now
             st = (st == NST - 1) ? 0 : st + 1;
         }

@@ -150,6 +150,7 @@ class DiT(nn.Module):
         # Opt-in: run the two classifier-free-guidance halves of `forward_with_cfg` as two concurrent HIP streams
         # (_forward16); identical kernels and results per row.  PRIMX_CFG_STREAMS=1 turns it on for every model.
         self.cfg_streams = os.environ.get("PRIMX_CFG_STREAMS") == "1"
+        self.weight_prefetch = os.environ.get("PRIMX_WPREFETCH", "1") != "0"   # LayerNorm launches carry the next GEMMs' weight prefetch (_forward16)
         self._side: Dict = {}
         self._t_plan: Optional[Dict] = None   # plan_timesteps(): the coming calls' timesteps and their modulation table
 
@@ -583,6 +584,17 @@ class DiT(nn.Module):
         hid = torch.empty(T, pk["blocks"][0]["w_fc1"].shape[0], dtype=dt, device=dev) if self.depth else None
         scale = dh ** -0.5
 
+        # Weight prefetch (PRIMX_WPREFETCH=0 turns it off): the 1.8 GB of weights stream through HBM once per forward, and the
+        # 128 x 144 GEMMs run 2 - 4 us longer with cold weights than with cache-resident ones (rocprofv3, tools/gpu/r3_touch.sh).
+        # Every LayerNorm launch - a short kernel that reads the residual stream from the Infinity Cache - carries the prefetch
+        # of the weights of the loader-wave GEMMs that follow it (ops.prefetch_hint): no launch, no event, no stream of its own.
+        wpf = self.weight_prefetch
+
+        def warm(*wts):
+            if wpf:
+                for wt in wts:
+                    ops.prefetch_hint(wt)
+
         def block(i, w, b0, b1, hook=None):
             """DiTBlock i on batch entries [b0, b1) (dit_crossattn.py:51-58): 11 launches on the current stream."""
             r0, r1 = b0 * N, b1 * N
@@ -591,6 +603,7 @@ class DiT(nn.Module):
             m = mod[b0:b1, i * 9 * D:(i + 1) * 9 * D]
             ch = [m[:, j * D:(j + 1) * D] for j in range(9)]  # shift/scale/gate x (mca, msa, mlp)
             # ---- cross-attention to the image tokens (dit_crossattn.py:55, attention.py:96-114)
+            warm(w["w_q"], w["w_cproj"])       # (the block's cross-attention K / V instead: -1.0 us on that kernel, +0.5 on this one)
             ops.layernorm_modulate(hh, ch[0], ch[1], N, xh, self.LN_EPS)
             ops.linear_heads(xh, w["w_q"], w["b_q"], N, H, dh, [HEADS_ROWS], [Qc[b0:b1]], nq_pad, scale0=scale)
             ops.attention(Qc[b0:b1], Kc_blk[i][b0:b1], Vc_blk[i][b0:b1], N, L, dh, scale, out=ah)
@@ -598,12 +611,14 @@ class DiT(nn.Module):
                 hook()
             ops.linear_gate_residual(ah.view(Th, D), w["w_cproj"], w["b_cproj"], ch[2], hh, N)
             # ---- self-attention over the primitive tokens (dit_crossattn.py:56, attention.py:48-59)
+            warm(w["w_proj"])
             ops.layernorm_modulate(hh, ch[3], ch[4], N, xh, self.LN_EPS)
             ops.linear_heads(xh, w["w_qkv"], w["b_qkv"], N, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT],
                              [Qs[b0:b1], Ks[b0:b1], Vs[b0:b1]], nq_pad)
             ops.attention(Qs[b0:b1], Ks[b0:b1], Vs[b0:b1], N, N, dh, scale, out=ah)
             ops.linear_gate_residual(ah.view(Th, D), w["w_proj"], w["b_proj"], ch[5], hh, N)
             # ---- MLP (dit_crossattn.py:57, models/utils.py:94-101)
+            warm(w["w_fc2"])
             ops.layernorm_modulate(hh, ch[6], ch[7], N, xh, self.LN_EPS)
             ops.linear(xh, w["w_fc1"], w["b_fc1"], out=hid[r0:r1], act=ACT_GELU_TANH)
             ops.linear_gate_residual(hid[r0:r1], w["w_fc2"], w["b_fc2"], ch[8], hh, N)

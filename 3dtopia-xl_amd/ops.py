@@ -192,6 +192,16 @@ def linear_f32(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], act_
     return out
 
 
+def prefetch_hint(t: torch.Tensor) -> None:
+    """The next layernorm_modulate launch also pulls `t`'s bytes into the caches (csrc/rowops.hip primx_prefetch_hint)."""
+    check(_lib.load().primx_prefetch_hint(_dev(t, "t"), t.numel() * t.element_size()), "primx_prefetch_hint")
+
+
+def prefetch(t: torch.Tensor, stream: "torch.cuda.Stream") -> None:
+    """Enqueue a cache prefetch of `t`'s bytes on `stream` (csrc/rowops.hip primx_prefetch); no result, no dependency."""
+    check(_lib.load().primx_prefetch(_dev(t, "t"), t.numel() * t.element_size(), stream.cuda_stream), "primx_prefetch")
+
+
 # ----------------------------------------------------------------------------- GEMMs
 def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
            act: int = ACT_NONE, out_scale: float = 1.0) -> torch.Tensor:

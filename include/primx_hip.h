@@ -93,6 +93,16 @@ int primx_vit_tokens(const float* patches, const float* cls, const float* pos, c
 int primx_point_features(const float* x, int64_t row_stride, const float* freqs, float* feat, int64_t feat_stride, int T,
                          int F, void* stream);
 
+/* Touch every 128-byte line of [ptr, ptr + bytes): a cache prefetch (Infinity Cache / L2), no result.  Enqueue it on a SIDE
+ * stream while a compute-bound kernel (attention, LayerNorm) runs, for the weights of the GEMM that follows.  No counterpart
+ * in the reference (its weights are whatever the caches hold); results are unaffected.  ABI 19. */
+int primx_prefetch(const void* ptr, int64_t bytes, void* stream);
+/* The same prefetch WITHOUT a launch of its own: registers [ptr, ptr + bytes) (at most two pending ranges per host thread) with
+ * the next primx_layernorm_modulate call on this thread, whose grid gets extra leading workgroups that load one word per
+ * 128-byte line (its D % 128 == 0 fast path; other shapes drop the hint).  A cross-stream prefetch costs an event pair per use
+ * (+0.1 ms per DDIM step measured); riding on the LayerNorm that precedes every GEMM group costs nothing on the host. */
+int primx_prefetch_hint(const void* ptr, int64_t bytes);
+
 /* out = cast16( silu(in) ) elementwise.  The SiLU in front of every adaLN Linear
  * (models/dit_crossattn.py:40-43,69-72) producing the 16-bit GEMM operand. */
 int primx_silu_cast(const float* in, void* out, int dtype, int64_t n, void* stream);

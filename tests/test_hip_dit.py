@@ -231,3 +231,24 @@ def test_additive_pos_emb_variant(pkg, golden):
         assert rel_l2(out, emu) < TOL_EMU[dtype], rel_l2(out, emu)
     with pytest.raises(AttributeError):
         m.forward_with_cfg(x.to(DEV), t.to(DEV), y.to(DEV), cfg_scale=6.0)
+
+
+def test_inference_mode_conditioning_tensor(pkg):
+    """A conditioning tensor created under torch.inference_mode() tracks no version counter: the conditioning cache must not
+    read `_version` of it (round-2 advisor finding: RuntimeError), and must not serve a stale image after an in-place edit."""
+    from oracle import synth
+    cfg = dict(in_channels=68, condition_channels=64, hidden_size=288, depth=1)
+    m = pkg.DiT(seq_length=128, num_heads=4, attn_proj_bias=True, cond_drop_prob=0.1, **cfg).eval()
+    m.load_state_dict(synth.dit_state_dict(7, **cfg))
+    m.to(DEV)
+    x = synth.tensor(7, "x", (1, 128, 68)).to(DEV)
+    t = torch.tensor([500], device=DEV)
+    with torch.inference_mode():
+        y = synth.tensor(7, "y", (1, 70, 64)).to(DEV) * 1.0
+        assert y.is_inference()
+        a = m.forward_with_cfg(x, t, y, 6.0, torch.float16, True).clone()
+        y.mul_(0.5)                                    # in place, undetectable through a version counter
+        b = m.forward_with_cfg(x, t, y, 6.0, torch.float16, True).clone()
+    y2 = (synth.tensor(7, "y", (1, 70, 64)).to(DEV) * 1.0) * 0.5
+    c = m.forward_with_cfg(x, t, y2, 6.0, torch.float16, True)
+    assert not torch.equal(a, b) and torch.equal(b, c)

@@ -171,3 +171,29 @@ def test_load_checkpoints_takes_the_packed_routes(pkg, tmp_path):
     mapped = pkg.DiT(**_SMALL_DIT)
     pipeline.load_checkpoints(model=mapped, dit_checkpoint_path=pk_path)
     assert torch.equal(want, mapped._pack[(torch.float16, torch.device("cpu"))]["_flat"].view(torch.int16))
+
+
+def test_additive_pos_emb_variant_travels_on_the_packed_routes(pkg, tmp_path):
+    """DiTAdditivePosEmb has parameters the base class lacks (point_emb.mlp, fp32 next to x_embedder) and a buffer
+    (point_emb.basis): the packed routes must carry the former, tolerate the latter, and refuse a base-class file."""
+    cfg = dict(seq_length=8, in_channels=4, condition_channels=8, hidden_size=64, depth=2, num_heads=2, attn_proj_bias=True)
+    a = pkg.DiTAdditivePosEmb(**cfg)
+    for prm in a.parameters():
+        prm.data.normal_()
+    sd = {k: v.clone() for k, v in a.state_dict().items()}
+    assert "point_emb.basis" in sd and "point_emb.mlp.weight" in sd
+    names = {id(p): n for n, p in a.named_parameters()}
+    small = [names[id(p)] for p in a._small_fp32_params()]
+    assert "point_emb.mlp.weight" in small and "point_emb.mlp.bias" in small
+    assert a._hyper()["class"] == "DiTAdditivePosEmb"
+    b = pkg.DiTAdditivePosEmb(**cfg)
+    b.pack_from_state_dict(sd, torch.float16)                  # the buffer key is not "unexpected"
+    assert torch.equal(b.point_emb.mlp.weight, a.point_emb.mlp.weight) and torch.equal(b.point_emb.mlp.bias, a.point_emb.mlp.bias)
+    path = str(tmp_path / "addpos.primxpk")
+    a.save_packed(path, torch.float16)
+    c = pkg.DiTAdditivePosEmb(**cfg)
+    c.load_packed(path)
+    assert torch.equal(c.point_emb.mlp.weight, a.point_emb.mlp.weight)
+    assert torch.equal(c.packed(torch.float16)["_flat"].view(torch.int16), a.packed(torch.float16)["_flat"].view(torch.int16))
+    with pytest.raises(RuntimeError, match="different model"):   # same hyper-parameters, other class: other parameter set
+        pkg.DiT(cond_drop_prob=0.0, **cfg).load_packed(path)

@@ -91,7 +91,9 @@ def _worker_packed(rank, world, port, batch, ret):
 
         def decode(samples):                                            # stand-in for latents_to_primitives
             calls["n"] = samples.shape[0]
-            return torch.cat([samples, samples.sum(-1, keepdim=True)], dim=-1)
+            # a decoder may reshape (e.g. [b, N, C, S, S, S]): the token dim is NOT kept - the ranks without samples
+            # (batch 1 on two ranks) must learn the whole per-sample shape, not just the last dim
+            return torch.cat([samples, samples.sum(-1, keepdim=True)], dim=-1).view(samples.shape[0], 2, 4, 5)
 
         out = sampler.sample_and_decode(batch, 8, 4, cond, seed=7, decode=decode, loop=lambda x, y: x + y[:, :1, :4])
         from topia_xl_amd.sharding import shard_bounds
@@ -100,7 +102,7 @@ def _worker_packed(rank, world, port, batch, ret):
         if rank == 0:
             noise = torch.randn(batch, 8, 4, generator=torch.Generator().manual_seed(7))
             s = noise + cond[:, :1, :4]
-            assert out.shape == (batch, 8, 5) and torch.equal(out, torch.cat([s, s.sum(-1, keepdim=True)], dim=-1))
+            assert out.shape == (batch, 2, 4, 5) and torch.equal(out, torch.cat([s, s.sum(-1, keepdim=True)], dim=-1).view(batch, 2, 4, 5))
             ret.put("ok")
         else:
             assert out is None
