@@ -4,10 +4,12 @@
               GRBM_GUI_ACTIVE --output-format csv -d DIR -o NAME -- python bench.py ...
     python tools/pmc_mfma_util.py DIR/**/NAME_counter_collection.csv <DIR/**/NAME_kernel_trace.csv | -> out.txt
 
-MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE): busy cycles are summed over the chip's
-SIMDs, GUI_ACTIVE counts the clock while the dispatch is on the GPU, so the ratio is clock-independent.  The effective
-shader clock = GRBM_GUI_ACTIVE / kernel duration (profiled passes clock lower than free runs, MI355X_MICROARCH.md DVFS
-note).  "frac of 2.5 PF" = algorithmic FLOPs / duration of THIS (profiled) pass / peak."""
+Columns: `busy/SIMD` = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs (cycles the matrix pipe of an average SIMD was busy);
+`util@2.4` = busy/SIMD / (duration x 2.4 GHz): the utilisation against the SPEC clock - a lower bound, because the chip does
+not hold 2.4 GHz under these kernels (the GEMM timelines, PRIMX_GEMM_PROF=1, measure 1.8 - 2.0 GHz as core cycles per 100 MHz
+tick inside the workgroups); `util@GUI` = busy/SIMD / GRBM_GUI_ACTIVE - GUI_ACTIVE also counts the dispatch overhead of a
+profiled launch, so it is only meaningful for kernels of >= 40 us.  "of 2.5PF" = algorithmic FLOPs / duration of THIS
+(profiled) pass / the 2.5 PFLOP/s dense peak."""
 import collections
 import csv
 import re
@@ -20,7 +22,8 @@ from pmc_traffic import CYCLES, short   # the launch-order -> shape tables  # no
 FLOPS = {"4096x1152x1152": 2 * 4096 * 1152 * 1152, "4096x1152x4608": 2 * 4096 * 1152 * 4608, "4096x4608x1152": 2 * 4096 * 4608 * 1152,
          "4096x3456x1152": 2 * 4096 * 3456 * 1152, "3072x64512x768": 2 * 2740 * 64512 * 768,
          "32x2048x2048x72": 4 * 32 * 2048 * 2048 * 72, "32x2048x1370x72": 4 * 32 * 2048 * 1370 * 72,
-         "256->256 @4^3 x2048": 2 * 2048 * 64 * 256 * 27 * 256}
+         "256->256 @4^3 x2048": 2 * 2048 * 64 * 256 * 27 * 256, "gn+256->32+sc @8^3 x2048": 2 * 2048 * 512 * 32 * 28 * 256,
+         "256->32 @8^3 x2048": 2 * 2048 * 512 * 32 * 27 * 256}
 
 
 def tag_of(kname, grid, seen):
@@ -56,8 +59,8 @@ for d in sorted(rows):
     if d in dur:
         agg[tag]["us"].append(dur[d])
 mean = lambda v: sum(v) / len(v) if v else float("nan")
-lines = ["# per (kernel, shape): means over the launches of one profiled bench pass; MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE)",
-         f"{'launches':>8} {'us':>8} {'clk GHz':>8} {'MFMA util':>9} {'MFMA insts':>11} {'VALU act/wave-cyc':>17} {'TF/s':>7} {'of 2.5PF':>8}  kernel"]
+lines = ["# per (kernel, shape): means over the launches of one profiled bench pass (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE)",
+         f"{'launches':>8} {'us':>8} {'busy/SIMD':>10} {'util@2.4':>8} {'util@GUI':>8} {'MFMA insts':>11} {'VALU act/wave-cyc':>17} {'TF/s':>7} {'of 2.5PF':>8}  kernel"]
 for tag in sorted(agg, key=lambda t: -sum(agg[t]["us"])):
     a = agg[tag]
     if not any(s in tag for s in ("gemm", "attn", "conv", "ln_modulate", "gemv", "groupnorm")):
@@ -72,6 +75,7 @@ for tag in sorted(agg, key=lambda t: -sum(agg[t]["us"])):
     fl = FLOPS.get(shape)
     tf = fl / us / 1e6 if fl and us else float("nan")
     valu = mean(a["SQ_ACTIVE_INST_VALU"]) / mean(a["SQ_WAVE_CYCLES"]) if a["SQ_WAVE_CYCLES"] else float("nan")
-    lines.append(f"{len(a['us']):8d} {us:8.2f} {clk:8.2f} {util:9.3f} {mean(a['SQ_INSTS_MFMA']):11.4g} {valu:17.3f} {tf:7.0f} {tf / 2500.0:8.3f}  {tag}")
+    u24 = busy / 1024.0 / (us * 2400.0) if us else float("nan")
+    lines.append(f"{len(a['us']):8d} {us:8.2f} {busy / 1024.0:10.0f} {u24:8.3f} {util:8.3f} {mean(a['SQ_INSTS_MFMA']):11.4g} {valu:17.3f} {tf:7.0f} {tf / 2500.0:8.3f}  {tag}")
 open(out, "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
