@@ -1153,6 +1153,9 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
     // the barrier
     float* red = reinterpret_cast<float*>(smem);
     float* mine = red + kg * (BM * RS);
+    // (72 ds_write_b32 per lane.  With the MFMA operands swapped the accumulator holds C^T and a tile parks with 18 ds_write_b128 -
+    // measured in round 3, same box: gate-residual 18.8 / 48.4 vs 19.1 / 47.5 us, the step 9.06 - 9.13 vs 8.90 - 8.97 ms: slower
+    // (16 lanes write the same 4 columns of 16 rows, 592 bytes apart: the row stride that suits the walk below conflicts there).)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
