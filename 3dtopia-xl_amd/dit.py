@@ -147,6 +147,14 @@ class DiT(nn.Module):
         # conditioning tensor and reused across DDIM steps.  Off by default: a step then executes the reference's full
         # algorithmic FLOPs (bench.py reports both when the flag is on).
         self.reuse_cond_kv = False
+        # Second opt-in exact-algebra shortcut, CFG forwards only: the unconditional half is conditioned on ONE row repeated L
+        # times (`y_null = null_cond_embedding.expand_as(y)`, dit_crossattn.py:207), so its L keys are identical, its softmax
+        # is uniform whatever the query, and its cross-attention output is the (identical) value row of every head - to_q and
+        # the attention core of that half compute nothing else.  With this flag they are skipped and the value row is broadcast;
+        # to_k / to_v, proj and everything else run as before.  Off by default: the headline executes the reference's full
+        # algorithmic FLOPs.  Measured at batch 1 (round 3): NO gain (8.55 vs 8.47 ms per step next to reuse_cond_kv) - the
+        # half-size to_q and attention launches occupy half of the CUs for the same time; it pays from batch 2 per GPU on.
+        self.collapse_null_cross_attention = False
         # Opt-in: run the two classifier-free-guidance halves of `forward_with_cfg` as two concurrent HIP streams
         # (_forward16); identical kernels and results per row.  PRIMX_CFG_STREAMS=1 turns it on for every model.
         self.cfg_streams = os.environ.get("PRIMX_CFG_STREAMS") == "1"
@@ -589,6 +597,7 @@ class DiT(nn.Module):
         # Every LayerNorm launch - a short kernel that reads the residual stream from the Infinity Cache - carries the prefetch
         # of the weights of the loader-wave GEMMs that follow it (ops.prefetch_hint): no launch, no event, no stream of its own.
         wpf = self.weight_prefetch
+        collapse = bool(self.collapse_null_cross_attention) and null_half
 
         def warm(*wts):
             if wpf:
@@ -605,8 +614,14 @@ class DiT(nn.Module):
             # ---- cross-attention to the image tokens (dit_crossattn.py:55, attention.py:96-114)
             warm(w["w_q"], w["w_cproj"])       # (the block's cross-attention K / V instead: -1.0 us on that kernel, +0.5 on this one)
             ops.layernorm_modulate(hh, ch[0], ch[1], N, xh, self.LN_EPS)
-            ops.linear_heads(xh, w["w_q"], w["b_q"], N, H, dh, [HEADS_ROWS], [Qc[b0:b1]], nq_pad, scale0=scale)
-            ops.attention(Qc[b0:b1], Kc_blk[i][b0:b1], Vc_blk[i][b0:b1], N, L, dh, scale, out=ah)
+            bc = min(b1, B) if collapse else b1          # batch entries [b0, bc) attend; [bc, b1) are unconditional rows
+            if bc > b0:
+                ops.linear_heads(xh[:(bc - b0) * N], w["w_q"], w["b_q"], N, H, dh, [HEADS_ROWS], [Qc[b0:bc]], nq_pad, scale0=scale)
+                ops.attention(Qc[b0:bc], Kc_blk[i][b0:bc], Vc_blk[i][b0:bc], N, L, dh, scale, out=ah[:bc - b0])
+            if bc < b1:
+                # V^T layout [b, h, DP, n_pad] (key 0 sits at position 0 of its quad-permuted group): the value row of every head
+                vrow = Vc_blk[i][max(bc, b0):b1, :, :dh, 0].reshape(b1 - max(bc, b0), 1, D)
+                ah[max(bc, b0) - b0:].copy_(vrow.expand(-1, N, -1))
             if hook is not None:
                 hook()
             ops.linear_gate_residual(ah.view(Th, D), w["w_cproj"], w["b_cproj"], ch[2], hh, N)

@@ -252,3 +252,25 @@ def test_inference_mode_conditioning_tensor(pkg):
     y2 = (synth.tensor(7, "y", (1, 70, 64)).to(DEV) * 1.0) * 0.5
     c = m.forward_with_cfg(x, t, y2, 6.0, torch.float16, True)
     assert not torch.equal(a, b) and torch.equal(b, c)
+
+
+def test_null_cross_attention_collapse_is_exact_algebra(pkg):
+    """`DiT.collapse_null_cross_attention`: the unconditional CFG half attends to ONE row repeated L times, so its cross-attention
+    output is that row's value projection whatever the query (dit_crossattn.py:207, attention.py:96-114).  The shortcut must give
+    the same guided output as the full computation up to the rounding of a uniform softmax."""
+    from oracle import synth
+    cfg = dict(in_channels=68, condition_channels=64, hidden_size=288, depth=2)
+    m = pkg.DiT(seq_length=128, num_heads=4, attn_proj_bias=True, cond_drop_prob=0.1, **cfg).eval()
+    m.load_state_dict(synth.dit_state_dict(7, **cfg))
+    m.to(DEV)
+    x = synth.tensor(7, "x", (2, 128, 68)).to(DEV)
+    y = synth.tensor(7, "y", (2, 70, 64)).to(DEV)
+    t = torch.tensor([500, 500], device=DEV)
+    for dt, tol in ((torch.float16, 1e-3), (torch.bfloat16, 8e-3)):
+        full = m.forward_with_cfg(x, t, y, 6.0, dt, True).float()
+        m.collapse_null_cross_attention = True
+        try:
+            short = m.forward_with_cfg(x, t, y, 6.0, dt, True).float()
+        finally:
+            m.collapse_null_cross_attention = False
+        assert rel_l2(short, full) < tol, (dt, rel_l2(short, full))
