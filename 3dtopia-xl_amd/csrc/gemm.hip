@@ -1036,9 +1036,6 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
 // Barrier protocol (all 10 waves execute every s_barrier): P (tile 0 landed) | S_kt per step (tile kt+1 landed: the loaders
 // waited for their own pieces; all fragment reads of tile kt are home: the compute waves waited lgkmcnt(0)) | D (ring
 // drained) | E (accumulators parked for the row-major walk).
-#ifndef PRIMX_G144L_NST
-#define PRIMX_G144L_NST 3   // ring depth of the loader-wave kernel (4 x 34,816 B still fit beside nothing: the epilogue's parking area is larger)
-#endif
 template <int DT, int EPI>
 __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p) {
     static_assert(EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_HEADS, "row-major epilogues only");
@@ -1047,7 +1044,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
     using V4e = typename T16<DT>::V4;
     typedef __attribute__((address_space(1))) const void GV;
     typedef __attribute__((address_space(3))) void LV;
-    constexpr int BM = 128, BN = 144, MI = 2, NI = 9, NST = PRIMX_G144L_NST;
+    constexpr int BM = 128, BN = 144, MI = 2, NI = 9, NST = 3;   // (4 stages fit and measured no better, also with cold weights in the step: 9.31 -> 9.36 ms)
     constexpr int ROWS = BM + BN, STAGE = ROWS * 64, NINST = ROWS / 8, NL = NINST / 2;   // 17 wave-instructions per loader per tile
     static_assert((NST - 1) * NL <= 63, "vmcnt is a 6-bit counter");
     constexpr int RS = BN + 4;

@@ -134,3 +134,26 @@ def test_pack_heads_layouts(ops, dtype):
         assert float(data.float().abs().sum()) == pytest.approx(float(src.float().abs().sum()), rel=1e-3)  # pads stay 0
         if kind == HEADS_VT:   # spare rows: row dh = ones at the valid keys (softmax denominator row), the rest zero
             assert float(buf[:, :, dh].float().sum()) == B * H * M and float(buf[:, :, dh + 1:].float().abs().sum()) == 0.0
+
+
+def test_prefetch_entry_points_change_nothing(ops):
+    """primx_prefetch / primx_prefetch_hint only pull bytes into the caches: the LayerNorm launch that carries a hint gives the
+    same bits as one without, a third pending hint is refused, and a launch consumes the hints."""
+    from topia_xl_amd._lib import PrimxError
+    x = synth.tensor(5, "x", (300, 1152)).to(DEV)
+    sh = synth.tensor(5, "sh", (3, 1152), 0.3).half().to(DEV)
+    sc = synth.tensor(5, "sc", (3, 1152), 0.3).half().to(DEV)
+    w1 = torch.randn(1152, 1152, device=DEV).half()
+    w2 = torch.randn(777, 64, device=DEV).half()            # a byte count that is not a multiple of a line
+    plain = ops.layernorm_modulate(x, sh, sc, 100, torch.empty(300, 1152, dtype=torch.float16, device=DEV))
+    ops.prefetch_hint(w1)
+    ops.prefetch_hint(w2)
+    with pytest.raises(PrimxError):
+        ops.prefetch_hint(w1)
+    hinted = ops.layernorm_modulate(x, sh, sc, 100, torch.empty(300, 1152, dtype=torch.float16, device=DEV))
+    assert torch.equal(plain, hinted)
+    ops.prefetch_hint(w1)                                    # the launch above consumed both: there is room again
+    again = ops.layernorm_modulate(x, sh, sc, 100, torch.empty(300, 1152, dtype=torch.float16, device=DEV))
+    assert torch.equal(plain, again)
+    ops.prefetch(w2, torch.cuda.current_stream())
+    torch.cuda.synchronize()
