@@ -20,6 +20,14 @@ def ops():
     return ops
 
 
+def _default_dispatch() -> bool:
+    """False when a kernel-selection switch of DESIGN.md section 8 is set: the arithmetic checks still run (that is what
+    tools/gpu/gpu_verify.sh --switches is for), the assertions on WHICH kernel was launched do not apply."""
+    import os
+    return not any(os.environ.get(v) for v in ("PRIMX_GEMM_LOADER", "PRIMX_GEMM_NOBIG", "PRIMX_GEMM_P2", "PRIMX_GEMM_BIG_MIN",
+                                               "PRIMX_GEMM_BIGHEADS_MIN", "PRIMX_GEMM_NOGEMV", "PRIMX_GEMM_PROF", "PRIMX_LIB"))
+
+
 def _mk(seed, M, N, K, dtype):
     A = synth.tensor(seed, "A", (M, K)).to(dtype)
     W = synth.tensor(seed, "W", (N, K), K ** -0.5).to(dtype)
@@ -149,7 +157,8 @@ def test_loader_wave_kernel_edges(ops, dtype, M, K):
     boundary inside a tile, q scale on segment 0)."""
     from topia_xl_amd._lib import HEADS_KROWS, HEADS_ROWS
     from topia_xl_amd import _lib
-    launched = lambda: _lib.load().primx_last_gemm_kernel().decode()      # what the library reports it launched
+    # what the library reports it launched (only checked under the default dispatch rules)
+    launched = (lambda: _lib.load().primx_last_gemm_kernel().decode()) if _default_dispatch() else (lambda: "gemm144l_dma_kernel (not checked)")
     N = 288
     A, W, b, ref = _mk(31, M, N, K, dtype)
     r = lambda t: t.to(dtype).double()
@@ -218,6 +227,8 @@ def test_reported_kernel_names_of_the_headline_shapes(ops):
     (primx_last_gemm_kernel: what csrc/gemm.hip's dispatch actually selected, as rocprofv3 prints it) + the launch shape.
     The BASELINE configs[1] shapes must land on the kernels DESIGN.md section 4 says they do."""
     from topia_xl_amd import _lib
+    if not _default_dispatch():
+        pytest.skip("a kernel-selection switch is set")
     f16, T, D, H, dh = torch.float16, 4096, 1152, 16, 72
     name = lambda: _lib.load().primx_last_gemm_kernel().decode()
     A = torch.zeros(T, 4 * D, dtype=f16, device=DEV)
