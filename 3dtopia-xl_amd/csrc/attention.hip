@@ -634,6 +634,95 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
 // ~4 cycles, half the rate two waves reach, and this kernel is bound by VALU issue (exp, pack, max), not by the matrix pipe.
 // Removed in round 3; the measurements are in DESIGN.md section 5.)
 
+// ---------------------------------------------------------------------------------------------------
+// Small problems: nq, nkv <= 64 at dh = 32 - the VAE mid-block attention over the 64 voxels of a 4^3 primitive
+// (models/vae3d_dib.py:168-186: 2048 primitives x 8 heads = 16,384 problems per sample).  The 8-wave kernel above gives one
+// workgroup of 256 query rows to each of them: six of its eight waves idle, the operand buffers padded to 256 tokens, 198 us per
+// decode at 43 TFLOP/s.  Here ONE WAVE owns a problem and nothing goes through LDS: the compact operand layouts (n_pad = 64) are
+// already in MFMA fragment order - Q / K rows give the 16-byte operand pieces of S^T = K Q^T directly, the PRIMX_HEADS_VT
+// layout's quad order makes a lane's eight keys of a PV step one 16-byte piece of a V^T row - so the wave loads 13 KB, runs
+// 8 + 8 MFMAs with the softmax of its 64 query rows in registers (queries in the lane dimension: per-lane max / sum, one
+// exchange with lane ^ 32) and stores 4 KB.  Memory-bound: 213 MB in, 67 MB out per decode.
+template <int DT>
+__global__ __launch_bounds__(256) void attn64_kernel(const typename T16<DT>::S* __restrict__ Qp, const typename T16<DT>::S* __restrict__ Kp,
+                                                     const typename T16<DT>::S* __restrict__ Vt, typename T16<DT>::S* __restrict__ out,
+                                                     int BH, int H, int nq, int nkv, float c /* scale * log2(e) */) {
+    using S = typename T16<DT>::S;
+    using V8 = typename T16<DT>::V8;
+    using V4 = typename T16<DT>::V4;
+    constexpr int NP = 64, DH = 32, KROW = DH + 8;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bh >= BH) return;
+    const S* q = Qp + (int64_t)bh * NP * DH;
+    const S* k = Kp + (int64_t)bh * NP * KROW;
+    const S* v = Vt + (int64_t)bh * DH * NP;
+    V8 qf[2][2], kf[2][2], vf[2][2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[blk][ks] = ldg16<V8>(q + (blk * 32 + l31) * DH + ks * 16 + hi * 8);
+            kf[blk][ks] = ldg16<V8>(k + (blk * 32 + l31) * KROW + ks * 16 + hi * 8);
+            vf[blk][ks] = ldg16<V8>(v + l31 * NP + (4 * blk + 2 * ks + hi) * 8);   // keys of 16-group 2 blk + ks, this half-wave's quads
+        }
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    const int b = bh / H, h = bh - b * H;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        f32x16 sc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            sc[kb] = T16<DT>::mfma32(kf[kb][0], qf[qb][0], zero16);
+            sc[kb] = T16<DT>::mfma32(kf[kb][1], qf[qb][1], sc[kb]);
+        }
+        if (nkv < NP) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= nkv) sc[kb][r] = -1e30f;
+        }
+        float mx = fmaxf(sc[0][0], sc[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sc[0][r]), sc[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mc = mx * c;
+        float psum = 0.f;
+        V8 pb[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][8 * k2 + e], c, -mc));
+                    psum += pv;
+                    pb[kb][k2][e] = (S)pv;
+                }
+        psum += __shfl_xor(psum, 32);
+        f32x16 o = zero16;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) o = T16<DT>::mfma32(vf[kb][k2], pb[kb][k2], o);
+        const float inv = 1.0f / psum;
+        const int qi = qb * 32 + l31;
+        if (qi < nq) {
+            S* orow = out + ((int64_t)b * nq + qi) * ((int64_t)H * DH) + (int64_t)h * DH;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                V4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (S)(o[4 * g + e] * inv);
+                *reinterpret_cast<V4*>(orow + 8 * g + 4 * hi) = w;
+            }
+        }
+    }
+}
+
 // PRIMX_ATTN_PROF=1|2: run the instrumented variant (dh 72, fp16) synchronously and print the per-segment cycle profile
 static const int g_attn_prof_on = [] {
     const char* e = getenv("PRIMX_ATTN_PROF");
@@ -673,7 +762,18 @@ extern "C" int primx_attention(const void* Qp, const void* Kp, const void* Vt, v
                                int nq_pad, int nkv, int nkv_pad, int dh, float scale, int dtype, void* stream) {
     PRIMX_REQUIRE(Qp && Kp && Vt && out, "primx_attention: null pointer");
     PRIMX_REQUIRE(B > 0 && H > 0 && nq > 0 && nkv > 0, "primx_attention: empty problem");
-    PRIMX_REQUIRE(nq_pad >= nq && nq_pad % QPAD == 0, "primx_attention: nq_pad must be a multiple of 128 and >= nq");
+    const bool small64 = dh == 32 && nq <= 64 && nkv <= 64 && nq_pad == 64 && nkv_pad == 64;   // one wave per problem (attn64_kernel)
+    if (small64) {
+        const float c64 = scale * 1.4426950408889634f;
+        PRIMX_DISPATCH_16(dtype, "primx_attention", {
+            using S = typename T16<DT>::S;
+            hipLaunchKernelGGL((attn64_kernel<DT>), dim3((unsigned)((B * H + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const S*)Qp,
+                               (const S*)Kp, (const S*)Vt, (S*)out, B * H, H, nq, nkv, c64);
+        });
+        PRIMX_CHECK_LAUNCH("primx_attention");
+        return PRIMX_OK;
+    }
+    PRIMX_REQUIRE(nq_pad >= nq && nq_pad % QPAD == 0, "primx_attention: nq_pad must be a multiple of 128 and >= nq (or 64 for the 64-token, dh = 32 kernel)");
     PRIMX_REQUIRE(nkv_pad >= nkv && nkv_pad % BKV == 0, "primx_attention: nkv_pad must be a multiple of 64 and >= nkv");
     PRIMX_REQUIRE(nq_pad / QPAD <= 65535, "primx_attention: too many query tiles");
     const float c = scale * 1.4426950408889634f;

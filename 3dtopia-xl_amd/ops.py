@@ -297,8 +297,10 @@ def attention(Qp: torch.Tensor, Kp: torch.Tensor, Vt: torch.Tensor, nq: int, nkv
     if out is None:
         out = torch.empty(B, nq, H * dh, dtype=Qp.dtype, device=Qp.device)
     # algorithmic FLOPs: QK^T + PV on the unpadded head dim, softmax excluded
-    _timed(f"attn_kernel<{dtype_code(Qp.dtype)}, {padded_head_dim(dh) // 16}, {(dh + 31) // 32}, {int(padded_head_dim(dh) == dh)}, 0> "
-           f"{B * H}x{nq}x{nkv}x{dh}", 4.0 * B * H * nq * nkv * dh, lambda: check(_lib.load().primx_attention(
+    small = dh == 32 and nq <= 64 and nkv <= 64 and nq_pad == 64 and nkv_pad == 64    # csrc/attention.hip: one wave per problem
+    name = f"attn64_kernel<{dtype_code(Qp.dtype)}>" if small else \
+        f"attn_kernel<{dtype_code(Qp.dtype)}, {padded_head_dim(dh) // 16}, {(dh + 31) // 32}, {int(padded_head_dim(dh) == dh)}, 0>"
+    _timed(f"{name} {B * H}x{nq}x{nkv}x{dh}", 4.0 * B * H * nq * nkv * dh, lambda: check(_lib.load().primx_attention(
         _dev(Qp, "Qp"), _dev(Kp, "Kp", Qp.dtype), _dev(Vt, "Vt", Qp.dtype), _dev(out, "out", Qp.dtype), B, H, nq,
         nq_pad, nkv, nkv_pad, dh, scale, dtype_code(Qp.dtype), _stream()), "primx_attention"))
     return out

@@ -277,12 +277,16 @@ class VAE(nn.Module):
         t = ops.groupnorm_silu(h, w["g"], w["b"], w["groups"], w["eps"], False)
         # persistent zero-padded operand buffers (the kernels never write the pads, so they stay zero): three 67 MB zero fills
         # per decode otherwise.  One entry per (P, dtype, device); bounded.
+        # 64 voxels x 32-wide heads (the shipped decoder): compact operands for the one-wave-per-problem kernel
+        # (csrc/attention.hip attn64_kernel); anything else: the 256-row workgroup kernel's padding
+        pad = 64 if (V <= 64 and dh == 32) else ops.BQ
+
         def alloc():
-            return (ops.alloc_heads(P, H, V, dh, HEADS_ROWS, h.dtype, h.device, ops.BQ, "q"),
-                    ops.alloc_heads(P, H, V, dh, HEADS_KROWS, h.dtype, h.device, ops.BQ, "k"),
-                    ops.alloc_heads(P, H, V, dh, HEADS_VT, h.dtype, h.device, ops.BQ))
+            return (ops.alloc_heads(P, H, V, dh, HEADS_ROWS, h.dtype, h.device, pad, "q"),
+                    ops.alloc_heads(P, H, V, dh, HEADS_KROWS, h.dtype, h.device, pad, "k"),
+                    ops.alloc_heads(P, H, V, dh, HEADS_VT, h.dtype, h.device, pad))
         if P <= 4096:                                      # (200 MB at P = 2048; larger one-off batches are not kept)
-            key = (P, H, V, dh, h.dtype, h.device)
+            key = (P, H, V, dh, pad, h.dtype, h.device)
             ws = self.__dict__.setdefault("_attn_ws", {})
             if key not in ws:
                 if len(ws) >= 2:

@@ -164,9 +164,11 @@ int primx_linear_heads(const void* A, const void* W, const void* bias, int M, in
  * denominator in output row dh), every other pad entry of Qp/Kp/Vt zero - a padded key then scores -30000
  * through the MFMA itself and its probability underflows to exactly 0, with no mask or row-sum code in the
  * softmax (ops.alloc_heads does this).  When DP - dh >= 3 the caller additionally sets Kp[.., key, dh+1] =
- * Kp[.., key, dh+2] = 1 for EVERY key row (Qp stays 0 there): the one-wave-per-SIMD kernel keeps the running row
- * max, split into two 16-bit halves and negated, in its register copy of Q's columns dh+1 / dh+2, so the MFMA itself
- * subtracts it (nq_pad % 256 == 0 selects that kernel; PRIMX_ATTN_V2=0 forces the 8-wave kernel).
+ * Kp[.., key, dh+2] = 1 for EVERY key row (Qp stays 0 there): the kernel keeps the running row max, split into two
+ * 16-bit halves and negated, in its register copy of Q's columns dh+1 / dh+2, so the MFMA itself subtracts it.
+ * Small problems (the VAE mid-block attention: nq, nkv <= 64, dh == 32) may come in COMPACT buffers, nq_pad == nkv_pad == 64;
+ * they run on a one-wave-per-problem kernel that reads the operands straight from memory (no 256-row workgroup, no
+ * padding to 128 / 256 tokens).
  * Replaces xformers.ops.memory_efficient_attention(q, k, v) (attention.py:54,109). */
 int primx_attention(const void* Qp, const void* Kp, const void* Vt, void* out, int B, int H, int nq, int nq_pad,
                     int nkv, int nkv_pad, int dh, float scale, int dtype, void* stream);

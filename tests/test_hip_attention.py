@@ -117,3 +117,23 @@ def test_attention_modules_against_golden(ops, golden):
     assert rel_l2(c(q.to(DEV), kv, kv), g["cross_dh72"]) < 3e-3
     with pytest.raises(NotImplementedError):
         c(q.to(DEV), kv, kv.clone())                                # k and v must be the same conditioning tensor
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("nq,nkv", [(64, 64), (64, 50), (37, 64), (1, 1)])
+def test_small_problem_kernel(ops, dtype, nq, nkv):
+    """attn64_kernel (one wave per problem, compact operands: n_pad = 64, dh = 32 - the VAE mid-block attention over the 64 voxels
+    of a primitive): against float64, ragged query / key counts included, many problems per launch (4 per workgroup + a tail)."""
+    from topia_xl_amd._lib import HEADS_KROWS, HEADS_ROWS, HEADS_VT
+    B, H, dh = 7, 3, 32
+    q = synth.tensor(61, "q", (B, nq, H, dh)).to(dtype)
+    k = synth.tensor(61, "k", (B, nkv, H, dh)).to(dtype)
+    v = synth.tensor(61, "v", (B, nkv, H, dh)).to(dtype)
+    Q = ops.pack_heads(q.to(DEV), HEADS_ROWS, 64, "q")
+    K = ops.pack_heads(k.to(DEV), HEADS_KROWS, 64, "k")
+    Vt = ops.pack_heads(v.to(DEV), HEADS_VT, 64)
+    assert Q.shape[2] == 64 and K.shape[2] == 64 and Vt.shape[3] == 64
+    got = ops.attention(Q, K, Vt, nq, nkv, dh, dh ** -0.5).view(B, nq, H, dh)
+    qd, kd, vd = (t.double().permute(0, 2, 1, 3) for t in (q, k, v))
+    ref = (torch.softmax(qd @ kd.transpose(-1, -2) * dh ** -0.5, -1) @ vd).permute(0, 2, 1, 3)
+    assert rel_l2(got, ref) < TOL[dtype], rel_l2(got, ref)
