@@ -21,6 +21,26 @@ from . import ops
 
 
 @ops.on_input_device
+_STATS_CACHE: dict = {}
+
+
+def _latent_stats(latent_mean, latent_std, dev):
+    """fp32 device tensors of the per-channel statistics.  The reference re-uploads them with every call
+    (inference.py:328-332); here a Python list / tuple is uploaded once per device (two pageable host-to-device copies and
+    their synchronisation per decode otherwise), tensors are used as they are."""
+    def one(v):
+        if isinstance(v, torch.Tensor):
+            return v.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        key = (tuple(float(a) for a in v), str(dev))
+        t = _STATS_CACHE.get(key)
+        if t is None:
+            if len(_STATS_CACHE) > 16:
+                _STATS_CACHE.clear()
+            t = _STATS_CACHE[key] = torch.tensor(key[0], dtype=torch.float32, device=dev)
+        return t
+    return one(latent_mean), one(latent_std)
+
+
 def latents_to_primitives(samples: torch.Tensor, vae, latent_mean: Optional[Sequence[float]] = None,
                           latent_std: Optional[Sequence[float]] = None, latent_nf: float = 1.0,
                           max_prims_per_call: int = 8 * 2048) -> torch.Tensor:
@@ -32,8 +52,7 @@ def latents_to_primitives(samples: torch.Tensor, vae, latent_mean: Optional[Sequ
     if latent_mean is None:
         # the reference's non-per-channel branch (inference.py:336-344) is dead for the shipped config (yml:64-65)
         raise NotImplementedError("per-channel latent_mean / latent_std are required (configs/inference_dit.yml:64-65)")
-    mean = torch.as_tensor(latent_mean, dtype=torch.float32, device=dev).reshape(-1).contiguous()
-    std = torch.as_tensor(latent_std, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+    mean, std = _latent_stats(latent_mean, latent_std, dev)      # device copies are made once per (values, device)
     if mean.numel() != C or std.numel() != C:
         raise AssertionError("latent_mean / latent_std must have one entry per latent channel")
     srt, z = ops.latent_denorm(samples.float().contiguous(), mean, std, latent_nf, 4)
