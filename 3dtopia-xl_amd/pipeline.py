@@ -20,7 +20,6 @@ import torch
 from . import ops
 
 
-@ops.on_input_device
 _STATS_CACHE: dict = {}
 
 
@@ -41,6 +40,7 @@ def _latent_stats(latent_mean, latent_std, dev):
     return one(latent_mean), one(latent_std)
 
 
+@ops.on_input_device
 def latents_to_primitives(samples: torch.Tensor, vae, latent_mean: Optional[Sequence[float]] = None,
                           latent_std: Optional[Sequence[float]] = None, latent_nf: float = 1.0,
                           max_prims_per_call: int = 8 * 2048) -> torch.Tensor:
