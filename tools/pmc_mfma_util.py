@@ -73,6 +73,8 @@ for tag in sorted(agg, key=lambda t: -sum(agg[t]["us"])):
     util = busy / (1024.0 * gui) if gui else float("nan")
     shape = tag.split("> ")[-1] if "> " in tag else ""
     fl = FLOPS.get(shape)
+    if "convt_" in tag:                      # the k2s2 upsample shares the convolution's shape tag: 8 taps, not 27
+        fl = 2 * 2048 * 64 * 8 * 256 * 256
     tf = fl / us / 1e6 if fl and us else float("nan")
     valu = mean(a["SQ_ACTIVE_INST_VALU"]) / mean(a["SQ_WAVE_CYCLES"]) if a["SQ_WAVE_CYCLES"] else float("nan")
     u24 = busy / 1024.0 / (us * 2400.0) if us else float("nan")
