@@ -262,3 +262,29 @@ def test_reported_kernel_names_of_the_headline_shapes(ops):
     finally:
         ops.PROFILE = None
     assert tag == "gemm288p_dma_kernel<1> 4096x4608x1152", tag
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K", [(4096, 64), (4096, 128), (3900, 192), (3600, 1152)])
+def test_two_pass_big_tile_edges(ops, dtype, M, K):
+    """gemm288p_dma_kernel (the Linear epilogue's 256 x 288 tile as two 256 x 144 passes with loader waves; one-round launches:
+    224 <= workgroups <= 256): one and two k-tiles per pass (fewer than ring stages: the ring then holds both passes at once), a
+    ragged last M tile, 15 instead of 16 row tiles, with / without bias, GELU (tanh and erf) and an output scale."""
+    from topia_xl_amd import _lib
+    N = 4608
+    assert 224 <= ((M + 255) // 256) * (N // 288) <= 256
+    A, W, b, ref = _mk(41, M, N, K, dtype)
+    r = lambda t: t.to(dtype).double()
+    got = ops.linear(A.to(DEV), W.to(DEV), b.to(DEV))
+    if _default_dispatch():
+        assert _lib.load().primx_last_gemm_kernel().decode().startswith("gemm288p_dma_kernel")
+    assert rel_l2(got, ref) < TOL[dtype], rel_l2(got, ref)
+    assert rel_l2(ops.linear(A.to(DEV), W.to(DEV), None), ref - b.double()) < TOL[dtype]
+    got = ops.linear(A.to(DEV), W.to(DEV), b.to(DEV), act=1)                              # tanh GELU
+    assert rel_l2(got, r(F.gelu(r(ref).float(), approximate="tanh"))) < 2 * TOL[dtype]
+    got = ops.linear(A.to(DEV), W.to(DEV), b.to(DEV), act=2, out_scale=0.25)              # exact GELU, then a scale
+    assert rel_l2(got, r(0.25 * r(F.gelu(r(ref).float())))) < 2 * TOL[dtype]
+    # untouched rows: an output buffer with a canary row behind the last valid one
+    out = torch.full((M + 1, N), 7.0, dtype=dtype, device=DEV)
+    ops.linear(A.to(DEV), W.to(DEV), b.to(DEV), out=out[:M])
+    assert float(out[M].float().min()) == 7.0 and float(out[M].float().max()) == 7.0
