@@ -329,6 +329,10 @@ __global__ __launch_bounds__(256) void prefetch_lines_kernel(const char* __restr
 }
 
 extern "C" int primx_prefetch_hint(const void* ptr, int64_t bytes) {
+    if (!ptr && bytes == 0) {            // (NULL, 0): drop what is pending (a caller whose LayerNorm launch did not happen)
+        g_pf_hint = PrefetchArgs{nullptr, nullptr, 0, 0, 0};
+        return PRIMX_OK;
+    }
     PRIMX_REQUIRE(ptr && bytes > 0, "primx_prefetch_hint: bad argument");
     if (!g_pf_hint.p0) { g_pf_hint.p0 = (const char*)ptr; g_pf_hint.lines0 = (bytes + 127) / 128; }
     else if (!g_pf_hint.p1) { g_pf_hint.p1 = (const char*)ptr; g_pf_hint.lines1 = (bytes + 127) / 128; }

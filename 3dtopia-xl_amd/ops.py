@@ -111,13 +111,20 @@ def layernorm_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor
                        out: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
     """x: [rows, D] fp32; shift/scale: [B, D] 16-bit views (last dim contiguous, row stride arbitrary)."""
     rows, D = x.shape
-    if shift.stride(-1) != 1 or scale.stride(-1) != 1 or shift.stride(0) != scale.stride(0):
-        raise RuntimeError("shift/scale must be last-dim contiguous with equal row strides")
-    if not (shift.is_cuda and scale.is_cuda and shift.dtype == out.dtype == scale.dtype):
-        raise TypeError("shift/scale/out dtype or device mismatch")
-    check(_lib.load().primx_layernorm_modulate(
-        _dev(x, "x", torch.float32), shift.data_ptr(), scale.data_ptr(), shift.stride(0), _dev(out, "out"),
-        dtype_code(out.dtype), rows, rows_per_batch, D, eps, _stream()), "primx_layernorm_modulate")
+    try:
+        if shift.stride(-1) != 1 or scale.stride(-1) != 1 or shift.stride(0) != scale.stride(0):
+            raise RuntimeError("shift/scale must be last-dim contiguous with equal row strides")
+        if not (shift.is_cuda and scale.is_cuda and shift.dtype == out.dtype == scale.dtype):
+            raise TypeError("shift/scale/out dtype or device mismatch")
+        check(_lib.load().primx_layernorm_modulate(
+            _dev(x, "x", torch.float32), shift.data_ptr(), scale.data_ptr(), shift.stride(0), _dev(out, "out"),
+            dtype_code(out.dtype), rows, rows_per_batch, D, eps, _stream()), "primx_layernorm_modulate")
+    except Exception:
+        # a launch that did not happen must not leave prefetch ranges pending for some later, unrelated LayerNorm
+        lib = _lib.load()
+        if hasattr(lib, "primx_prefetch_hint"):
+            lib.primx_prefetch_hint(None, 0)
+        raise
     return out
 
 

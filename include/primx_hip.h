@@ -100,7 +100,8 @@ int primx_prefetch(const void* ptr, int64_t bytes, void* stream);
 /* The same prefetch WITHOUT a launch of its own: registers [ptr, ptr + bytes) (at most two pending ranges per host thread) with
  * the next primx_layernorm_modulate call on this thread, whose grid gets extra leading workgroups that load one word per
  * 128-byte line (its D % 128 == 0 fast path; other shapes drop the hint).  A cross-stream prefetch costs an event pair per use
- * (+0.1 ms per DDIM step measured); riding on the LayerNorm that precedes every GEMM group costs nothing on the host. */
+ * (+0.1 ms per DDIM step measured); riding on the LayerNorm that precedes every GEMM group costs nothing on the host.
+ * (NULL, 0) drops the pending ranges: the ranges must still be allocated when the LayerNorm launch that carries them runs. */
 int primx_prefetch_hint(const void* ptr, int64_t bytes);
 
 /* out = cast16( silu(in) ) elementwise.  The SiLU in front of every adaLN Linear
