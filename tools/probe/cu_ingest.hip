@@ -9,6 +9,9 @@
 //   mode 2  as 1, every W fragment fetched by FOUR waves (waves split M as today: 72 KiB per k-tile)
 //   mode 3  W only, as in 1 (plain-load rate)           mode 4  A only by LDS-DMA (DMA rate, half the bytes)
 //   mode 5  W only by LDS-DMA from the loaders (18 KiB) mode 6  W only, as in 2 (72 KiB of plain loads)
+//   mode 7  W only by LDS-DMA from the ROW-MAJOR [1152][K] matrix (8 rows x 128 B per instruction, what the shipped kernels do) -
+//           against mode 5: does a pre-packed weight image (1 KiB contiguous per instruction) enter the CU faster?
+//   mode 8  A + row-major W by LDS-DMA: the shipped loop's traffic exactly (mode 0 has the packed W image)
 // Build: hipcc --offload-arch=gfx950 -O3 -o cu_ingest cu_ingest.hip ; run: ./cu_ingest [K=1152]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -29,9 +32,14 @@ __global__ __launch_bounds__(640) void ingest(const char* __restrict__ A, const 
     __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mt = blockIdx.x >> 3, nt = blockIdx.x & 7;                 // 32 x 8 tiles of a 4096 x 1152 output
-    constexpr bool DMA_A = MODE == 0 || MODE == 1 || MODE == 2 || MODE == 4;
-    constexpr bool DMA_W = MODE == 0 || MODE == 5;
+    // 32 x 8 tiles of a 4096 x 1152 output; workgroup id -> XCD id & 7: the 32 workgroups of an XCD take 4 row tiles x all 8
+    // column tiles, so an XCD's L2 holds 4 A panels + W (the real kernels' xcd_remap does the same; with the naive id -> tile map
+    // every XCD fetched ALL of A and the A modes measured the fabric: 12.7 B/clk/CU)
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int mt = xcd * 4 + (jx >> 3), nt = jx & 7;
+    constexpr bool DMA_A = MODE == 0 || MODE == 1 || MODE == 2 || MODE == 4 || MODE == 8;
+    constexpr bool DMA_W = MODE == 0 || MODE == 5 || MODE == 7 || MODE == 8;
+    constexpr bool W_ROWS = MODE == 7 || MODE == 8;      // W by LDS-DMA from the row-major [1152][K] matrix (8 rows x 128 B per instruction)
     constexpr int W_REP = (MODE == 1 || MODE == 3) ? 1 : (MODE == 2 || MODE == 6) ? 4 : 0;
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -41,7 +49,8 @@ __global__ __launch_bounds__(640) void ingest(const char* __restrict__ A, const 
         const int lw = wave - 8;
         const unsigned lds0 = (unsigned)(uintptr_t)(LV*)smem;
         const char* a_base = A + ((size_t)mt * 128 + (lane >> 3)) * (size_t)K * 2 + (lane & 7) * 16;
-        const char* w_base = Wp + (size_t)nt * nk * 18432 + lane * 16;
+        const char* w_base = W_ROWS ? Wp + ((size_t)nt * 144 + (lane >> 3)) * (size_t)K * 2 + (lane & 7) * 16
+                                    : Wp + (size_t)nt * nk * 18432 + lane * 16;
         constexpr int NI = (DMA_A ? 16 : 0) + (DMA_W ? 18 : 0);
         if (NI > 0) {
             for (int t = 0; t < nk; ++t) {
@@ -51,7 +60,8 @@ __global__ __launch_bounds__(640) void ingest(const char* __restrict__ A, const 
                     const int i = 2 * ii + lw;
                     const bool is_a = DMA_A && i < 16;
                     const int iw = DMA_A ? i - 16 : i;
-                    const char* src = is_a ? a_base + (size_t)(i * 8) * K * 2 + (size_t)t * 128 : w_base + ((size_t)t * 18 + iw) * 1024;
+                    const char* src = is_a ? a_base + (size_t)(i * 8) * K * 2 + (size_t)t * 128
+                                      : W_ROWS ? w_base + (size_t)(iw * 8) * K * 2 + (size_t)t * 128 : w_base + ((size_t)t * 18 + iw) * 1024;
                     const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + st * STAGE + i * 1024);
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src) : "memory");
                 }
@@ -122,9 +132,11 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&W, w_bytes));
     CK(hipMemset(A, 1, a_bytes));
     CK(hipMemset(W, 2, w_bytes));
-    run<0>("0: A + W by LDS-DMA (2 loader waves)", A, W, K, 34816.0);
+    run<8>("8: A + row-major W by LDS-DMA (shipped form)", A, W, K, 34816.0);
+    run<0>("0: A + packed W by LDS-DMA (2 loader waves)", A, W, K, 34816.0);
+    run<7>("7: W only by LDS-DMA, row-major source", A, W, K, 18432.0);
     run<4>("4: A only by LDS-DMA", A, W, K, 16384.0);
-    run<5>("5: W only by LDS-DMA", A, W, K, 18432.0);
+    run<5>("5: W only by LDS-DMA, packed source", A, W, K, 18432.0);
     run<3>("3: W only, global->VGPR, each fragment once", A, W, K, 24576.0);
     run<6>("6: W only, global->VGPR, each fragment x4", A, W, K, 73728.0);
     run<1>("1: A by LDS-DMA + W global->VGPR once", A, W, K, 16384.0 + 24576.0);
