@@ -83,6 +83,20 @@ struct GemmArgs {
     int cout;      // EPI_CONVT: N = 8 * cout
 };
 
+// Kernel arguments of the LDS-DMA kernels.  A struct passed by value lives in the kernarg segment and every wave starts with an
+// s_load of it - a scalar-cache miss, since the packet processor has just written that memory - before it can form its first DMA
+// address.  The fields the prologue needs come as LEADING SCALAR arguments instead, which the build preloads into SGPRs at wave
+// launch (csrc/build.py: -mllvm -amdgpu-kernarg-preload-count=16; aggregates are not preloadable): -0.25 us per launch measured on
+// the LayerNorm kernel, whose arguments are scalars anyway (rocprofv3, 3910 launches: 8.35 -> 8.10 us).  The rest of the struct is
+// loaded behind the first DMAs.
+#define PRIMX_GEMM_PARAMS(DT)                                                                                                \
+    const typename T16<DT>::S *pl_A, const typename T16<DT>::S *pl_W, int pl_M, int pl_N, int pl_K, int pl_xcd_gm, int pl_prof, \
+        const GemmArgs<DT> pl_rest
+// (no local copy of the struct with the scalars patched in: the dynamically indexed members - kind[], dst[], rep_stride[] - would
+// turn it into a scratch array; the kernels name the leading arguments directly and read everything else through `p`)
+#define PRIMX_GEMM_ARGS(DT) const GemmArgs<DT>& p = pl_rest
+#define PRIMX_GEMM_PASS(x) (x).A, (x).W, (x).M, (x).N, (x).K, (x).xcd_gm, (x).prof, (x)
+
 // Activation of the EPI_LINEAR epilogue.  `p.act` is uniform, but both branches are pure arithmetic, so hipcc if-converts
 // them: every element then paid for the tanh form AND the erf polynomial (~40 VALU instructions instead of ~12; the fc1
 // epilogue was 31k of the kernel's 91k cycles, PRIMX_GEMM_PROF).  The empty volatile asm makes each side
@@ -751,9 +765,10 @@ __device__ unsigned long long g_gemm_prof[12];
 __device__ unsigned long long g_gemm_wg[4096][4];
 
 template <int DT, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> p) {
+__global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(PRIMX_GEMM_PARAMS(DT)) {
+    PRIMX_GEMM_ARGS(DT);
     unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pc2 = 0;
-    if (p.prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
+    if (pl_prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
     typedef __attribute__((address_space(1))) const void GV;
@@ -776,7 +791,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     const int kg = wave >> 2, wm = wave & 3;
     const int lr = lane & 15, lg = lane >> 4;
 
-    const int nt = p.N / BN, mt = (p.M + BM - 1) / BM;
+    const int nt = pl_N / BN, mt = (pl_M + BM - 1) / BM;
     const int id = xcd_remap(blockIdx.x, nt * mt);
     const int m0 = (id / nt) * BM, n0 = (id % nt) * BN;
 
@@ -787,8 +802,8 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
         const int t = min(wave + 8 * i, NINST - 1);
         const int row = 8 * t + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        gp[i] = (row < BM) ? p.A + (int64_t)min(m0 + row, p.M - 1) * p.K + c * 8
-                           : p.W + (int64_t)(n0 + row - BM) * p.K + c * 8;
+        gp[i] = (row < BM) ? pl_A + (int64_t)min(m0 + row, pl_M - 1) * pl_K + c * 8
+                           : pl_W + (int64_t)(n0 + row - BM) * pl_K + c * 8;
     }
     const bool last_slot = wave + 8 * (NSLOT - 1) < NINST;  // wave-uniform
     auto issue_one = [&](int kt, int stage, int i) {        // instruction t = wave + 8 i lands at stage + t * 1 KiB
@@ -848,16 +863,16 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
         for (int i = 0; i < NROWCH; ++i) {
             const int cid = tid + 512 * i;
             const int row = cid / (BN / 4), c4 = cid - row * (BN / 4);
-            const int m = min(m0 + row, p.M - 1);
-            xpre[i] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.N + n0 + 4 * c4);
+            const int m = min(m0 + row, pl_M - 1);
+            xpre[i] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * pl_N + n0 + 4 * c4);
         }
     }
 
-    const int nk = p.K / BK;
+    const int nk = pl_K / BK;
 #pragma unroll
     for (int s0 = 0; s0 < NST; ++s0) issue(min(s0, nk - 1), s0);
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NST - 1)) : "memory");  // tile 0 landed (4..5 DMAs per tile per wave)
-    if (p.prof) pc1 = __builtin_readcyclecounter();
+    if (pl_prof) pc1 = __builtin_readcyclecounter();
     V8 a0[MI], b0[NI], a1[MI], b1[NI];
     read_frags(0, a0, b0);
     int st_cur = 0, st_next = 1;  // stage of tile kt / tile kt+1
@@ -880,10 +895,10 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
     }
     if (kt < nk) step(kt, a0, b0, a1, b1);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // drain the (redundant) tail DMAs before LDS reuse
-    if (p.prof) pc2 = __builtin_readcyclecounter();
+    if (pl_prof) pc2 = __builtin_readcyclecounter();
     unsigned long long pc_stg = 0;
     auto prof_end = [&]() {
-        if (p.prof) {
+        if (pl_prof) {
             const unsigned long long pc_iss = __builtin_readcyclecounter();
             if (tid == 0) atomicAdd(&g_gemm_prof[7], ((pc_stg - pc2) << 32) | (pc_iss - pc_stg));
             __builtin_amdgcn_s_waitcnt(0);   // the epilogue's stores have been issued AND acknowledged
@@ -940,7 +955,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
             bpre[i] = V4e{};
             if (p.bias && EPI != EPI_CONVT) bpre[i] = *reinterpret_cast<const V4e*>(p.bias + n0 + 4 * c4);
             if (EPI == EPI_GATE_RESIDUAL) {
-                const int m = min(m0 + row, p.M - 1);
+                const int m = min(m0 + row, pl_M - 1);
                 gpre[i] = *reinterpret_cast<const V4e*>(p.gate + (int64_t)(m / p.rows_per_batch) * p.gate_stride + n0 + 4 * c4);
             }
         }
@@ -952,7 +967,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mine[(wm * 32 + mi * 16 + 4 * lg + r) * RS + ni * 16 + lr] = acc[mi][ni][r];
         __syncthreads();
-        if (p.prof) pc_stg = __builtin_readcyclecounter();
+        if (pl_prof) pc_stg = __builtin_readcyclecounter();
         // (Issuing all 18 LDS reads up front - hipcc sinks each pair into the guarded block that uses it - shortens the
         // issue phase 6.2k -> 4.0k cycles but not the kernel: the epilogue ends when the stores are acknowledged.)
 #pragma unroll
@@ -961,7 +976,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
             const int row = cid / (BN / 4), c4 = cid - row * (BN / 4);
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(red + row * RS + 4 * c4);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(red + BM * RS + row * RS + 4 * c4);
-            if (m0 + row >= p.M) continue;
+            if (m0 + row >= pl_M) continue;
             if (EPI == EPI_HEADS && h_fast) {
                 using V4 = typename T16<DT>::V4;
                 int d = h_dd0 + 4 * c4, hh = h_hh0;          // d < dh + 144 <= 4 dh
@@ -987,7 +1002,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     xv[j] = xv[j] + rnd16<DT>((float)gv[j] * rnd16<DT>(v0[j] + v1[j] + (p.bias ? (float)bv[j] : 0.f)));
-                out_store(reinterpret_cast<f32x4*>(p.x + (int64_t)m * p.N + n), xv);
+                out_store(reinterpret_cast<f32x4*>(p.x + (int64_t)m * pl_N + n), xv);
             } else {
                 epilogue_row4<DT, EPI>(p, m0 + row, n0 + 4 * c4, v0 + v1, bpre[i]);
             }
@@ -1037,7 +1052,8 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(const GemmArgs<DT> 
 // waited for their own pieces; all fragment reads of tile kt are home: the compute waves waited lgkmcnt(0)) | D (ring
 // drained) | E (accumulators parked for the row-major walk).
 template <int DT, int EPI>
-__global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p) {
+__global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)) {
+    PRIMX_GEMM_ARGS(DT);
     static_assert(EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_HEADS, "row-major epilogues only");
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
@@ -1064,10 +1080,10 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
     // 4.7k until the last store is acknowledged, i.e. the 256 workgroups' simultaneous WRITE burst.  Both options removed.)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = p.N / BN, mt = (p.M + BM - 1) / BM;
+    const int nt = pl_N / BN, mt = (pl_M + BM - 1) / BM;
     const int id = xcd_remap(blockIdx.x, nt * mt);
     const int m0 = (id / nt) * BM, n0 = (id % nt) * BN;
-    const int nk = p.K / BK;
+    const int nk = pl_K / BK;
 
     if (wave >= 8) {
         // ---------------- loader wave lw: instructions t = lw * 17 + i, rows 8t .. 8t+7 of the 272-row stage image
@@ -1077,8 +1093,8 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
         for (int i = 0; i < NL; ++i) {
             const int row = 8 * (lw * NL + i) + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
-            gp[i] = (row < BM) ? p.A + (int64_t)min(m0 + row, p.M - 1) * p.K + c * 8
-                               : p.W + (int64_t)(n0 + row - BM) * p.K + c * 8;
+            gp[i] = (row < BM) ? pl_A + (int64_t)min(m0 + row, pl_M - 1) * pl_K + c * 8
+                               : pl_W + (int64_t)(n0 + row - BM) * pl_K + c * 8;
         }
         auto issue = [&](int kt, int stage) {
 #pragma unroll
@@ -1181,12 +1197,12 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
     for (int i = 0; i < NROWCH; ++i) {
         const int cid = tid + 512 * i;
         const int row = cid / (BN / 4), c4 = cid - row * (BN / 4);
-        const int m = min(m0 + row, p.M - 1);
+        const int m = min(m0 + row, pl_M - 1);
         bpre[i] = V4e{};
         if (p.bias) bpre[i] = *reinterpret_cast<const V4e*>(p.bias + n0 + 4 * c4);
         if (EPI == EPI_GATE_RESIDUAL) {
             gpre[i] = *reinterpret_cast<const V4e*>(p.gate + (int64_t)(m / p.rows_per_batch) * p.gate_stride + n0 + 4 * c4);
-            xpre[i] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.N + n0 + 4 * c4);
+            xpre[i] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * pl_N + n0 + 4 * c4);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                     // E
@@ -1196,7 +1212,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
         const int row = cid / (BN / 4), c4 = cid - row * (BN / 4);
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(red + row * RS + 4 * c4);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(red + BM * RS + row * RS + 4 * c4);
-        if (m0 + row >= p.M) continue;
+        if (m0 + row >= pl_M) continue;
         if (EPI == EPI_HEADS) {
             int d = h_dd0 + 4 * c4, hh = h_hh0;          // d < dh + 144 <= 4 dh
             if (d >= p.dh) { d -= p.dh; ++hh; }
@@ -1219,7 +1235,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 xv[j] = xv[j] + rnd16<DT>((float)gv[j] * rnd16<DT>(v0[j] + v1[j] + (p.bias ? (float)bv[j] : 0.f)));
-            out_store(reinterpret_cast<f32x4*>(p.x + (int64_t)(m0 + row) * p.N + n0 + 4 * c4), xv);
+            out_store(reinterpret_cast<f32x4*>(p.x + (int64_t)(m0 + row) * pl_N + n0 + 4 * c4), xv);
         } else {
             epilogue_row4<DT, EPI>(p, m0 + row, n0 + 4 * c4, v0 + v1, bpre[i]);
         }
@@ -1241,9 +1257,10 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(const GemmArgs<DT> p)
 // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) hit 16 distinct 16-byte slots (rows r&3 pick the 64-byte quarter of a
 // 256-byte bank window, the XOR separates rows 0-7 from 8-15 which the groups pair with chunk c and c+1).
 template <int DT, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT> p) {
+__global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(DT)) {
+    PRIMX_GEMM_ARGS(DT);
     unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pc2 = 0;   // PRIMX_GEMM_PROF=1 timeline (see g_gemm_prof)
-    if (p.prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
+    if (pl_prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
     typedef __attribute__((address_space(1))) const void GV;
@@ -1266,10 +1283,10 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 15, lg = lane >> 4;
 
-    const int nt = p.N / BN, mt = (p.M + BM - 1) / BM;
+    const int nt = pl_N / BN, mt = (pl_M + BM - 1) / BM;
     int mi_t, ni_t;
-    if (p.xcd_gm > 0 && p.xcd_gm < 8) {
-        xcd_tile2d(blockIdx.x, mt, nt, p.xcd_gm, mi_t, ni_t);
+    if (pl_xcd_gm > 0 && pl_xcd_gm < 8) {
+        xcd_tile2d(blockIdx.x, mt, nt, pl_xcd_gm, mi_t, ni_t);
     } else {
         const int id = xcd_remap(blockIdx.x, nt * mt);
         mi_t = id / nt;
@@ -1283,8 +1300,8 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
         const int t = min(wave + 8 * i, NINST - 1);
         const int row = 16 * t + (lane >> 2);
         const int c = (lane & 3) ^ (((row >> 3) & 1) << 1);
-        gp[i] = (row < BM) ? p.A + (int64_t)min(m0 + row, p.M - 1) * p.K + c * 8
-                           : p.W + (int64_t)(n0 + row - BM) * p.K + c * 8;
+        gp[i] = (row < BM) ? pl_A + (int64_t)min(m0 + row, pl_M - 1) * pl_K + c * 8
+                           : pl_W + (int64_t)(n0 + row - BM) * pl_K + c * 8;
     }
     const bool last_slot = wave + 8 * (NSLOT - 1) < NINST;  // wave-uniform (waves 0,1)
     auto issue_one = [&](int ks, int stage, int i) {        // slot i of this wave for k-slice ks
@@ -1305,7 +1322,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
     const int a_off = (wm * 64 + lr) * KS + ((lg ^ sw2) << 3);            // + i * 16 rows
     const int w_off = (BM + wn * 144 + lr) * KS + ((lg ^ sw2) << 3);      // + j * 16 rows
 
-    const int nks = p.K / KS;
+    const int nks = pl_K / KS;
 #pragma unroll
     for (int pre = 0; pre < NST - 1; ++pre)
 #pragma unroll
@@ -1315,7 +1332,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
     constexpr int NPF = 3;
     V8 a_n[MI], b_n[NPF];
     asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");     // slice 0 landed
-    if (p.prof) pc1 = __builtin_readcyclecounter();
+    if (pl_prof) pc1 = __builtin_readcyclecounter();
     {
         const S* base0 = smem;
 #pragma unroll
@@ -1370,9 +1387,9 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
     if (EPI == EPI_HEADS && vt_tile) main_loop(std::false_type{});
     else main_loop(std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (clamped tail DMAs)
-    if (p.prof) pc2 = __builtin_readcyclecounter();
+    if (pl_prof) pc2 = __builtin_readcyclecounter();
     auto prof_end = [&]() {
-        if (p.prof) {
+        if (pl_prof) {
             __builtin_amdgcn_s_waitcnt(0);   // the epilogue's stores have been issued AND acknowledged
             const unsigned long long pc3 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
             if (tid == 0) {
@@ -1502,14 +1519,14 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * 64 + i * 16 + lr;
 #ifdef PRIMX_PROBE_SKIPSTORE   // measurement builds only: 1 = odd tile columns store nothing, 2 = nobody stores (results invalid)
-        const bool ok = m < p.M && !(PRIMX_PROBE_SKIPSTORE == 2 || (ni_t & 1));
+        const bool ok = m < pl_M && !(PRIMX_PROBE_SKIPSTORE == 2 || (ni_t & 1));
 #else
-        const bool ok = m < p.M;
+        const bool ok = m < pl_M;
 #endif
-        const int mc = ok ? m : p.M - 1;
+        const int mc = ok ? m : pl_M - 1;
         if (EPI == EPI_GATE_RESIDUAL) {
             const S* grow = p.gate + (int64_t)(mc / p.rows_per_batch) * p.gate_stride + nb;
-            float* xrow = p.x + (int64_t)mc * p.N + nb;
+            float* xrow = p.x + (int64_t)mc * pl_N + nb;
             V4e gv[NI];
             f32x4 xv[NI];
 #pragma unroll
@@ -1532,7 +1549,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
             // group g then owns 8 consecutive columns of tile j + (g & 1) - 16 bytes per lane, 64 bytes per row and instruction,
             // half the instructions (probe "fc1 regs 16B": 12k cycles).  The ninth tile has no partner and keeps the 8-byte form.
             typedef unsigned int u32;
-            S* orow = p.out + (int64_t)mc * p.N + n0 + wn * 144;
+            S* orow = p.out + (int64_t)mc * pl_N + n0 + wn * 144;
 #pragma unroll
             for (int j = 0; j + 1 < NI; j += 2) {
                 const u32x2 a = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j], bpre[j]));
@@ -1571,9 +1588,10 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(const GemmArgs<DT>
 // ONE barrier per k-tile sits between its two steps: B_g = "reads of tile g are home (its stage may be refilled), tile g + 1 has
 // landed" - the same two-tiles-of-flight ring protocol as gemm144l_dma_kernel, all ten waves execute every barrier.
 template <int DT>
-__global__ __launch_bounds__(640) void gemm288p_dma_kernel(const GemmArgs<DT> p) {
+__global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)) {
+    PRIMX_GEMM_ARGS(DT);
     unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pc2 = 0;   // PRIMX_GEMM_PROF=1 timeline (see g_gemm_prof)
-    if (p.prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
+    if (pl_prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
     using V4e = typename T16<DT>::V4;
@@ -1586,17 +1604,17 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(const GemmArgs<DT> p)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = p.N / (NPASS * BN), mt = (p.M + BM - 1) / BM;
+    const int nt = pl_N / (NPASS * BN), mt = (pl_M + BM - 1) / BM;
     int mi_t, ni_t;
-    if (p.xcd_gm > 0 && p.xcd_gm < 8) {
-        xcd_tile2d(blockIdx.x, mt, nt, p.xcd_gm, mi_t, ni_t);
+    if (pl_xcd_gm > 0 && pl_xcd_gm < 8) {
+        xcd_tile2d(blockIdx.x, mt, nt, pl_xcd_gm, mi_t, ni_t);
     } else {
         const int id = xcd_remap(blockIdx.x, nt * mt);
         mi_t = id / nt;
         ni_t = id - mi_t * nt;
     }
     const int m0 = mi_t * BM, n00 = ni_t * NPASS * BN;
-    const int nk = p.K / BK, total = NPASS * nk;
+    const int nk = pl_K / BK, total = NPASS * nk;
 
     if (wave >= 8) {
         // ---------------- loader wave lw: instructions t = lw * 25 + i, rows 8 t .. 8 t + 7 of the 400-row stage image (rows
@@ -1607,11 +1625,11 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(const GemmArgs<DT> p)
         for (int i = 0; i < NL; ++i) {
             const int row = 8 * (lw * NL + i) + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
-            gp[i] = (row < BM) ? p.A + (int64_t)min(m0 + row, p.M - 1) * p.K + c * 8 : p.W + (int64_t)(n00 + row - BM) * p.K + c * 8;
+            gp[i] = (row < BM) ? pl_A + (int64_t)min(m0 + row, pl_M - 1) * pl_K + c * 8 : pl_W + (int64_t)(n00 + row - BM) * pl_K + c * 8;
         }
         auto issue = [&](int g, int stage) {  // global tile g = pass * nk + kt
             const int pass = g >= nk ? 1 : 0, kt = g - pass * nk;
-            const int64_t wpass = (int64_t)pass * BN * p.K;                                // pass 1: the next 144 weight rows
+            const int64_t wpass = (int64_t)pass * BN * pl_K;                                // pass 1: the next 144 weight rows
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
                 const int64_t adv = ((lw * NL + i) * 8 >= BM ? wpass : 0) + kt * BK;      // (wave-uniform: an instruction is all activation or all weight rows)
@@ -1654,7 +1672,7 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(const GemmArgs<DT> p)
             for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(b[j], a[i], acc[i][j]);
     };
     asm volatile("s_barrier" ::: "memory");                                              // P
-    if (p.prof) pc1 = __builtin_readcyclecounter();
+    if (pl_prof) pc1 = __builtin_readcyclecounter();
     int st = 0;
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -1676,7 +1694,7 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(const GemmArgs<DT> p)
             multiply(a1, b1);
             st = st_next;
         }
-        if (p.prof && pass == NPASS - 1) pc2 = __builtin_readcyclecounter();
+        if (pl_prof && pass == NPASS - 1) pc2 = __builtin_readcyclecounter();
         // ---- epilogue of the pass, from registers: bias, rounding, activation, 16-byte stores (the lane groups of a row trade
         // halves of neighbouring 16-column tiles with v_permlane16_swap, see gemm288q_dma_kernel).  Nothing below waits for the
         // stores: the next pass's fragments and MFMAs follow immediately.
@@ -1691,8 +1709,8 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(const GemmArgs<DT> p)
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = m0 + wave * 32 + i * 16 + lr;
-            const bool ok = m < p.M;
-            S* orow = p.out + (int64_t)(ok ? m : p.M - 1) * p.N + n0;
+            const bool ok = m < pl_M;
+            S* orow = p.out + (int64_t)(ok ? m : pl_M - 1) * pl_N + n0;
 #pragma unroll
             for (int j = 0; j + 1 < NI; j += 2) {
                 const u32x2 a = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j], bpre[j]));
@@ -1705,7 +1723,7 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(const GemmArgs<DT> p)
             if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), linear_out4<DT>(p, acc[i][NI - 1], bpre[NI - 1]));
         }
     }
-    if (p.prof) {
+    if (pl_prof) {
         __builtin_amdgcn_s_waitcnt(0);   // the stores have been acknowledged
         const unsigned long long pc3 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {
@@ -1792,18 +1810,18 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
         // overlaps the previous one's drain and the one-pass tile's fewer bytes per FLOP win (T = 32768: 428 vs 451 us)
         if (BIG && EPI == EPI_LINEAR && g_two_pass && (int)grid.x <= 256) {
             PRIMX_NOTE_KERNEL("gemm288p_dma_kernel<%d>", DT);
-            hipLaunchKernelGGL((gemm288p_dma_kernel<DT>), grid, dim3(640), 0, st, x);
+            hipLaunchKernelGGL((gemm288p_dma_kernel<DT>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
         } else if (BIG) {
             PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d>", DT, EPI);
-            hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
+            hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, PRIMX_GEMM_PASS(x));
         } else if (g_loader && loader_ok && !g_gemm_prof_on) {   // (no timeline stamps in the loader-wave kernel)
             if constexpr (EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_HEADS) {
                 PRIMX_NOTE_KERNEL("gemm144l_dma_kernel<%d, %d>", DT, EPI);
-                hipLaunchKernelGGL((gemm144l_dma_kernel<DT, EPI>), grid, dim3(640), 0, st, x);
+                hipLaunchKernelGGL((gemm144l_dma_kernel<DT, EPI>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
             }
         } else {
             PRIMX_NOTE_KERNEL("gemm144_dma_kernel<%d, %d>", DT, EPI);
-            hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, x);
+            hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, PRIMX_GEMM_PASS(x));
         }
     };
     if (!g_gemm_prof_on) {

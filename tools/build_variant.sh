@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../3dtopia-xl_amd/csrc"
 stem=$1; name=$2; shift; shift
 extra=""
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function -I../../include $extra "$@" -c $stem.hip -o ${stem}_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=16 -I../../include $extra "$@" -c $stem.hip -o ${stem}_$name.o
 objs=""
 for o in rowops gemm attention vae primsdf raymarch fp32 conv3 conv3s8 conv3s8c32 convt; do
   if [ $o = $stem ]; then objs="$objs ${stem}_$name.o"; else objs="$objs $o.o"; fi
