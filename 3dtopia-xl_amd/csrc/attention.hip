@@ -146,18 +146,21 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     // MFMA itself subtracts the max (exact products, fp32 accumulation) and a probability is ONE v_exp_f32 of an accumulator
     // register: no scale / subtract VALU work (16 v_pk_fma_f32 per wave and tile before).
     constexpr bool QCOL = PRIMX_ATTN_QCOL && !KMASK && (16 * KSTEPS - 3 >= 16 * (KSTEPS - 1) + 8);   // the three columns lie in the hi half of the last fragment
+    // (loaded by load_q() BEHIND the prologue's DMA issue: with the Q loads first hipcc waited vmcnt(0) for them - and for the three K(0)
+    // pieces issued after them - before it scaled Q, and only then issued pairs 0 and 1: two memory round trips in series in front
+    // of the first MFMA of every launch)
     V8 qf[KSTEPS];
-    {
+    auto load_q = [&]() {
         const S* qrow = Qp + ((int64_t)bh * nq_pad + min(q0 + wave * 32 + l31, nq_pad - 1)) * DP + hi * 8;
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            qf[s] = ldg16<V8>(qrow + s * 16);
-            if (QCOL) {
+        for (int s = 0; s < KSTEPS; ++s) qf[s] = ldg16<V8>(qrow + s * 16);
+        if (QCOL) {
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) qf[s][e] = (S)((float)qf[s][e] * c);
-            }
         }
-    }
+    };
     const int dq = dh - 16 * (KSTEPS - 1) - 8 * hi;      // position of column dh in this lane's last fragment (hi lanes: 0 at dh = 72)
     auto set_q_cols = [&](float m) {                    // columns dh, dh+1, dh+2 of Q: 1, -m_hi, -m_lo
         const S mh = (S)(-m);
@@ -169,7 +172,6 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
             if (e == dq + 2) qf[KSTEPS - 1][e] = ml;
         }
     };
-    if (QCOL) set_q_cols(0.f);
 
     // ---- DMA issue.  Piece t of a pair: t < NK -> 1 KiB piece t of the (contiguous) K tile; else V^T rows
     // 8(t-NK) .. +7, lane (row = lane>>3, LDS chunk = lane&7) fetching the source chunk (lane&7) ^ ((row>>1)&7).  The
@@ -498,6 +500,8 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
 #pragma unroll
     for (int pr = 0; pr < NSTAGE - 1; ++pr) issue_pair(pr, pr);
 #endif
+    load_q();
+    if (QCOL) set_q_cols(0.f);
     f32x16 sA[2], sB[2];
     PRIMX_ATTN_WAITB();                   // K(0) and pair 0 landed
     {
