@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PRIMX_LIB") or os.path.join(_HERE, "csrc", "libprimx_
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
 HEADS_ROWS, HEADS_VT, HEADS_KROWS = 0, 1, 2
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -34,6 +34,7 @@ SIGNATURES = {
     "primx_point_features": [_p, _l, _p, _p, _l, _i, _i, _p],
     "primx_prefetch": [_p, _l, _p],
     "primx_prefetch_hint": [_p, _l],
+    "primx_prefetch_hint_gemm": [_p, _l],
     "primx_silu_cast": [_p, _p, _i, _l, _p],
     "primx_cast16": [_p, _p, _i, _l, _p],
     "primx_linear_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
@@ -67,8 +68,8 @@ SIGNATURES = {
 }
 _RESTYPES = {"primx_last_error": C.c_char_p, "primx_last_gemm_kernel": C.c_char_p}
 # an alternate build named by PRIMX_LIB (same-box A/B against an older library) may predate these additive entry points
-_OPTIONAL_IN_AB_BUILDS = {"primx_last_gemm_kernel", "primx_prefetch", "primx_prefetch_hint"}
-_AB_ABI_VERSIONS = (18,)
+_OPTIONAL_IN_AB_BUILDS = {"primx_last_gemm_kernel", "primx_prefetch", "primx_prefetch_hint", "primx_prefetch_hint_gemm"}
+_AB_ABI_VERSIONS = (18, 19)
 
 _lib: Optional[C.CDLL] = None
 

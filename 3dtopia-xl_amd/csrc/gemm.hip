@@ -81,7 +81,33 @@ struct GemmArgs {
     int S3;        // grid edge S (volume S^3)
     int cin_log2;  // log2(Cin)
     int cout;      // EPI_CONVT: N = 8 * cout
+    // primx_prefetch_hint_gemm: pf_lines 128-byte lines from pf_ptr that the compute waves of the loader-wave kernels touch once
+    const char* pf_ptr;
+    int64_t pf_lines;
 };
+
+// Weight prefetch carried by a GEMM launch (primx_prefetch_hint_gemm, consumed or dropped by the next GEMM entry point on this
+// thread).  In the loader-wave kernels the compute waves never use their vector-memory queue inside the k-loop, so each of them
+// can request one dword per 128-byte line of ANOTHER GEMM's weights in front of the loop - one or two instructions per wave - and
+// the lines travel HBM -> Infinity Cache while the loop runs from L2, when the fabric is otherwise idle.  (Carried by the LayerNorm
+// launches instead - primx_prefetch_hint - the same bytes compete with the LayerNorm's own stream: 6.8 -> 8.3 us per launch.)
+thread_local const char* g_gemm_pf_ptr = nullptr;
+thread_local int64_t g_gemm_pf_lines = 0;
+
+typedef unsigned int pf_u32x2 __attribute__((ext_vector_type(2)));
+template <int DT>
+__device__ __forceinline__ pf_u32x2 gemm_prefetch_lines(const GemmArgs<DT>& p, int wave, int lane) {
+    // (the two values are handed back untouched - any arithmetic on them here would make hipcc wait for the loads on the spot - and
+    // are "used" by an empty asm behind the k-loop, where the compiler's own vmcnt wait for them costs nothing)
+    pf_u32x2 v = {0u, 0u};
+    if (p.pf_lines > 0) {                                  // (uniform)
+        const int64_t l0 = ((int64_t)blockIdx.x * 8 + wave) * 64 + lane, stride = (int64_t)gridDim.x * 512;
+        // two independent requests per lane cover 1024 lines per workgroup: 33.5 MB with 256 workgroups; longer ranges are cut
+        if (l0 < p.pf_lines) v[0] = *reinterpret_cast<const unsigned*>(p.pf_ptr + l0 * 128);
+        if (l0 + stride < p.pf_lines) v[1] = *reinterpret_cast<const unsigned*>(p.pf_ptr + (l0 + stride) * 128);
+    }
+    return v;
+}
 
 // Kernel arguments of the LDS-DMA kernels.  A struct passed by value lives in the kernarg segment and every wave starts with an
 // s_load of it - a scalar-cache miss, since the packet processor has just written that memory - before it can form its first DMA
@@ -1142,6 +1168,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     };
     constexpr int NROWCH = (BM * (BN / 4)) / 512;
     f32x4 xpre[NROWCH];
+    const pf_u32x2 pf_v = gemm_prefetch_lines<DT>(p, wave, lane);                        // (primx_prefetch_hint_gemm)
     asm volatile("s_barrier" ::: "memory");                                              // P
     V8 a0[MI], b0[NI], a1[MI], b1[NI];
     read_frags(0, a0, b0);
@@ -1158,6 +1185,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
         step(a1, b1, a0, b0);
     }
     if (kt < nk) step(a0, b0, a1, b1);
+    asm volatile("" ::"v"(pf_v[0]), "v"(pf_v[1]));                                                        // the prefetch requests have returned
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                     // D: the stages may be reused
 
     // ---------------- epilogue: both K halves park their accumulators as fp32 [half][128][148]; row-major walk, 4 columns
@@ -1671,6 +1699,7 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(b[j], a[i], acc[i][j]);
     };
+    const pf_u32x2 pf_v = gemm_prefetch_lines<DT>(p, wave, lane);                        // (primx_prefetch_hint_gemm)
     asm volatile("s_barrier" ::: "memory");                                              // P
     if (pl_prof) pc1 = __builtin_readcyclecounter();
     int st = 0;
@@ -1723,6 +1752,7 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
             if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), linear_out4<DT>(p, acc[i][NI - 1], bpre[NI - 1]));
         }
     }
+    asm volatile("" ::"v"(pf_v[0]), "v"(pf_v[1]));
     if (pl_prof) {
         __builtin_amdgcn_s_waitcnt(0);   // the stores have been acknowledged
         const unsigned long long pc3 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
@@ -1874,7 +1904,10 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
 }
 
 template <int DT, int EPI, int GATHER = 0>
-int launch(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
+int launch(const GemmArgs<DT>& a_in, hipStream_t st, const char* name) {
+    GemmArgs<DT> a = a_in;
+    a.pf_ptr = g_gemm_pf_ptr; a.pf_lines = g_gemm_pf_lines;      // consumed by this launch (kernels that cannot carry it ignore it)
+    g_gemm_pf_ptr = nullptr; g_gemm_pf_lines = 0;
     PRIMX_REQUIRE(a.A && a.W, "%s: null operand", name);
     PRIMX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 8 == 0, "%s: need M,N>0 and K %% 8 == 0 (M=%d N=%d K=%d)",
                   name, a.M, a.N, a.K);
@@ -2001,6 +2034,17 @@ static const bool g_no_gemv = [] {
 }  // namespace
 
 extern "C" const char* primx_last_gemm_kernel(void) { return g_last_gemm_kernel; }
+
+extern "C" int primx_prefetch_hint_gemm(const void* ptr, int64_t bytes) {
+    if (!ptr && bytes == 0) {                                     // drop a pending hint
+        g_gemm_pf_ptr = nullptr; g_gemm_pf_lines = 0;
+        return PRIMX_OK;
+    }
+    PRIMX_REQUIRE(ptr && bytes > 0, "primx_prefetch_hint_gemm: bad argument");
+    g_gemm_pf_ptr = (const char*)ptr;
+    g_gemm_pf_lines = (bytes + 127) / 128;
+    return PRIMX_OK;
+}
 
 extern "C" int primx_linear(const void* A, const void* W, const void* bias, void* out, int M, int N, int K, int dtype,
                             int act, float out_scale, void* stream) {

@@ -158,7 +158,9 @@ class DiT(nn.Module):
         # Opt-in: run the two classifier-free-guidance halves of `forward_with_cfg` as two concurrent HIP streams
         # (_forward16); identical kernels and results per row.  PRIMX_CFG_STREAMS=1 turns it on for every model.
         self.cfg_streams = os.environ.get("PRIMX_CFG_STREAMS") == "1"
-        self.weight_prefetch = os.environ.get("PRIMX_WPREFETCH", "1") != "0"   # LayerNorm launches carry the next GEMMs' weight prefetch (_forward16)
+        # weight prefetch of the loader-wave GEMMs (_forward16): 2 = carried by the GEMM launches one or two ahead, 1 = carried by the
+        # LayerNorm launches, 0 = off (PRIMX_WPREFETCH)
+        self.weight_prefetch = int(os.environ.get("PRIMX_WPREFETCH", "2"))
         self._side: Dict = {}
         self._t_plan: Optional[Dict] = None   # plan_timesteps(): the coming calls' timesteps and their modulation table
 
@@ -596,13 +598,20 @@ class DiT(nn.Module):
         # 128 x 144 GEMMs run 2 - 4 us longer with cold weights than with cache-resident ones (rocprofv3, tools/gpu/r3_touch.sh).
         # Every LayerNorm launch - a short kernel that reads the residual stream from the Infinity Cache - carries the prefetch
         # of the weights of the loader-wave GEMMs that follow it (ops.prefetch_hint): no launch, no event, no stream of its own.
-        wpf = self.weight_prefetch
+        # Round 3, later: the GEMM launches carry it instead (`weight_prefetch` = 2, ops._carrying): the compute waves of a
+        # loader-wave kernel touch the lines of a LATER GEMM's weights in front of their k-loop - to_q carries cproj's weights, cproj
+        # proj's, fc1 fc2's, fc2 the next block's to_q - and the LayerNorm launches are back to their own bytes.
+        wpf = int(self.weight_prefetch)
         collapse = bool(self.collapse_null_cross_attention) and null_half
+        blocks = pk["blocks"]
 
         def warm(*wts):
-            if wpf:
+            if wpf == 1:
                 for wt in wts:
                     ops.prefetch_hint(wt)
+
+        def carry(wt):
+            return wt if wpf == 2 else None
 
         def block(i, w, b0, b1, hook=None):
             """DiTBlock i on batch entries [b0, b1) (dit_crossattn.py:51-58): 11 launches on the current stream."""
@@ -616,7 +625,8 @@ class DiT(nn.Module):
             ops.layernorm_modulate(hh, ch[0], ch[1], N, xh, self.LN_EPS)
             bc = min(b1, B) if collapse else b1          # batch entries [b0, bc) attend; [bc, b1) are unconditional rows
             if bc > b0:
-                ops.linear_heads(xh[:(bc - b0) * N], w["w_q"], w["b_q"], N, H, dh, [HEADS_ROWS], [Qc[b0:bc]], nq_pad, scale0=scale)
+                ops.linear_heads(xh[:(bc - b0) * N], w["w_q"], w["b_q"], N, H, dh, [HEADS_ROWS], [Qc[b0:bc]], nq_pad, scale0=scale,
+                                 carry=carry(w["w_cproj"]))
                 ops.attention(Qc[b0:bc], Kc_blk[i][b0:bc], Vc_blk[i][b0:bc], N, L, dh, scale, out=ah[:bc - b0])
             if bc < b1:
                 # V^T layout [b, h, DP, n_pad] (key 0 sits at position 0 of its quad-permuted group): the value row of every head
@@ -624,7 +634,7 @@ class DiT(nn.Module):
                 ah[max(bc, b0) - b0:].copy_(vrow.expand(-1, N, -1))
             if hook is not None:
                 hook()
-            ops.linear_gate_residual(ah.view(Th, D), w["w_cproj"], w["b_cproj"], ch[2], hh, N)
+            ops.linear_gate_residual(ah.view(Th, D), w["w_cproj"], w["b_cproj"], ch[2], hh, N, carry=carry(w["w_proj"]))
             # ---- self-attention over the primitive tokens (dit_crossattn.py:56, attention.py:48-59)
             warm(w["w_proj"])
             ops.layernorm_modulate(hh, ch[3], ch[4], N, xh, self.LN_EPS)
@@ -635,8 +645,9 @@ class DiT(nn.Module):
             # ---- MLP (dit_crossattn.py:57, models/utils.py:94-101)
             warm(w["w_fc2"])
             ops.layernorm_modulate(hh, ch[6], ch[7], N, xh, self.LN_EPS)
-            ops.linear(xh, w["w_fc1"], w["b_fc1"], out=hid[r0:r1], act=ACT_GELU_TANH)
-            ops.linear_gate_residual(hid[r0:r1], w["w_fc2"], w["b_fc2"], ch[8], hh, N)
+            ops.linear(xh, w["w_fc1"], w["b_fc1"], out=hid[r0:r1], act=ACT_GELU_TANH, carry=carry(w["w_fc2"]))
+            ops.linear_gate_residual(hid[r0:r1], w["w_fc2"], w["b_fc2"], ch[8], hh, N,
+                                     carry=carry(blocks[i + 1]["w_q"]) if i + 1 < len(blocks) else None)
 
         if self.cfg_streams and null_half and self.depth and ops.PROFILE is None:
             # Two HIP streams, one per CFG half (the conditional and the unconditional rows are independent chains of

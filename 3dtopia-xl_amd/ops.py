@@ -210,37 +210,54 @@ def prefetch(t: torch.Tensor, stream: "torch.cuda.Stream") -> None:
 
 
 # ----------------------------------------------------------------------------- GEMMs
+def _carrying(carry: Optional[torch.Tensor], launch):
+    """Run `launch` (one GEMM entry point) with `carry`'s bytes registered as the weight prefetch that GEMM carries
+    (csrc/gemm.hip primx_prefetch_hint_gemm: consumed or dropped by exactly that launch)."""
+    if carry is None:
+        return launch()
+    lib = _lib.load()
+    if not hasattr(lib, "primx_prefetch_hint_gemm"):       # (A/B builds of an older ABI)
+        return launch()
+    check(lib.primx_prefetch_hint_gemm(_dev(carry, "carry"), carry.numel() * carry.element_size()), "primx_prefetch_hint_gemm")
+    try:
+        return launch()
+    except Exception:
+        lib.primx_prefetch_hint_gemm(None, 0)              # a launch that did not happen must not leave the range pending
+        raise
+
+
 def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
-           act: int = ACT_NONE, out_scale: float = 1.0) -> torch.Tensor:
+           act: int = ACT_NONE, out_scale: float = 1.0, carry: Optional[torch.Tensor] = None) -> torch.Tensor:
     M, K = A.shape
     N = W.shape[0]
     if W.shape[1] != K or W.dtype != A.dtype:
         raise RuntimeError("linear: operand mismatch")
     if out is None:
         out = torch.empty(M, N, dtype=A.dtype, device=A.device)
-    _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear(
+    _carrying(carry, lambda: _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear(
         _dev(A, "A"), _dev(W, "W"), _dev(bias, "bias", A.dtype) if bias is not None else None,
-        _dev(out, "out", A.dtype), M, N, K, dtype_code(A.dtype), act, out_scale, _stream()), "primx_linear"))
+        _dev(out, "out", A.dtype), M, N, K, dtype_code(A.dtype), act, out_scale, _stream()), "primx_linear")))
     return out
 
 
 def linear_gate_residual(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], gate: torch.Tensor,
-                         x: torch.Tensor, rows_per_batch: int) -> torch.Tensor:
-    """x[M, N] (fp32, in place) += cast16(gate[b] * cast16(A W^T + bias))."""
+                         x: torch.Tensor, rows_per_batch: int, carry: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x[M, N] (fp32, in place) += cast16(gate[b] * cast16(A W^T + bias)).  `carry`: see _carrying."""
     M, K = A.shape
     N = W.shape[0]
     if gate.stride(-1) != 1 or gate.dtype != A.dtype or not gate.is_cuda:
         raise RuntimeError("gate must be a last-dim-contiguous 16-bit device view")
-    _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_gate_residual(
+    _carrying(carry, lambda: _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_gate_residual(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None,
         gate.data_ptr(), gate.stride(0), _dev(x, "x", torch.float32), M, N, K, rows_per_batch,
-        dtype_code(A.dtype), _stream()), "primx_linear_gate_residual"))
+        dtype_code(A.dtype), _stream()), "primx_linear_gate_residual")))
     return x
 
 
 def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], rows_per_batch: int, heads: int,
                  dh: int, kinds: Sequence[int], dsts: Sequence[torch.Tensor], n_pad: int,
-                 scale0: float = 1.0, n_rep: int = 1, rep_batches: int = 0, real_rows: Optional[int] = None) -> None:
+                 scale0: float = 1.0, n_rep: int = 1, rep_batches: int = 0, real_rows: Optional[int] = None,
+                 carry: Optional[torch.Tensor] = None) -> None:
     """n_rep > 1: the column groups repeat; repetition r fills batch entries [r*rep_batches, (r+1)*rep_batches) of dsts.
     `real_rows`: rows of A that are not zero padding (the conditioning tokens are padded 1370 -> 1536 per batch entry) -
     only the per-kernel FLOP credit of bench.py's roofline leg uses it; the launch covers all M rows."""
@@ -249,11 +266,11 @@ def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     n_seg = len(kinds)
     kind_arr = (C.c_int * n_seg)(*kinds)
     dst_arr = (C.c_void_p * n_seg)(*[_dev(d, "dst", A.dtype) for d in dsts])
-    _timed(f"None {M}x{N}x{K}", 2.0 * (real_rows if real_rows is not None else M) * N * K, lambda: check(_lib.load().primx_linear_heads(
+    _carrying(carry, lambda: _timed(f"None {M}x{N}x{K}", 2.0 * (real_rows if real_rows is not None else M) * N * K, lambda: check(_lib.load().primx_linear_heads(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None, M, N, K,
         rows_per_batch, heads, dh, n_seg, kind_arr, dst_arr, n_rep, rep_batches, n_pad, scale0, dtype_code(A.dtype),
         _stream()),
-        "primx_linear_heads"))
+        "primx_linear_heads")))
 
 
 # ----------------------------------------------------------------------------- attention

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 19
+#define PRIMX_ABI_VERSION 20
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -103,6 +103,13 @@ int primx_prefetch(const void* ptr, int64_t bytes, void* stream);
  * (+0.1 ms per DDIM step measured); riding on the LayerNorm that precedes every GEMM group costs nothing on the host.
  * (NULL, 0) drops the pending ranges: the ranges must still be allocated when the LayerNorm launch that carries them runs. */
 int primx_prefetch_hint(const void* ptr, int64_t bytes);
+/* The same, carried by a GEMM: the next primx_linear / primx_linear_residual / primx_linear_gate_residual / primx_linear_heads
+ * call on this thread consumes the range (one pending range per host thread; launches that take a kernel without loader waves
+ * drop it).  The compute waves of the loader-wave kernels never use their vector-memory queue inside the k-loop, so each of them
+ * requests one word per 128-byte line of the range in front of the loop (at most 1024 lines per workgroup: 33.5 MB at 256
+ * workgroups, longer ranges are cut) and the lines travel HBM -> Infinity Cache while the loop runs from L2.  Used for the weights
+ * of the GEMM one or two launches ahead; results are unaffected.  (NULL, 0) drops a pending range.  ABI 20. */
+int primx_prefetch_hint_gemm(const void* ptr, int64_t bytes);
 
 /* out = cast16( silu(in) ) elementwise.  The SiLU in front of every adaLN Linear
  * (models/dit_crossattn.py:40-43,69-72) producing the 16-bit GEMM operand. */

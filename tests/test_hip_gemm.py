@@ -288,3 +288,52 @@ def test_two_pass_big_tile_edges(ops, dtype, M, K):
     out = torch.full((M + 1, N), 7.0, dtype=dtype, device=DEV)
     ops.linear(A.to(DEV), W.to(DEV), b.to(DEV), out=out[:M])
     assert float(out[M].float().min()) == 7.0 and float(out[M].float().max()) == 7.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gemm_carried_prefetch_changes_nothing(ops, dtype):
+    """primx_prefetch_hint_gemm (`carry=`): the compute waves of the loader-wave kernels touch the lines of another tensor in
+    front of their k-loop.  Results are bit-identical with and without it on every carrying kernel (128 x 144 loader-wave
+    Linear / gate-residual / heads, two-pass 256 x 288), a range longer than the launch covers is cut, a range of a few bytes
+    works, kernels without loader waves drop the hint, and a pending hint does not survive the launch that followed it."""
+    from topia_xl_amd import _lib
+    lib = _lib.load()
+    T, D, H, dh = 4096, 1152, 16, 72
+    A, W, b, _ = _mk(51, T, D, D, dtype)
+    Ad, Wd, bd = A.to(DEV), W.to(DEV), b.to(DEV)
+    other = torch.randn(3 * 1024 * 1024 + 5, device=DEV)                         # 12.6 MB, odd length
+    huge = torch.empty(48 * 1024 * 1024, dtype=torch.float16, device=DEV)        # 100 MB > the 33.5 MB a 256-workgroup launch covers
+    tiny = torch.zeros(3, dtype=dtype, device=DEV)
+    # Linear on the 128 x 144 loader-wave kernel
+    base = ops.linear(Ad, Wd, bd)
+    for c in (other, huge, tiny):
+        assert torch.equal(ops.linear(Ad, Wd, bd, carry=c), base)
+    # gate-residual
+    gate = synth.tensor(51, "gate", (2, D), 0.5).to(dtype).to(DEV)
+    x0 = synth.tensor(51, "x", (T, D)).to(DEV)
+    xa, xb = x0.clone(), x0.clone()
+    ops.linear_gate_residual(Ad, Wd, bd, gate, xa, 2048)
+    ops.linear_gate_residual(Ad, Wd, bd, gate, xb, 2048, carry=other)
+    assert torch.equal(xa, xb)
+    # token-major heads (to_q)
+    qa = ops.alloc_heads(2, H, 2048, dh, _lib.HEADS_ROWS, dtype, DEV, 256, role="q")
+    qb = qa.clone()
+    ops.linear_heads(Ad, Wd, bd, 2048, H, dh, [_lib.HEADS_ROWS], [qa], qa.shape[2])
+    ops.linear_heads(Ad, Wd, bd, 2048, H, dh, [_lib.HEADS_ROWS], [qb], qb.shape[2], carry=other)
+    assert torch.equal(qa, qb)
+    # two-pass 256 x 288 (fc1's shape) and a kernel without loader waves (N = 136: the hint is dropped, nothing else happens)
+    W4 = synth.tensor(51, "W4", (4 * D, D), D ** -0.5).to(dtype).to(DEV)
+    assert torch.equal(ops.linear(Ad, W4, None, act=1, carry=other), ops.linear(Ad, W4, None, act=1))
+    assert torch.equal(ops.linear(Ad, Wd[:136].contiguous(), bd[:136], carry=other), ops.linear(Ad, Wd[:136].contiguous(), bd[:136]))
+    # the entry point itself: bad arguments are errors, (NULL, 0) drops
+    assert lib.primx_prefetch_hint_gemm(None, 5) != 0
+    assert lib.primx_prefetch_hint_gemm(other.data_ptr(), other.numel() * 4) == 0
+    assert lib.primx_prefetch_hint_gemm(None, 0) == 0
+    # freed memory must not be touched by a later launch: the hint is consumed by the launch that follows it
+    scratch = torch.empty(1 << 20, device=DEV)
+    assert lib.primx_prefetch_hint_gemm(scratch.data_ptr(), scratch.numel() * 4) == 0
+    ops.linear(Ad, Wd, bd)                                                       # consumes it
+    del scratch
+    torch.cuda.empty_cache()
+    assert torch.equal(ops.linear(Ad, Wd, bd), base)
+    torch.cuda.synchronize()
