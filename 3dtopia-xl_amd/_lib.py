@@ -42,6 +42,7 @@ SIGNATURES = {
     "primx_linear_gate_residual": [_p, _p, _p, _p, _l, _p, _i, _i, _i, _i, _i, _p],
     "primx_linear_heads": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _i, _i, _f, _i, _p],
     "primx_attention": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
+    "primx_attention_bcast": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _i, _i, _i, _p],
     "primx_pack_heads": [_p, _l, _l, _l, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "primx_cfg_combine": [_p, _p, _i, _l, _f, _p],
     "primx_diffusion_step": [_p, _p, _i, _l, _i, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
@@ -68,7 +69,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"primx_last_error": C.c_char_p, "primx_last_gemm_kernel": C.c_char_p}
 # an alternate build named by PRIMX_LIB (same-box A/B against an older library) may predate these additive entry points
-_OPTIONAL_IN_AB_BUILDS = {"primx_last_gemm_kernel", "primx_prefetch", "primx_prefetch_hint", "primx_prefetch_hint_gemm"}
+_OPTIONAL_IN_AB_BUILDS = {"primx_last_gemm_kernel", "primx_prefetch", "primx_prefetch_hint", "primx_prefetch_hint_gemm", "primx_attention_bcast"}
 _AB_ABI_VERSIONS = (18, 19)
 
 _lib: Optional[C.CDLL] = None

@@ -103,7 +103,9 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
                                                           const typename T16<DT>::S* __restrict__ Kp,
                                                           const typename T16<DT>::S* __restrict__ Vt,
                                                           typename T16<DT>::S* __restrict__ out, int H, int nq, int nq_pad,
-                                                          int nkv, int nkv_pad, int dh, float c /* scale * log2(e) */) {
+                                                          int nkv, int nkv_pad, int dh, float c /* scale * log2(e) */,
+                                                          const typename T16<DT>::S* __restrict__ Kb,
+                                                          const typename T16<DT>::S* __restrict__ Vb, int b_from, int nkv_pad_b) {
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
     using V4 = typename T16<DT>::V4;
@@ -128,8 +130,15 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.x;  // (batch, head) fastest: with B*H % 8 == 0 all query tiles of a head share an XCD's L2
     const int q0 = blockIdx.y * BQ;
-    const S* Kbase = Kp + (int64_t)bh * nkv_pad * KROW;
-    const S* Vbase = Vt + (int64_t)bh * DP * nkv_pad;
+    // Batch entries >= b_from attend to nkv COPIES OF ONE key / value row (primx_attention_bcast: the unconditional half of
+    // classifier-free guidance, whose conditioning tokens are one embedding expanded to the sequence length).  Their operands
+    // hold that sequence once - tile 0 = 64 copies, tile 1 = the ragged last tile (nkv % 64 keys, the rest masked like any
+    // pad rows) - in ONE entry shared by all of them; the walk over the nkv keys is unchanged, only the tile ADDRESS maps
+    // j -> (j is the ragged last tile ? 1 : 0).  Same tile contents, same arithmetic, 1/11 of the bytes and L2-resident.
+    const bool bcast = (bh / H) >= b_from;                                      // workgroup-uniform
+    const int kvp = bcast ? nkv_pad_b : nkv_pad;
+    const S* Kbase = bcast ? Kb + (int64_t)(bh % H) * kvp * KROW : Kp + (int64_t)bh * kvp * KROW;
+    const S* Vbase = bcast ? Vb + (int64_t)(bh % H) * DP * kvp : Vt + (int64_t)bh * DP * kvp;
 
     // zero the V^T rows >= DP of every stage once (the DMA never writes them; they only feed discarded output rows)
     if (VR > DP) {
@@ -184,15 +193,20 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     const int n_pc = grp ? NV : NK, per = (n_pc + HW - 1) / HW;
     const int run_first = min(rw * per, n_pc - 1);
     const int run_len = max(min(per, n_pc - rw * per), 1);
-    const int64_t piece_stride = grp ? (int64_t)8 * nkv_pad : 512;              // halves between consecutive pieces
+    const int64_t piece_stride = grp ? (int64_t)8 * kvp : 512;                  // halves between consecutive pieces
     const int tile_stride = grp ? BKV : KT;
     const S* role_base = grp ? Vbase : Kbase;
     const int v_lrow = lane >> 3, v_lc = lane & 7;
     // per-lane source offset inside a piece; for V^T it depends on the parity of the 8-row group (swizzle term 4*tv & 7)
-    const int lane_off0 = grp ? v_lrow * nkv_pad + ((v_lc ^ ((v_lrow >> 1) & 7)) * 8) : lane * 8;
-    const int lane_off1 = grp ? v_lrow * nkv_pad + ((v_lc ^ ((4 + (v_lrow >> 1)) & 7)) * 8) : lane * 8;
+    const int lane_off0 = grp ? v_lrow * kvp + ((v_lc ^ ((v_lrow >> 1) & 7)) * 8) : lane * 8;
+    const int lane_off1 = grp ? v_lrow * kvp + ((v_lc ^ ((4 + (v_lrow >> 1)) & 7)) * 8) : lane * 8;
+    const bool ragged = (nkv & (BKV - 1)) != 0;
+    auto tile_at = [&](int tile) {            // tile index inside this entry's operand buffers (uniform)
+        const int tl = min(tile, ntiles - 1);
+        return bcast ? ((ragged && tl == ntiles - 1) ? 1 : 0) : tl;
+    };
     auto issue_run = [&](int tile, int stage) {   // this wave's pieces of K(tile) (group 0) / V(tile) (group 1)
-        const S* tb = role_base + (int64_t)min(tile, ntiles - 1) * tile_stride;
+        const S* tb = role_base + (int64_t)tile_at(tile) * tile_stride;
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
             const int pc = run_first + min(i, run_len - 1);
@@ -210,7 +224,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     V8 stg[NSLOT];
     int pend_stage = -1;                                        // stage the registers' pair belongs to (wave-uniform)
     auto gload_run = [&](int tile) {
-        const S* tb = role_base + (int64_t)min(tile, ntiles - 1) * tile_stride;
+        const S* tb = role_base + (int64_t)tile_at(tile) * tile_stride;
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
             const int pc = run_first + min(i, run_len - 1);
@@ -735,12 +749,13 @@ static const int g_attn_prof_on = [] {
 
 template <int DT, int KSTEPS, int DTILES, int KMASK>
 void launch_attn(const void* Qp, const void* Kp, const void* Vt, void* out, int B, int H, int nq, int nq_pad, int nkv,
-                 int nkv_pad, int dh, float c, hipStream_t st) {
+                 int nkv_pad, int dh, float c, const void* Kb, const void* Vb, int b_from, int nkv_pad_b, hipStream_t st) {
     using S = typename T16<DT>::S;
     dim3 grid(B * H, (nq_pad + BQ - 1) / BQ);
 #define PRIMX_ATTN_LAUNCH(P)                                                                                         \
     hipLaunchKernelGGL((attn_kernel<DT, KSTEPS, DTILES, KMASK, P>), grid, dim3(64 * NW), 0, st, (const S*)Qp,         \
-                       (const S*)Kp, (const S*)Vt, (S*)out, H, nq, nq_pad, nkv, nkv_pad, dh, c)
+                       (const S*)Kp, (const S*)Vt, (S*)out, H, nq, nq_pad, nkv, nkv_pad, dh, c, (const S*)Kb, (const S*)Vb,  \
+                       b_from, nkv_pad_b)
     if constexpr (DT == PRIMX_F16 && KSTEPS == 5) {
         if (g_attn_prof_on) {
             unsigned long long z[8] = {0}, r[8];
@@ -764,8 +779,23 @@ void launch_attn(const void* Qp, const void* Kp, const void* Vt, void* out, int 
 
 extern "C" int primx_attention(const void* Qp, const void* Kp, const void* Vt, void* out, int B, int H, int nq,
                                int nq_pad, int nkv, int nkv_pad, int dh, float scale, int dtype, void* stream) {
-    PRIMX_REQUIRE(Qp && Kp && Vt && out, "primx_attention: null pointer");
+    return primx_attention_bcast(Qp, Kp, Vt, out, B, H, nq, nq_pad, nkv, nkv_pad, dh, scale, nullptr, nullptr, B, 0, dtype, stream);
+}
+
+extern "C" int primx_attention_bcast(const void* Qp, const void* Kp, const void* Vt, void* out, int B, int H, int nq, int nq_pad,
+                                     int nkv, int nkv_pad, int dh, float scale, const void* Kb, const void* Vb, int b_from,
+                                     int nkv_pad_b, int dtype, void* stream) {
+    PRIMX_REQUIRE(Qp && out && ((Kp && Vt) || b_from == 0), "primx_attention: null pointer");
     PRIMX_REQUIRE(B > 0 && H > 0 && nq > 0 && nkv > 0, "primx_attention: empty problem");
+    PRIMX_REQUIRE(b_from >= 0 && b_from <= B, "primx_attention_bcast: b_from must lie in [0, B] (b_from=%d B=%d)", b_from, B);
+    if (b_from < B) {
+        const int need = ((nkv % 64) != 0 && nkv > 64) ? 128 : 64;
+        PRIMX_REQUIRE(Kb && Vb, "primx_attention_bcast: null broadcast operands");
+        PRIMX_REQUIRE(nkv >= 64 && nkv_pad_b >= need && nkv_pad_b % 64 == 0,
+                      "primx_attention_bcast: needs nkv >= 64 and nkv_pad_b a multiple of 64 >= %d (nkv=%d nkv_pad_b=%d)", need, nkv, nkv_pad_b);
+        PRIMX_REQUIRE(!(dh == 32 && nq <= 64 && nkv <= 64 && nq_pad == 64 && nkv_pad == 64),
+                      "primx_attention_bcast: the one-wave 64-token kernel has no broadcast entries");
+    }
     const bool small64 = dh == 32 && nq <= 64 && nkv <= 64 && nq_pad == 64 && nkv_pad == 64;   // one wave per problem (attn64_kernel)
     if (small64) {
         const float c64 = scale * 1.4426950408889634f;
@@ -778,14 +808,14 @@ extern "C" int primx_attention(const void* Qp, const void* Kp, const void* Vt, v
         return PRIMX_OK;
     }
     PRIMX_REQUIRE(nq_pad >= nq && nq_pad % QPAD == 0, "primx_attention: nq_pad must be a multiple of 128 and >= nq (or 64 for the 64-token, dh = 32 kernel)");
-    PRIMX_REQUIRE(nkv_pad >= nkv && nkv_pad % BKV == 0, "primx_attention: nkv_pad must be a multiple of 64 and >= nkv");
+    PRIMX_REQUIRE(b_from == 0 || (nkv_pad >= nkv && nkv_pad % BKV == 0), "primx_attention: nkv_pad must be a multiple of 64 and >= nkv");
     PRIMX_REQUIRE(nq_pad / QPAD <= 65535, "primx_attention: too many query tiles");
     const float c = scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
     PRIMX_DISPATCH_16(dtype, "primx_attention", {
-        if (dh == 72) launch_attn<DT, 5, 3, 0>(Qp, Kp, Vt, out, B, H, nq, nq_pad, nkv, nkv_pad, dh, c, st);
-        else if (dh == 64) launch_attn<DT, 4, 2, 1>(Qp, Kp, Vt, out, B, H, nq, nq_pad, nkv, nkv_pad, dh, c, st);
-        else if (dh == 32) launch_attn<DT, 2, 1, 1>(Qp, Kp, Vt, out, B, H, nq, nq_pad, nkv, nkv_pad, dh, c, st);
+        if (dh == 72) launch_attn<DT, 5, 3, 0>(Qp, Kp, Vt, out, B, H, nq, nq_pad, nkv, nkv_pad, dh, c, Kb, Vb, b_from, nkv_pad_b, st);
+        else if (dh == 64) launch_attn<DT, 4, 2, 1>(Qp, Kp, Vt, out, B, H, nq, nq_pad, nkv, nkv_pad, dh, c, Kb, Vb, b_from, nkv_pad_b, st);
+        else if (dh == 32) launch_attn<DT, 2, 1, 1>(Qp, Kp, Vt, out, B, H, nq, nq_pad, nkv, nkv_pad, dh, c, Kb, Vb, b_from, nkv_pad_b, st);
         else {
             primx_set_error("primx_attention: unsupported head dim %d (supported: 32, 64, 72)", dh);
             return PRIMX_EINVAL;

@@ -158,6 +158,11 @@ class DiT(nn.Module):
         # Opt-in: run the two classifier-free-guidance halves of `forward_with_cfg` as two concurrent HIP streams
         # (_forward16); identical kernels and results per row.  PRIMX_CFG_STREAMS=1 turns it on for every model.
         self.cfg_streams = os.environ.get("PRIMX_CFG_STREAMS") == "1"
+        # forward_with_cfg: the unconditional half's conditioning is ONE embedding expanded to L tokens (dit_crossattn.py:207), so
+        # its L rows of to_k / to_v are identical: project 64 + L % 64 of them once per forward and let the cross-attention kernel
+        # address them as the L-key sequence (ops.attention(bcast=)) - same tiles, same arithmetic.  PRIMX_NULL_KV_DEDUP=0: the
+        # expanded rows are projected, stored and read like the conditional ones.
+        self.dedup_null_kv = os.environ.get("PRIMX_NULL_KV_DEDUP", "1") != "0"
         # weight prefetch of the loader-wave GEMMs (_forward16): 2 = carried by the GEMM launches one or two ahead, 1 = carried by the
         # LayerNorm launches, 0 = off (PRIMX_WPREFETCH)
         self.weight_prefetch = int(os.environ.get("PRIMX_WPREFETCH", "2"))
@@ -475,7 +480,11 @@ class DiT(nn.Module):
             null16 = ops.cast16(self.null_cond_embedding.detach().float().contiguous().to(y.device), dt)
             buf[B:, :L] = null16
         st = {"y": y, "ver": ver, "dt": dt, "null_half": null_half, "Lk": Lk, "y16": buf.view(Be * Lk, Dc),
-              "kv_valid": False}
+              "kv_valid": False, "null16": None}
+        if null_half and L >= 64:
+            # the broadcast operand entry of the unconditional half: ops.bcast_keys(L) copies of the null row (one full 64-key tile
+            # + the ragged last tile of the L-key sequence)
+            st["null16"] = null16.reshape(1, Dc).expand(ops.bcast_keys(L), Dc).contiguous()
         self._cond = st
         return st
 
@@ -578,13 +587,25 @@ class DiT(nn.Module):
         Qc = self._heads("Qc", Be, N, HEADS_ROWS, dt, dev, ops.BQ)
         # cross-attention K / V of every block in ONE projection GEMM (N = depth * 2D): [depth*Be, H, L_pad, DP]
         kv_pad = 256 if Lk != L else ops.BKV
-        Kc = self._heads("Kc", self.depth * Be, L, HEADS_KROWS, dt, dev, kv_pad)
-        Vc = self._heads("Vc", self.depth * Be, L, HEADS_VT, dt, dev, kv_pad)
-        Kc_blk = Kc.view(self.depth, Be, *Kc.shape[1:])
-        Vc_blk = Vc.view(self.depth, Be, *Vc.shape[1:])
+        # (dedup: the operands hold the B conditional entries only; the unconditional ones share the broadcast entry Kn / Vn)
+        dedup = bool(self.dedup_null_kv) and null_half and cs["null16"] is not None and self.depth > 0
+        Bkv = B if dedup else Be
+        Kc = self._heads("Kc", self.depth * Bkv, L, HEADS_KROWS, dt, dev, kv_pad)
+        Vc = self._heads("Vc", self.depth * Bkv, L, HEADS_VT, dt, dev, kv_pad)
+        Kc_blk = Kc.view(self.depth, Bkv, *Kc.shape[1:])
+        Vc_blk = Vc.view(self.depth, Bkv, *Vc.shape[1:])
+        Kn_blk = Vn_blk = None
+        if dedup:
+            Ln = ops.bcast_keys(L)
+            Kn = self._heads("Kn", self.depth, Ln, HEADS_KROWS, dt, dev, ops.BKV)
+            Vn = self._heads("Vn", self.depth, Ln, HEADS_VT, dt, dev, ops.BKV)
+            Kn_blk, Vn_blk = Kn.view(self.depth, 1, *Kn.shape[1:]), Vn.view(self.depth, 1, *Vn.shape[1:])
         if self.depth and not (self.reuse_cond_kv and cs["kv_valid"] and cs.get("kv_id") == (Kc.data_ptr(), Vc.data_ptr())):
-            ops.linear_heads(y16, pk["w_kv_all"], pk["b_kv_all"], Lk, H, dh, [HEADS_KROWS, HEADS_VT], [Kc, Vc],
-                             Kc.shape[2], n_rep=self.depth, rep_batches=Be, real_rows=Be * L)
+            ops.linear_heads(y16[:Bkv * Lk], pk["w_kv_all"], pk["b_kv_all"], Lk, H, dh, [HEADS_KROWS, HEADS_VT], [Kc, Vc],
+                             Kc.shape[2], n_rep=self.depth, rep_batches=Bkv, real_rows=Bkv * L)
+            if dedup:
+                ops.linear_heads(cs["null16"], pk["w_kv_all"], pk["b_kv_all"], Ln, H, dh, [HEADS_KROWS, HEADS_VT], [Kn, Vn],
+                                 Kn.shape[2], n_rep=self.depth, rep_batches=1)
             cs["kv_valid"], cs["kv_id"] = True, (Kc.data_ptr(), Vc.data_ptr())
         Qs = self._heads("Qs", Be, N, HEADS_ROWS, dt, dev, ops.BQ)
         Ks = self._heads("Ks", Be, N, HEADS_KROWS, dt, dev, ops.BQ)
@@ -627,10 +648,17 @@ class DiT(nn.Module):
             if bc > b0:
                 ops.linear_heads(xh[:(bc - b0) * N], w["w_q"], w["b_q"], N, H, dh, [HEADS_ROWS], [Qc[b0:bc]], nq_pad, scale0=scale,
                                  carry=carry(w["w_cproj"]))
-                ops.attention(Qc[b0:bc], Kc_blk[i][b0:bc], Vc_blk[i][b0:bc], N, L, dh, scale, out=ah[:bc - b0])
+                if dedup and bc > B:                     # entries [max(b0, B), bc) take the broadcast key / value entry
+                    kc = Kc_blk[i][b0:B] if b0 < B else None
+                    ops.attention(Qc[b0:bc], kc, Vc_blk[i][b0:B] if b0 < B else None, N, L, dh, scale, out=ah[:bc - b0],
+                                  bcast=(Kn_blk[i], Vn_blk[i]))
+                else:
+                    ops.attention(Qc[b0:bc], Kc_blk[i][b0:bc], Vc_blk[i][b0:bc], N, L, dh, scale, out=ah[:bc - b0])
             if bc < b1:
                 # V^T layout [b, h, DP, n_pad] (key 0 sits at position 0 of its quad-permuted group): the value row of every head
-                vrow = Vc_blk[i][max(bc, b0):b1, :, :dh, 0].reshape(b1 - max(bc, b0), 1, D)
+                nb = b1 - max(bc, b0)
+                vsrc = Vn_blk[i].expand(nb, -1, -1, -1) if dedup else Vc_blk[i][max(bc, b0):b1]
+                vrow = vsrc[:, :, :dh, 0].reshape(nb, 1, D)
                 ah[max(bc, b0) - b0:].copy_(vrow.expand(-1, N, -1))
             if hook is not None:
                 hook()

@@ -312,9 +312,35 @@ def alloc_heads(B: int, H: int, n: int, dh: int, kind: int, dtype: torch.dtype, 
     return buf
 
 
-def attention(Qp: torch.Tensor, Kp: torch.Tensor, Vt: torch.Tensor, nq: int, nkv: int, dh: int, scale: float,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def bcast_keys(nkv: int) -> int:
+    """Keys a broadcast operand entry of attention(..., bcast=) holds for a sequence of nkv identical keys: one full 64-key
+    tile and, when nkv % 64 != 0, the ragged last tile behind it."""
+    return 64 + (nkv % 64 if nkv > 64 else 0)
+
+
+def attention(Qp: torch.Tensor, Kp: Optional[torch.Tensor], Vt: Optional[torch.Tensor], nq: int, nkv: int, dh: int, scale: float,
+              out: Optional[torch.Tensor] = None, bcast: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+    """bcast = (Kb, Vb): the LAST B - Kp.shape[0] batch entries of Qp attend to nkv copies of one key / value row, held once in
+    the single operand entry Kb [1, H, n_pad_b, DP + 8] / Vb [1, H, DP, n_pad_b] (bcast_keys(nkv) keys: csrc/attention.hip
+    primx_attention_bcast); Kp / Vt hold the leading entries (None when every entry is a broadcast one)."""
     B, H, nq_pad, DP = Qp.shape
+    if bcast is not None:
+        Kb, Vb = bcast
+        b_from = 0 if Kp is None else Kp.shape[0]
+        nkv_pad_b = Kb.shape[2]
+        if Kb.shape != (1, H, nkv_pad_b, DP + 8) or Vb.shape != (1, H, DP, nkv_pad_b) or not 0 <= b_from < B:
+            raise RuntimeError("attention: broadcast operand layout mismatch")
+        if Kp is not None and (Vt is None or Vt.shape != (b_from, H, DP, Kp.shape[2]) or Kp.shape[1:] != (H, Kp.shape[2], DP + 8)):
+            raise RuntimeError("attention: operand layout mismatch")
+        nkv_pad = Kp.shape[2] if Kp is not None else nkv_pad_b
+        if out is None:
+            out = torch.empty(B, nq, H * dh, dtype=Qp.dtype, device=Qp.device)
+        name = f"attn_kernel<{dtype_code(Qp.dtype)}, {padded_head_dim(dh) // 16}, {(dh + 31) // 32}, {int(padded_head_dim(dh) == dh)}, 0>"
+        _timed(f"{name} {B * H}x{nq}x{nkv}x{dh}", 4.0 * B * H * nq * nkv * dh, lambda: check(_lib.load().primx_attention_bcast(
+            _dev(Qp, "Qp"), _dev(Kp, "Kp", Qp.dtype) if Kp is not None else None, _dev(Vt, "Vt", Qp.dtype) if Kp is not None else None,
+            _dev(out, "out", Qp.dtype), B, H, nq, nq_pad, nkv, nkv_pad, dh, scale, _dev(Kb, "Kb", Qp.dtype), _dev(Vb, "Vb", Qp.dtype),
+            b_from, nkv_pad_b, dtype_code(Qp.dtype), _stream()), "primx_attention_bcast"))
+        return out
     nkv_pad = Kp.shape[2]
     if Vt.shape != (B, H, DP, nkv_pad) or Kp.shape != (B, H, nkv_pad, DP + 8):
         raise RuntimeError("attention: operand layout mismatch")

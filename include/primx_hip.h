@@ -180,6 +180,19 @@ int primx_linear_heads(const void* A, const void* W, const void* bias, int M, in
  * Replaces xformers.ops.memory_efficient_attention(q, k, v) (attention.py:54,109). */
 int primx_attention(const void* Qp, const void* Kp, const void* Vt, void* out, int B, int H, int nq, int nq_pad,
                     int nkv, int nkv_pad, int dh, float scale, int dtype, void* stream);
+/* primx_attention in which the batch entries b >= b_from attend to nkv COPIES OF ONE key / value row - the unconditional half of
+ * `DiT.forward_with_cfg`, whose conditioning is `null_cond_embedding.expand_as(y)` (models/dit_crossattn.py:204-209): L identical
+ * tokens, hence L identical rows of to_k(y_null) / to_v(y_null) (models/attention.py:106-107).  Those entries share ONE operand
+ * entry Kb [1, H, nkv_pad_b, DP + 8] / Vb [1, H, DP, nkv_pad_b] in the layouts of Kp / Vt that holds the sequence once: keys
+ * [0, 64) = the row, and - when nkv % 64 != 0 - keys [64, 64 + nkv % 64) = the row again with the pad keys behind them masked
+ * like any pad keys (primx_linear_heads on 64 + nkv % 64 identical rows writes exactly this).  The kernel walks all nkv keys
+ * as always and only maps the tile address (ragged last tile -> tile 1, every other tile -> tile 0): the same tile contents
+ * and arithmetic as with the expanded operands, without projecting, storing and re-reading nkv copies.  Kp / Vt hold the
+ * entries [0, b_from) (may be NULL when b_from == 0); b_from == B is primx_attention.  Needs nkv >= 64; not available on the
+ * one-wave 64-token kernel.  ABI 20. */
+int primx_attention_bcast(const void* Qp, const void* Kp, const void* Vt, void* out, int B, int H, int nq, int nq_pad, int nkv,
+                          int nkv_pad, int dh, float scale, const void* Kb, const void* Vb, int b_from, int nkv_pad_b, int dtype,
+                          void* stream);
 
 /* Gather a [B, M, H, dh] tensor with arbitrary element strides (the xFormers BMHK operand, e.g.
  * a view into the fused qkv buffer) into an attention operand layout. */

@@ -137,3 +137,37 @@ def test_small_problem_kernel(ops, dtype, nq, nkv):
     qd, kd, vd = (t.double().permute(0, 2, 1, 3) for t in (q, k, v))
     ref = (torch.softmax(qd @ kd.transpose(-1, -2) * dh ** -0.5, -1) @ vd).permute(0, 2, 1, 3)
     assert rel_l2(got, ref) < TOL[dtype], rel_l2(got, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,b_from,Mq,Mk,H,dh", [(2, 1, 300, 1370, 4, 72), (3, 0, 256, 1370, 2, 72), (2, 1, 256, 256, 2, 72),
+                                                 (2, 1, 200, 64, 2, 72), (2, 1, 128, 200, 2, 64), (3, 2, 64, 129, 4, 32)])
+def test_broadcast_key_value_entries(ops, dtype, B, b_from, Mq, Mk, H, dh):
+    """primx_attention_bcast: the batch entries >= b_from attend to Mk copies of one key / value row, stored once (one full tile
+    + the ragged last tile).  BIT-IDENTICAL to primx_attention on the expanded operands (the kernel visits the same tile
+    contents in the same order) and right against float64; ragged (1370, 200, 129) and whole-tile (256, 64) key counts,
+    every entry a broadcast one (b_from = 0), the three head dims."""
+    from topia_xl_amd import _lib
+    q = synth.tensor(25, "q", (B, Mq, H, dh)).to(dtype)
+    k = synth.tensor(25, "k", (B, Mk, H, dh)).to(dtype)
+    v = synth.tensor(25, "v", (B, Mk, H, dh)).to(dtype)
+    krow, vrow = synth.tensor(25, "krow", (1, 1, H, dh)).to(dtype), synth.tensor(25, "vrow", (1, 1, H, dh)).to(dtype)
+    k[b_from:] = krow                                                          # the expanded form: Mk identical rows
+    v[b_from:] = vrow
+    ref = dit_ref.attention_core(q, k, v, dh ** -0.5)
+    Qp = ops.pack_heads(q.to(DEV), _lib.HEADS_ROWS, ops.BQ, "q")
+    full = ops.attention(Qp, ops.pack_heads(k.to(DEV), _lib.HEADS_KROWS, ops.BKV, "k"), ops.pack_heads(v.to(DEV), _lib.HEADS_VT, ops.BKV),
+                         Mq, Mk, dh, dh ** -0.5)
+    nb = ops.bcast_keys(Mk)
+    assert nb == 64 + (Mk % 64 if Mk > 64 else 0)
+    Kb = ops.pack_heads(krow.expand(1, nb, H, dh).contiguous().to(DEV), _lib.HEADS_KROWS, ops.BKV, "k")
+    Vb = ops.pack_heads(vrow.expand(1, nb, H, dh).contiguous().to(DEV), _lib.HEADS_VT, ops.BKV)
+    Kp = ops.pack_heads(k[:b_from].to(DEV), _lib.HEADS_KROWS, ops.BKV, "k") if b_from else None
+    Vt = ops.pack_heads(v[:b_from].to(DEV), _lib.HEADS_VT, ops.BKV) if b_from else None
+    got = ops.attention(Qp, Kp, Vt, Mq, Mk, dh, dh ** -0.5, bcast=(Kb, Vb))
+    assert torch.equal(got, full)
+    assert rel_l2(got.view(B, Mq, H, dh), ref) < TOL[dtype]
+    # identical keys: every broadcast entry's output rows are the value row itself (softmax weights 1 / Mk)
+    assert max_abs(got.view(B, Mq, H, dh)[b_from:], vrow.double().expand(B - b_from, Mq, H, dh)) < (2e-3 if dtype == torch.float16 else 1.6e-2)
+    with pytest.raises(RuntimeError):
+        ops.attention(Qp, Kp, Vt, Mq, Mk, dh, dh ** -0.5, bcast=(Kb[:, :, :32], Vb))          # operand layout mismatch

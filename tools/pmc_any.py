@@ -29,7 +29,7 @@ def main():
         k = short(meta[d][0])
         cyc = CYCLES.get(k)
         if k.startswith("gemm288q_dma_kernel<1, 2>"):
-            tag = k + (" 3072x64512x768" if meta[d][1] > 512 * 400 else " 4096x3456x1152")
+            tag = k + (" 1536x64512x768" if meta[d][1] > 512 * 400 else " 4096x3456x1152")
         elif cyc:
             tag = f"{k} {cyc[seen[k] % len(cyc)]}"
             seen[k] += 1

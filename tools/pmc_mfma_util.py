@@ -20,7 +20,7 @@ cfile, tfile, out, mode = sys.argv[1], sys.argv[2], sys.argv[3], (sys.argv[4] or
 from pmc_traffic import CYCLES, short   # the launch-order -> shape tables  # noqa: E402
 
 FLOPS = {"4096x1152x1152": 2 * 4096 * 1152 * 1152, "4096x1152x4608": 2 * 4096 * 1152 * 4608, "4096x4608x1152": 2 * 4096 * 4608 * 1152,
-         "4096x3456x1152": 2 * 4096 * 3456 * 1152, "3072x64512x768": 2 * 2740 * 64512 * 768,
+         "4096x3456x1152": 2 * 4096 * 3456 * 1152, "1536x64512x768": 2 * 1370 * 64512 * 768,
          "32x2048x2048x72": 4 * 32 * 2048 * 2048 * 72, "32x2048x1370x72": 4 * 32 * 2048 * 1370 * 72,
          "256->256 @4^3 x2048": 2 * 2048 * 64 * 256 * 27 * 256, "gn+256->32+sc @8^3 x2048": 2 * 2048 * 512 * 32 * 28 * 256,
          "256->32 @8^3 x2048": 2 * 2048 * 512 * 32 * 27 * 256}
@@ -30,7 +30,7 @@ def tag_of(kname, grid, seen):
     k = short(kname)
     cyc = CYCLES.get(k)
     if k.startswith("gemm288q_dma_kernel<1, 2>"):
-        return k + (" 3072x64512x768" if grid > 512 * 400 else " 4096x3456x1152")
+        return k + (" 1536x64512x768" if grid > 512 * 400 else " 4096x3456x1152")
     if cyc:
         t = f"{k} {cyc[seen[k] % len(cyc)]}"
         seen[k] += 1

@@ -40,7 +40,7 @@ def load(path, counter):
         k = short(r["Kernel_Name"])
         cyc = CYCLES.get(k)
         if k.startswith("gemm288q_dma_kernel<1, 2>"):   # qkv per block + ONE batched K/V projection per forward: split by grid
-            tag = k + (" 3072x64512x768" if int(r.get("Grid_Size", 0)) > 512 * 400 else " 4096x3456x1152")
+            tag = k + (" 1536x64512x768" if int(r.get("Grid_Size", 0)) > 512 * 400 else " 4096x3456x1152")
         elif cyc:
             tag = f"{k} {cyc[seen[k] % len(cyc)]}"
             seen[k] += 1
