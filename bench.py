@@ -373,7 +373,22 @@ def main() -> None:
                  "executed_tflops_per_step": ex / 1e12,
                  "note": "DiT.reuse_cond_kv=True: to_k(y) / to_v(y) of all blocks computed once per conditioning tensor "
                          "(models/attention.py:106-107 do not depend on t); identical samples (tests/test_hip_fullconfig.py); "
-                         "NOT the headline value - that one executes the reference's full algorithmic FLOPs"}
+                         "NOT the headline value - that one projects the conditioning tokens in every step"}
+
+    # The same K steps with the unconditional half's conditioning rows projected and read EXPANDED (DiT.dedup_null_kv = False): what
+    # the headline's de-duplication of `null_cond_embedding.expand_as(y)` saves, for the record.
+    expanded = None
+    if args.config == "ddim" and rank == 0 and world == 1 and getattr(model, "dedup_null_kv", False):
+        model.dedup_null_kv = False
+        run_steps(args.warmup)
+        el, _ = timed_repeats(run_steps, args.steps, max(1, args.repeats), 1, dist, dev)
+        model.dedup_null_kv = True
+        run_steps(1)
+        e = statistics.median(el)
+        expanded = {"ms_per_step": 1e3 * e / args.steps, "value": B * args.steps / e, "unit": "denoise-steps/s",
+                    "note": "DiT.dedup_null_kv=False (PRIMX_NULL_KV_DEDUP=0): the L identical conditioning rows of the unconditional "
+                            "half are projected by to_k / to_v, stored and read like the conditional ones; bit-identical attention "
+                            "results (tests/test_hip_attention.py::test_broadcast_key_value_entries)"}
 
     # ddim: the rest of the metric (SURVEY.md section 8d metric (2)), outside the headline's timed region: the VAE leg on
     # this GPU, and ONE whole sampling job - the 25-step DDIM loop (plan + 25 x forward_with_cfg + update) followed by the
@@ -452,6 +467,14 @@ def main() -> None:
             if args.reuse_cond_kv:   # report against the UNREDUCED count, and the executed one next to it
                 ex = flops_step - B * kv_projection_flops(L_COND) * (1.0 - 1.0 / 25.0)
                 res["executed_tflops_per_step"] = ex / 1e12
+            elif getattr(model, "dedup_null_kv", False) and L_COND >= 64:
+                # forward_with_cfg's unconditional half: L identical conditioning rows (null_cond_embedding.expand_as(y)) - 64 + L % 64
+                # of them are projected, the rates above stay against the UNREDUCED algorithmic count
+                ln = 64 + (L_COND % 64 if L_COND > 64 else 0)
+                res["executed_tflops_per_step"] = (flops_step - B * kv_projection_flops(L_COND) * (1.0 - ln / L_COND)) / 1e12
+                res["config"]["null_cond_kv"] = (f"the unconditional half's {L_COND} identical conditioning rows are projected once "
+                                                 f"({ln} rows) and addressed as the {L_COND}-key sequence by the attention kernel "
+                                                 "(bit-identical results); `with_expanded_null_kv` times the expanded form")
         elif args.config == "decode":
             res.update({
                 "metric": "VAE decode samples/sec (2048 primitives per sample: latent de-normalise + vae3d_dib decode + inverse normalisation)",
@@ -473,6 +496,8 @@ def main() -> None:
                 "ddim_ms_per_step": ms_step, "decode_ms": 1e3 * decode_s, "seconds_per_batch": total})
         if reuse:
             res["with_reuse_cond_kv"] = reuse
+        if expanded:
+            res["with_expanded_null_kv"] = expanded
         if prof:
             res["roofline"], res["kernels"] = kernel_report(prof, args.steps, traffic_file())
         if dleg:
