@@ -2042,7 +2042,7 @@ extern "C" int primx_prefetch_hint_gemm(const void* ptr, int64_t bytes) {
     }
     PRIMX_REQUIRE(ptr && bytes > 0, "primx_prefetch_hint_gemm: bad argument");
     g_gemm_pf_ptr = (const char*)ptr;
-    g_gemm_pf_lines = (bytes + 127) / 128;
+    g_gemm_pf_lines = bytes >= 4 ? (bytes - 4) / 128 + 1 : 0;   // one dword per line, every dword inside [ptr, ptr + bytes)
     return PRIMX_OK;
 }
 

@@ -334,15 +334,16 @@ extern "C" int primx_prefetch_hint(const void* ptr, int64_t bytes) {
         return PRIMX_OK;
     }
     PRIMX_REQUIRE(ptr && bytes > 0, "primx_prefetch_hint: bad argument");
-    if (!g_pf_hint.p0) { g_pf_hint.p0 = (const char*)ptr; g_pf_hint.lines0 = (bytes + 127) / 128; }
-    else if (!g_pf_hint.p1) { g_pf_hint.p1 = (const char*)ptr; g_pf_hint.lines1 = (bytes + 127) / 128; }
+    if (!g_pf_hint.p0) { g_pf_hint.p0 = (const char*)ptr; g_pf_hint.lines0 = bytes >= 4 ? (bytes - 4) / 128 + 1 : 0; }
+    else if (!g_pf_hint.p1) { g_pf_hint.p1 = (const char*)ptr; g_pf_hint.lines1 = bytes >= 4 ? (bytes - 4) / 128 + 1 : 0; }
     else { primx_set_error("primx_prefetch_hint: two hints are already pending"); return PRIMX_EINVAL; }
     return PRIMX_OK;
 }
 
 extern "C" int primx_prefetch(const void* ptr, int64_t bytes, void* stream) {
     PRIMX_REQUIRE(ptr && bytes > 0, "primx_prefetch: bad argument");
-    const int64_t lines = (bytes + 127) / 128;
+    const int64_t lines = bytes >= 4 ? (bytes - 4) / 128 + 1 : 0;   // one dword per line, every dword inside the range
+    if (lines == 0) return PRIMX_OK;
     hipLaunchKernelGGL(prefetch_lines_kernel, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const char*)ptr, lines);
     PRIMX_CHECK_LAUNCH("primx_prefetch");
     return PRIMX_OK;

@@ -213,7 +213,7 @@ def prefetch(t: torch.Tensor, stream: "torch.cuda.Stream") -> None:
 def _carrying(carry: Optional[torch.Tensor], launch):
     """Run `launch` (one GEMM entry point) with `carry`'s bytes registered as the weight prefetch that GEMM carries
     (csrc/gemm.hip primx_prefetch_hint_gemm: consumed or dropped by exactly that launch)."""
-    if carry is None:
+    if carry is None or not carry.is_contiguous() or not carry.is_cuda:
         return launch()
     lib = _lib.load()
     if not hasattr(lib, "primx_prefetch_hint_gemm"):       # (A/B builds of an older ABI)
