@@ -451,8 +451,8 @@ class DiT(nn.Module):
         the caller keeps passing the same tensor (same storage, shape, strides and in-place version; the cache holds a
         reference to `y`, so its storage cannot be recycled for another tensor behind our back).  This is a cast of an
         INPUT, not skipped arithmetic.  The step-invariant K / V projections themselves are reused only when
-        `self.reuse_cond_kv` is set (exact algebra; off by default so that a step executes
-        the reference's full algorithmic FLOPs)."""
+        `self.reuse_cond_kv` is set (exact algebra; off by default so that every step projects
+        its conditioning tokens, as the reference does)."""
         B, L, Dc = y.shape
         Be = 2 * B if null_half else B
         st = self._cond
