@@ -26,6 +26,7 @@
 // over channels-last [P, S^3, Cin] activations: k = tap * Cin + ci, row m = (p, voxel); out-of-volume taps
 // and any K tail read a 16-byte zero block instead of branching.
 #include <stdio.h>
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -175,12 +176,23 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // With whole tile rows per XCD (gm = 8) every XCD streams the WHOLE weight matrix through its L2: fc1 at T = 4096 fetched
 // 93 MB per launch for 20 MB of operands (PMC: A 9.4 + 8 x W 10.6); a 2 x 4 / 4 x 2 split replicates both operands a
 // little instead of one of them eightfold.  Host picks gm (launch144_dma); needs mt % gm == 0 and nt % (8 / gm) == 0.
-__device__ __forceinline__ void xcd_tile2d(int bid, int mt, int nt, int gm, int& mi, int& ni) {
+// Inside its bm x bn block an XCD takes the tiles in the order its 32 CUs should hold them TOGETHER: sub-blocks of sr x sc tiles
+// (sr x sc ~ 32, both ~ 6), m fastest inside a sub-block, sub-blocks down a column strip, strips left to right.  A round of
+// workgroups then streams sr + sc operand panels through the 4 MB L2 instead of 1 - 2 + bn with the row-major walk (fc1 at
+// T = 32768: 2 + 16 panels of 0.6 MB per round, i.e. the whole weight matrix from the Infinity Cache in every round; the batched
+// K / V projection: 1 + 28), and the workgroups of a round move through k together, so a panel's slice is fetched once per round.
+// `gm_packed` = gm | sr << 8 | sc << 16 (xcd_pack, host): the sub-block shape is found once per launch, not once per workgroup.
+__device__ __forceinline__ void xcd_tile2d(int bid, int mt, int nt, int gm_packed, int& mi, int& ni) {
+    const int gm = gm_packed & 255, sr = (gm_packed >> 8) & 255, sc = gm_packed >> 16;
     const int gn = 8 / gm, bm = mt / gm, bn = nt / gn;
     const int x = bid & 7, local = bid >> 3;
-    const int lm = local / bn, ln = local - lm * bn;
-    mi = (x / gn) * bm + lm;
-    ni = (x - (x / gn) * gn) * bn + ln;
+    const int per_strip = bm * sc;
+    const int st = local / per_strip, rem = local - st * per_strip;
+    const int w = min(sc, bn - st * sc);                // (the last strip may be narrower)
+    const int g = rem / (sr * w), rem2 = rem - g * (sr * w);
+    const int c = rem2 / sr, r = rem2 - c * sr;
+    mi = (x / gn) * bm + g * sr + r;
+    ni = (x - (x / gn) * gn) * bn + st * sc + c;
 }
 
 // byte-free LDS addressing in halves: row-major 64-half rows, 16-byte chunks XOR-swizzled
@@ -1313,7 +1325,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
 
     const int nt = pl_N / BN, mt = (pl_M + BM - 1) / BM;
     int mi_t, ni_t;
-    if (pl_xcd_gm > 0 && pl_xcd_gm < 8) {
+    if (pl_xcd_gm > 0) {   // packed gm | sr << 8 | sc << 16 (xcd_pack)
         xcd_tile2d(blockIdx.x, mt, nt, pl_xcd_gm, mi_t, ni_t);
     } else {
         const int id = xcd_remap(blockIdx.x, nt * mt);
@@ -1634,7 +1646,7 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = pl_N / (NPASS * BN), mt = (pl_M + BM - 1) / BM;
     int mi_t, ni_t;
-    if (pl_xcd_gm > 0 && pl_xcd_gm < 8) {
+    if (pl_xcd_gm > 0) {   // packed gm | sr << 8 | sc << 16 (xcd_pack)
         xcd_tile2d(blockIdx.x, mt, nt, pl_xcd_gm, mi_t, ni_t);
     } else {
         const int id = xcd_remap(blockIdx.x, nt * mt);
@@ -1812,6 +1824,19 @@ static const bool g_gemm_prof_on = [] {   // PRIMX_GEMM_PROF=1: synchronous laun
 thread_local char g_last_gemm_kernel[112] = "";
 #define PRIMX_NOTE_KERNEL(...) snprintf(g_last_gemm_kernel, sizeof(g_last_gemm_kernel), __VA_ARGS__)
 
+// XCD block shape gm (8 / gm column groups) + the sub-block an XCD's 32 CUs work on together (xcd_tile2d): sr = the largest divisor
+// of the block's bm rows that is <= 8 (bm itself when bm <= 8), sc = 32 / sr columns (at most the block's bn).
+static int xcd_pack(int gm, int mtb, int ntb, bool row_major) {
+    const int bm = mtb / gm, bn = ntb / (8 / gm);
+    if (row_major) return gm | (1 << 8) | (bn << 16);      // sr = 1, sc = bn: n fastest over the whole block
+    int sr = bm;
+    if (bm > 8)
+        for (int d = 8; d >= 1; --d)
+            if (bm % d == 0) { sr = d; break; }
+    const int sc = std::max(1, std::min(bn, 32 / sr));
+    return gm | (sr << 8) | (sc << 16);
+}
+
 template <int DT, int EPI, int BIG = 0>
 void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     const dim3 grid(BIG ? ((a.M + 255) / 256) * (a.N / 288) : mt * (a.N / 144));
@@ -1826,6 +1851,10 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
             const double cost = (double)a.M * gn + (double)a.N * gm;      // x K x 2 bytes each
             if (cost < best) { best = cost; a2.xcd_gm = gm; }
         }
+        // (the heads epilogue keeps the row-major walk: the batched K / V projection measured 210 vs 217 us with sub-blocks - its rounds
+        // are bound by the two-layout scatter of the tile, not by operand traffic - while the dense-output GEMMs of a large batch
+        // gain: fc1 at T = 32768 440 -> 410 us, the batch-8 step 61.25 -> 60.86 ms)
+        if (a2.xcd_gm > 0) a2.xcd_gm = xcd_pack(a2.xcd_gm, mtb, ntb, EPI == EPI_HEADS);
     }
     // loader-wave kernel: the row-major epilogues (heads: token-major segments whose tiles stay inside one segment)
     bool loader_ok = !BIG && (EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL);
