@@ -1,5 +1,6 @@
 #!/bin/bash
-# GroupNorm + SiLU folded into the 4^3 convolution's operand load (conv3_s4c256_kernel<.., 1>): parity, then decode A/B
+# GroupNorm + SiLU folded into the 4^3 convolution operand load (conv3_s4c256_kernel<.., 1>): parity, then decode A/B.
+# Needs tools/probe/conv3_gn_at_load.patch applied (the variant measured slower and is not in the tree: profiles/r3_experiments.txt section 21).
 OUT=gpurun_out/gn
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
