@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PRIMX_LIB") or os.path.join(_HERE, "csrc", "libprimx_
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
 HEADS_ROWS, HEADS_VT, HEADS_KROWS = 0, 1, 2
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -25,7 +25,7 @@ SIGNATURES = {
     "primx_last_error": [],
     "primx_last_gemm_kernel": [],
     "primx_padded_head_dim": [_i],
-    "primx_layernorm_modulate": [_p, _p, _p, _l, _p, _i, _i, _i, _i, _f, _p],
+    "primx_layernorm_modulate": [_p, _p, _p, _l, _p, _i, _i, _i, _i, _f, _p, _l, _p, _l, _p],
     "primx_timestep_embedding": [_p, _p, _p, _i, _i, _p],
     "primx_compute_raydirs": [_p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _p],
     "primx_raymarch": [_p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p],
@@ -33,14 +33,14 @@ SIGNATURES = {
     "primx_vit_tokens": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "primx_point_features": [_p, _l, _p, _p, _l, _i, _i, _p],
     "primx_prefetch": [_p, _l, _p],
-    "primx_prefetch_hint": [_p, _l],
-    "primx_prefetch_hint_gemm": [_p, _l],
     "primx_silu_cast": [_p, _p, _i, _l, _p],
     "primx_cast16": [_p, _p, _i, _l, _p],
     "primx_linear_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "primx_linear": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
-    "primx_linear_gate_residual": [_p, _p, _p, _p, _l, _p, _i, _i, _i, _i, _i, _p],
-    "primx_linear_heads": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _i, _i, _f, _i, _p],
+    "primx_linear": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _l, _p],
+    "primx_linear_gate_residual": [_p, _p, _p, _p, _l, _p, _i, _i, _i, _i, _i, _p, _l, _p],
+    "primx_linear_gate_residual_ln": [_p, _p, _p, _p, _l, _p, _i, _i, _i, _i, _p, _p, _l, _p, _f, _p, _l, _i, _p, _l, _p],
+    "primx_ln_sync_timeouts": [],
+    "primx_linear_heads": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _i, _i, _f, _i, _p, _l, _p],
     "primx_attention": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "primx_attention_bcast": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _i, _i, _i, _p],
     "primx_pack_heads": [_p, _l, _l, _l, _p, _i, _i, _i, _i, _i, _i, _i, _p],
@@ -68,9 +68,10 @@ SIGNATURES = {
     "primx_silu_f32": [_p, _p, _l, _p],
 }
 _RESTYPES = {"primx_last_error": C.c_char_p, "primx_last_gemm_kernel": C.c_char_p}
-# an alternate build named by PRIMX_LIB (same-box A/B against an older library) may predate these additive entry points
-_OPTIONAL_IN_AB_BUILDS = {"primx_last_gemm_kernel", "primx_prefetch", "primx_prefetch_hint", "primx_prefetch_hint_gemm", "primx_attention_bcast"}
-_AB_ABI_VERSIONS = (18, 19)
+# an alternate build named by PRIMX_LIB (same-box A/B against another build) must speak the same ABI: version 21 changed the
+# argument lists of the GEMM / LayerNorm entry points (explicit prefetch ranges), so older libraries cannot be bound any more
+_OPTIONAL_IN_AB_BUILDS: set = set()
+_AB_ABI_VERSIONS: tuple = ()
 
 _lib: Optional[C.CDLL] = None
 

@@ -245,6 +245,12 @@ __global__ __launch_bounds__(512) void conv3_s4c256_kernel(const typename T16<DT
         column(std::integral_constant<int, 3>{}); column(std::integral_constant<int, 4>{}); column(std::integral_constant<int, 5>{});
         column(std::integral_constant<int, 6>{}); column(std::integral_constant<int, 7>{}); column(std::integral_constant<int, 8>{});
     }
+    // The MFMAs above are inline asm (mfma16_acc): the compiler's hazard recognizer does not see them, so the wait states between
+    // the LAST matrix instruction's accumulator write and the first v_accvgpr_read of the epilogue are provided here explicitly
+    // instead of by whatever happens to be scheduled in between (an 8-pass 16x16x32 XDL write needs 11 before a VALU / accvgpr read
+    // of the same registers, MI300 ISA guide 4.5 "MFMA hazards": 24 are given), and nothing may move across the fence.
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the redundant tail DMAs must not outlive the workgroup's LDS
     if (PROF) pc2 = __builtin_readcyclecounter();
     auto prof_end = [&]() {

@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "ln_row.h"
 
 namespace {
 
@@ -50,7 +51,8 @@ __device__ __forceinline__ V8 ldg16(const S* ptr, bool keep) {
 
 constexpr int BK = 64;
 
-enum { EPI_LINEAR = 0, EPI_GATE_RESIDUAL = 1, EPI_HEADS = 2, EPI_RES = 3, EPI_CONVT = 4 };
+// (EPI_GATE_RESIDUAL_LN: gemm144l_dma_kernel only - the gate-residual epilogue followed by the LayerNorm + modulate of the row block)
+enum { EPI_LINEAR = 0, EPI_GATE_RESIDUAL = 1, EPI_HEADS = 2, EPI_RES = 3, EPI_CONVT = 4, EPI_GATE_RESIDUAL_LN = 5 };
 
 template <int DT>
 struct GemmArgs {
@@ -82,18 +84,33 @@ struct GemmArgs {
     int S3;        // grid edge S (volume S^3)
     int cin_log2;  // log2(Cin)
     int cout;      // EPI_CONVT: N = 8 * cout
-    // primx_prefetch_hint_gemm: pf_lines 128-byte lines from pf_ptr that the compute waves of the loader-wave kernels touch once
+    // the entry points' `prefetch` range: pf_lines 128-byte lines from pf_ptr that the compute waves of the loader-wave kernels touch once
     const char* pf_ptr;
     int64_t pf_lines;
+    // primx_linear_gate_residual_ln: LayerNorm + modulate of the updated rows (ln_out = null: plain gate-residual).  `sync`: two
+    // zero-initialised words per 128-row block (arrivals, departures); ln_light: same-XCD fences (see gemm144l_dma_kernel)
+    const S* ln_shift;
+    const S* ln_scale;
+    int64_t ln_mod_stride;
+    S* ln_out;
+    float ln_eps;
+    unsigned* sync;
+    int ln_light;
 };
 
-// Weight prefetch carried by a GEMM launch (primx_prefetch_hint_gemm, consumed or dropped by the next GEMM entry point on this
-// thread).  In the loader-wave kernels the compute waves never use their vector-memory queue inside the k-loop, so each of them
-// can request one dword per 128-byte line of ANOTHER GEMM's weights in front of the loop - one or two instructions per wave - and
-// the lines travel HBM -> Infinity Cache while the loop runs from L2, when the fabric is otherwise idle.  (Carried by the LayerNorm
-// launches instead - primx_prefetch_hint - the same bytes compete with the LayerNorm's own stream: 6.8 -> 8.3 us per launch.)
-thread_local const char* g_gemm_pf_ptr = nullptr;
-thread_local int64_t g_gemm_pf_lines = 0;
+// Weight prefetch carried by a GEMM launch (the `prefetch` / `prefetch_bytes` arguments of primx_linear, primx_linear_heads,
+// primx_linear_gate_residual[_ln]).  In the loader-wave kernels the compute waves never use their vector-memory queue inside the
+// k-loop, so each of them can request one dword per 128-byte line of ANOTHER GEMM's weights in front of the loop - one or two
+// instructions per wave - and the lines travel HBM -> Infinity Cache while the loop runs from L2, when the fabric is otherwise
+// idle.  (Carried by the LayerNorm launches instead - primx_layernorm_modulate's pf0 / pf1 - the same bytes compete with the
+// LayerNorm's own stream: 6.8 -> 8.3 us per launch.)  Kernels without loader waves ignore the range.
+template <int DT>
+static int set_prefetch(GemmArgs<DT>& a, const void* ptr, int64_t bytes, const char* name) {
+    PRIMX_REQUIRE((ptr != nullptr) == (bytes > 0) && bytes >= 0, "%s: the prefetch range is (pointer, bytes > 0) or (NULL, 0)", name);
+    a.pf_ptr = (const char*)ptr;
+    a.pf_lines = bytes >= 4 ? (bytes - 4) / 128 + 1 : 0;   // one dword per line, every dword inside [ptr, ptr + bytes)
+    return PRIMX_OK;
+}
 
 typedef unsigned int pf_u32x2 __attribute__((ext_vector_type(2)));
 template <int DT>
@@ -1077,6 +1094,9 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(PRIMX_GEMM_PARAMS(D
     prof_end();
 }
 
+// spin waits of gemm144l_dma_kernel<., EPI_GATE_RESIDUAL_LN> that gave up (primx_ln_sync_timeouts): must stay 0
+__device__ unsigned g_ln_sync_timeouts = 0;
+
 // ---------------------------------------------------------------------------------------------------
 // The 128 x 144 LDS-DMA kernel with LOADER WAVES (PRIMX_GEMM_LOADER=0 switches it off): the dense-output epilogues and the
 // token-major heads epilogue (host-checked: tiles inside one segment, no PRIMX_HEADS_VT segment, dh >= 48, dh % 4 == 0,
@@ -1092,7 +1112,8 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(PRIMX_GEMM_PARAMS(D
 template <int DT, int EPI>
 __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)) {
     PRIMX_GEMM_ARGS(DT);
-    static_assert(EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_HEADS, "row-major epilogues only");
+    static_assert(EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_HEADS || EPI == EPI_GATE_RESIDUAL_LN, "row-major epilogues only");
+    constexpr bool GATE_RES = EPI == EPI_GATE_RESIDUAL || EPI == EPI_GATE_RESIDUAL_LN;
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
     using V4e = typename T16<DT>::V4;
@@ -1180,7 +1201,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     };
     constexpr int NROWCH = (BM * (BN / 4)) / 512;
     f32x4 xpre[NROWCH];
-    const pf_u32x2 pf_v = gemm_prefetch_lines<DT>(p, wave, lane);                        // (primx_prefetch_hint_gemm)
+    const pf_u32x2 pf_v = gemm_prefetch_lines<DT>(p, wave, lane);                        // (the launch's prefetch range)
     asm volatile("s_barrier" ::: "memory");                                              // P
     V8 a0[MI], b0[NI], a1[MI], b1[NI];
     read_frags(0, a0, b0);
@@ -1240,7 +1261,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
         const int m = min(m0 + row, pl_M - 1);
         bpre[i] = V4e{};
         if (p.bias) bpre[i] = *reinterpret_cast<const V4e*>(p.bias + n0 + 4 * c4);
-        if (EPI == EPI_GATE_RESIDUAL) {
+        if (GATE_RES) {
             gpre[i] = *reinterpret_cast<const V4e*>(p.gate + (int64_t)(m / p.rows_per_batch) * p.gate_stride + n0 + 4 * c4);
             xpre[i] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * pl_N + n0 + 4 * c4);
         }
@@ -1269,15 +1290,64 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
                 o[j] = (S)y;
             }
             out_store(reinterpret_cast<V4e*>(h_dst + (((int64_t)bb * p.heads + hh) * p.n_pad + tok) * h_rs + d), o);
-        } else if (EPI == EPI_GATE_RESIDUAL) {
+        } else if (GATE_RES) {
             const V4e gv = gpre[i], bv = bpre[i];
             f32x4 xv = xpre[i];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 xv[j] = xv[j] + rnd16<DT>((float)gv[j] * rnd16<DT>(v0[j] + v1[j] + (p.bias ? (float)bv[j] : 0.f)));
             out_store(reinterpret_cast<f32x4*>(p.x + (int64_t)(m0 + row) * pl_N + n0 + 4 * c4), xv);
-        } else {
+        } else if constexpr (EPI == EPI_LINEAR) {
             epilogue_row4<DT, EPI>(p, m0 + row, n0 + 4 * c4, v0 + v1, bpre[i]);
+        }
+    }
+    if constexpr (EPI == EPI_GATE_RESIDUAL_LN) {
+        // ---------------- LayerNorm + modulate of the 128-row block, in the tail of the GEMM that completes its rows
+        // (dit_crossattn.py:55-57: every gated residual add is followed by the LayerNorm of the next branch).  The nt column
+        // tiles of a row block are nt workgroups; a row is complete when all of them have stored.  Every compute wave (nt x 8
+        // per block) releases its stores, counts itself in on sync[2 g], waits until all have arrived and then normalises ITS
+        // share of the block's rows - 128 / (8 nt) pairs, one row per half-wave, the row body of ln_modulate_row32_kernel
+        // (ln_row.h: same bits).  What this saves is a dependent launch per LayerNorm (~4.5 us fixed + the boundary, 85 per
+        // DDIM step) for ~1k cycles of tail; the rows come from the L2 that the block's tiles share (xcd_remap: consecutive
+        // tile ids = one XCD).  Waiting inside a kernel is safe here because the waited-for workgroups never depend on the
+        // waiting ones and are dispatched no later than them: the workgroups of a block have consecutive ids on one XCD, the
+        // dispatcher hands out ids in order, so whenever the XCD's CUs are all held by waiting workgroups the oldest block among
+        // them is complete (32 CUs >= 3 whole blocks of 8) - the host additionally keeps the grid within one round of the
+        // CUs (launch144_dma).  A bounded spin (~1 s) turns a violated assumption into a counted error (primx_ln_sync_timeouts)
+        // instead of a hang.  Fences: agent-scope release / acquire as the HSA memory model wants them between workgroups
+        // (L2 write-back + invalidate); `ln_light` (PRIMX_LN_FENCE=light) keeps only what same-XCD workgroups need - stores
+        // acknowledged by the shared L2, L1 invalidated.  Departures are counted on sync[2 g + 1]; the last wave to leave
+        // zeroes both words, so a block's words are zero between launches whatever nt the next launch has.
+        const unsigned per = (unsigned)nt * 8u;
+        unsigned* cnt = p.sync + 2 * (m0 / BM);
+        if (p.ln_light) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) {
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 20)) {
+                    atomicAdd(&g_ln_sync_timeouts, 1u);
+                    break;
+                }
+            }
+        }
+        if (p.ln_light) asm volatile("buffer_inv sc1" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int q = (n0 / BN) * 8 + wave;                   // this wave among the block's `per`
+        for (int r = 2 * q + (lane >> 5); r < BM; r += 2 * (int)per) {
+            const int m = m0 + r;
+            if (m >= pl_M) continue;
+            const int64_t bo = (int64_t)(m / p.rows_per_batch) * p.ln_mod_stride;
+            ln_row32<DT, 9>(p.x + (int64_t)m * pl_N, p.ln_shift + bo, p.ln_scale + bo, p.ln_out + (int64_t)m * pl_N, lane & 31, p.ln_eps);
+        }
+        if (lane == 0) {
+            const unsigned d = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == per - 1) {                                // everybody has passed the wait: the words go back to zero
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -1711,7 +1781,7 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(b[j], a[i], acc[i][j]);
     };
-    const pf_u32x2 pf_v = gemm_prefetch_lines<DT>(p, wave, lane);                        // (primx_prefetch_hint_gemm)
+    const pf_u32x2 pf_v = gemm_prefetch_lines<DT>(p, wave, lane);                        // (the launch's prefetch range)
     asm volatile("s_barrier" ::: "memory");                                              // P
     if (pl_prof) pc1 = __builtin_readcyclecounter();
     int st = 0;
@@ -1813,6 +1883,23 @@ static const bool g_xcd2d = [] {   // PRIMX_GEMM_XCD2D=0: whole tile rows per XC
     return !(e && e[0] == '0');
 }();
 
+// LayerNorm in the tail of the gate-residual GEMM (primx_linear_gate_residual_ln): PRIMX_LN_FUSE=0 always takes the two-launch
+// route; PRIMX_LN_FENCE=light keeps only the same-XCD part of the release / acquire pair (A/B measurements);
+// PRIMX_LN_FUSE_MAXGRID bounds the grid of a fused launch.
+static const bool g_ln_fuse = [] {
+    const char* e = getenv("PRIMX_LN_FUSE");
+    return !(e && e[0] == '0');
+}();
+static const bool g_ln_light = [] {
+    const char* e = getenv("PRIMX_LN_FENCE");
+    return e && e[0] == 'l';
+}();
+static const int g_ln_maxgrid = [] {
+    const char* e = getenv("PRIMX_LN_FUSE_MAXGRID");
+    return e ? atoi(e) : 2048;
+}();
+thread_local bool g_ln_fused = false;   // did the last launch144_dma on this thread run the LayerNorm in the GEMM's tail?
+
 static const bool g_gemm_prof_on = [] {   // PRIMX_GEMM_PROF=1: synchronous launches + per-workgroup timeline print (8-wave kernels)
     const char* e = getenv("PRIMX_GEMM_PROF");
     return e && atoi(e) != 0;
@@ -1841,6 +1928,7 @@ template <int DT, int EPI, int BIG = 0>
 void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     const dim3 grid(BIG ? ((a.M + 255) / 256) * (a.N / 288) : mt * (a.N / 144));
     GemmArgs<DT> a2 = a;
+    a2.ln_light = g_ln_light ? 1 : 0;
     if (BIG && g_xcd2d) {
         // XCD block shape: minimise (A bytes x column groups + W bytes x row groups) over the splits the tile grid allows
         const int mtb = (a.M + 255) / 256, ntb = a.N / 288;
@@ -1874,6 +1962,19 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
             PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d>", DT, EPI);
             hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, PRIMX_GEMM_PASS(x));
         } else if (g_loader && loader_ok && !g_gemm_prof_on) {   // (no timeline stamps in the loader-wave kernel)
+            if constexpr (EPI == EPI_GATE_RESIDUAL) {
+                // LayerNorm of the updated rows in the kernel's tail: N = 1152 (nine 128-column chunks per half-wave row), 8-byte
+                // aligned modulation vectors, and every row block's column tiles on ONE XCD with consecutive ids (mt % 8 == 0:
+                // xcd_remap hands each XCD mt / 8 whole blocks) - see the kernel for why the in-kernel wait is safe then
+                const int nt = x.N / 144;
+                if (x.ln_out && x.sync && g_ln_fuse && x.N == 1152 && mt % 8 == 0 && (int)grid.x <= g_ln_maxgrid && nt * 8 <= 128 &&
+                    (((uintptr_t)x.ln_shift | (uintptr_t)x.ln_scale | (uintptr_t)x.ln_out) & 7) == 0 && x.ln_mod_stride % 4 == 0) {
+                    PRIMX_NOTE_KERNEL("gemm144l_dma_kernel<%d, %d>", DT, EPI_GATE_RESIDUAL_LN);
+                    hipLaunchKernelGGL((gemm144l_dma_kernel<DT, EPI_GATE_RESIDUAL_LN>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
+                    g_ln_fused = true;
+                    return;
+                }
+            }
             if constexpr (EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_HEADS) {
                 PRIMX_NOTE_KERNEL("gemm144l_dma_kernel<%d, %d>", DT, EPI);
                 hipLaunchKernelGGL((gemm144l_dma_kernel<DT, EPI>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
@@ -1935,8 +2036,6 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
 template <int DT, int EPI, int GATHER = 0>
 int launch(const GemmArgs<DT>& a_in, hipStream_t st, const char* name) {
     GemmArgs<DT> a = a_in;
-    a.pf_ptr = g_gemm_pf_ptr; a.pf_lines = g_gemm_pf_lines;      // consumed by this launch (kernels that cannot carry it ignore it)
-    g_gemm_pf_ptr = nullptr; g_gemm_pf_lines = 0;
     PRIMX_REQUIRE(a.A && a.W, "%s: null operand", name);
     PRIMX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 8 == 0, "%s: need M,N>0 and K %% 8 == 0 (M=%d N=%d K=%d)",
                   name, a.M, a.N, a.K);
@@ -2064,21 +2163,18 @@ static const bool g_no_gemv = [] {
 
 extern "C" const char* primx_last_gemm_kernel(void) { return g_last_gemm_kernel; }
 
-extern "C" int primx_prefetch_hint_gemm(const void* ptr, int64_t bytes) {
-    if (!ptr && bytes == 0) {                                     // drop a pending hint
-        g_gemm_pf_ptr = nullptr; g_gemm_pf_lines = 0;
-        return PRIMX_OK;
-    }
-    PRIMX_REQUIRE(ptr && bytes > 0, "primx_prefetch_hint_gemm: bad argument");
-    g_gemm_pf_ptr = (const char*)ptr;
-    g_gemm_pf_lines = bytes >= 4 ? (bytes - 4) / 128 + 1 : 0;   // one dword per line, every dword inside [ptr, ptr + bytes)
-    return PRIMX_OK;
+extern "C" int primx_ln_sync_timeouts(void) {
+    unsigned v = 0;
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ln_sync_timeouts), sizeof(v));   // (synchronises with the device)
+    return (int)v;
 }
 
 extern "C" int primx_linear(const void* A, const void* W, const void* bias, void* out, int M, int N, int K, int dtype,
-                            int act, float out_scale, void* stream) {
+                            int act, float out_scale, const void* prefetch, int64_t prefetch_bytes, void* stream) {
     PRIMX_REQUIRE(out, "primx_linear: null output");
     PRIMX_REQUIRE(act == PRIMX_ACT_NONE || act == PRIMX_ACT_GELU_TANH || act == PRIMX_ACT_GELU_ERF, "primx_linear: bad activation code");
+    PRIMX_REQUIRE((prefetch != nullptr) == (prefetch_bytes > 0) && prefetch_bytes >= 0,
+                  "primx_linear: the prefetch range is (pointer, bytes > 0) or (NULL, 0)");   // (the few-row kernel below ignores it)
     if (M > 0 && M <= GEMV_MAX_ROWS16 && N % GEMV_COLS == 0 && K > 0 && K % 8 == 0 && act == PRIMX_ACT_NONE &&
         out_scale == 1.0f && !g_no_gemv) {
         PRIMX_REQUIRE(A && W, "primx_linear: null operand");
@@ -2102,6 +2198,7 @@ extern "C" int primx_linear(const void* A, const void* W, const void* bias, void
         a.A = (const S*)A; a.W = (const S*)W; a.bias = (const S*)bias;
         a.M = M; a.N = N; a.K = K;
         a.out = (S*)out; a.act = act; a.out_scale = out_scale;
+        if (int rc = set_prefetch<DT>(a, prefetch, prefetch_bytes, "primx_linear")) return rc;
         return launch<DT, EPI_LINEAR>(a, (hipStream_t)stream, "primx_linear");
     });
     return PRIMX_OK;
@@ -2121,24 +2218,49 @@ extern "C" int primx_linear_residual(const void* A, const void* W, const void* b
     return PRIMX_OK;
 }
 
-extern "C" int primx_linear_gate_residual(const void* A, const void* W, const void* bias, const void* gate,
-                                          int64_t gate_stride, float* x, int M, int N, int K, int rows_per_batch,
-                                          int dtype, void* stream) {
-    PRIMX_REQUIRE(gate && x && rows_per_batch > 0, "primx_linear_gate_residual: bad argument");
-    PRIMX_DISPATCH_16(dtype, "primx_linear_gate_residual", {
+// (rowops.hip)
+int primx_launch_ln_modulate(const float* x, const void* shift, const void* scale, int64_t mod_stride, void* out, int dtype,
+                             int rows, int rows_per_batch, int D, float eps, const void* pf0, int64_t pf0_bytes,
+                             const void* pf1, int64_t pf1_bytes, void* stream, const char* name);
+
+extern "C" int primx_linear_gate_residual_ln(const void* A, const void* W, const void* bias, const void* gate,
+                                             int64_t gate_stride, float* x, int M, int N, int K, int rows_per_batch,
+                                             const void* ln_shift, const void* ln_scale, int64_t ln_mod_stride, void* ln_out,
+                                             float ln_eps, void* sync, int64_t sync_words, int dtype, const void* prefetch,
+                                             int64_t prefetch_bytes, void* stream) {
+    const char* name = ln_out ? "primx_linear_gate_residual_ln" : "primx_linear_gate_residual";
+    PRIMX_REQUIRE(gate && x && rows_per_batch > 0, "%s: bad argument", name);
+    PRIMX_REQUIRE(!ln_out || (ln_shift && ln_scale), "%s: ln_out needs ln_shift and ln_scale", name);
+    PRIMX_REQUIRE(!sync || sync_words >= 2 * (int64_t)((M + 127) / 128), "%s: sync needs two words per 128-row block", name);
+    g_ln_fused = false;
+    PRIMX_DISPATCH_16(dtype, name, {
         using S = typename T16<DT>::S;
         GemmArgs<DT> a = {};
         a.A = (const S*)A; a.W = (const S*)W; a.bias = (const S*)bias;
         a.M = M; a.N = N; a.K = K;
         a.gate = (const S*)gate; a.gate_stride = gate_stride; a.x = x; a.rows_per_batch = rows_per_batch;
-        return launch<DT, EPI_GATE_RESIDUAL>(a, (hipStream_t)stream, "primx_linear_gate_residual");
+        a.ln_shift = (const S*)ln_shift; a.ln_scale = (const S*)ln_scale; a.ln_mod_stride = ln_mod_stride;
+        a.ln_out = (S*)ln_out; a.ln_eps = ln_eps; a.sync = (unsigned*)sync;
+        if (int rc = set_prefetch<DT>(a, prefetch, prefetch_bytes, name)) return rc;
+        if (int rc = launch<DT, EPI_GATE_RESIDUAL>(a, (hipStream_t)stream, name)) return rc;
     });
+    if (ln_out && !g_ln_fused)   // shapes the tail does not cover: the same LayerNorm as a launch of its own
+        return primx_launch_ln_modulate(x, ln_shift, ln_scale, ln_mod_stride, ln_out, dtype, M, rows_per_batch, N, ln_eps, nullptr, 0,
+                                        nullptr, 0, stream, name);
     return PRIMX_OK;
+}
+
+extern "C" int primx_linear_gate_residual(const void* A, const void* W, const void* bias, const void* gate,
+                                          int64_t gate_stride, float* x, int M, int N, int K, int rows_per_batch,
+                                          int dtype, const void* prefetch, int64_t prefetch_bytes, void* stream) {
+    return primx_linear_gate_residual_ln(A, W, bias, gate, gate_stride, x, M, N, K, rows_per_batch, nullptr, nullptr, 0, nullptr,
+                                         0.f, nullptr, 0, dtype, prefetch, prefetch_bytes, stream);
 }
 
 extern "C" int primx_linear_heads(const void* A, const void* W, const void* bias, int M, int N, int K,
                                   int rows_per_batch, int heads, int dh, int n_seg, const int* kind, void* const* dst,
-                                  int n_rep, int rep_batches, int n_pad, float scale0, int dtype, void* stream) {
+                                  int n_rep, int rep_batches, int n_pad, float scale0, int dtype, const void* prefetch,
+                                  int64_t prefetch_bytes, void* stream) {
     PRIMX_REQUIRE(kind && dst && n_seg >= 1 && n_seg <= 3 && n_rep >= 1, "primx_linear_heads: n_seg must be 1..3, n_rep >= 1");
     PRIMX_REQUIRE(heads > 0 && dh > 0 && N == n_rep * n_seg * heads * dh,
                   "primx_linear_heads: N must equal n_rep*n_seg*heads*dh");
@@ -2162,6 +2284,7 @@ extern "C" int primx_linear_heads(const void* A, const void* W, const void* bias
             a.rep_stride[s] = (int64_t)rep_batches * heads * n_pad * (a.kind[s] == PRIMX_HEADS_VT ? a.DP : heads_row_stride(a.kind[s], a.DP));
             a.dst[s] = s < n_seg ? (S*)dst[s] : nullptr;
         }
+        if (int rc = set_prefetch<DT>(a, prefetch, prefetch_bytes, "primx_linear_heads")) return rc;
         return launch<DT, EPI_HEADS>(a, (hipStream_t)stream, "primx_linear_heads");
     });
     return PRIMX_OK;

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 
 #include "common.h"
+#include "ln_row.h"
 
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -74,21 +75,16 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
 }
 
 // Fast path for D % 128 == 0 (DiT-XL: 1152): one row per HALF-wave, float4 (16-byte) loads, 8-byte stores,
-// 5-step xor reductions inside the 32-lane half.  8 rows per 256-thread block.
-__device__ __forceinline__ float half_wave_sum(float v) {
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
+// 5-step xor reductions inside the 32-lane half (the row body lives in ln_row.h: the gate-residual GEMM's LayerNorm tail
+// runs the same code).  8 rows per 256-thread block.
 
-// primx_prefetch_hint: up to two byte ranges that the next primx_layernorm_modulate launch on this thread pulls into the caches
+// Up to two byte ranges that a primx_layernorm_modulate launch also pulls into the caches (its `pf0` / `pf1` arguments)
 struct PrefetchArgs {
     const char* p0;
     const char* p1;
     int64_t lines0, lines1;
     int blocks;
 };
-thread_local PrefetchArgs g_pf_hint = {nullptr, nullptr, 0, 0, 0};
 
 template <int DT, int NCH4>
 __global__ __launch_bounds__(256) void ln_modulate_row32_kernel(const float* __restrict__ x,
@@ -97,13 +93,10 @@ __global__ __launch_bounds__(256) void ln_modulate_row32_kernel(const float* __r
                                                                int64_t mod_stride,
                                                                typename T16<DT>::S* __restrict__ out, int rows,
                                                                int rows_per_batch, float eps, const PrefetchArgs pf) {
-    using S = typename T16<DT>::S;
-    using V4 = typename T16<DT>::V4;
     constexpr int D = NCH4 * 128;
-    const int l32 = threadIdx.x & 31;
-    // The first pf.blocks workgroups carry a cache prefetch (primx_prefetch_hint): one 4-byte load per 128-byte line of the
-    // weights of the GEMMs that follow.  They are dispatched first, read from HBM while the LayerNorm rows stream from the
-    // Infinity Cache, and retire when their loads have returned.
+    // The first pf.blocks workgroups carry a cache prefetch: one 4-byte load per 128-byte line of the weights of the GEMMs
+    // that follow.  They are dispatched first, read from HBM while the LayerNorm rows stream from the Infinity Cache, and
+    // retire when their loads have returned.
     if ((int)blockIdx.x < pf.blocks) {
         const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
         const char* p = l < pf.lines0 ? pf.p0 + l * 128 : (l - pf.lines0 < pf.lines1 ? pf.p1 + (l - pf.lines0) * 128 : nullptr);
@@ -115,50 +108,17 @@ __global__ __launch_bounds__(256) void ln_modulate_row32_kernel(const float* __r
     }
     const int row = ((int)blockIdx.x - pf.blocks) * 8 + (threadIdx.x >> 5);
     if (row >= rows) return;
-    const float* xr = x + (int64_t)row * D + l32 * 4;
-    f32x4 v[NCH4];
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH4; ++c) {
-        v[c] = *reinterpret_cast<const f32x4*>(xr + c * 128);
-        s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
-    }
-    const float mean = half_wave_sum(s) * (1.0f / D);
-    float q = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH4; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float a = v[c][j] - mean;
-            q += a * a;
-        }
-    const float rstd = 1.0f / sqrtf(half_wave_sum(q) * (1.0f / D) + eps);
     const int b = row / rows_per_batch;
-    const S* sh = shift + (int64_t)b * mod_stride + l32 * 4;
-    const S* sc = scale + (int64_t)b * mod_stride + l32 * 4;
-    S* orow = out + (int64_t)row * D + l32 * 4;
-#pragma unroll
-    for (int c = 0; c < NCH4; ++c) {
-        const V4 s4 = *reinterpret_cast<const V4*>(sc + c * 128);
-        const V4 h4 = *reinterpret_cast<const V4*>(sh + c * 128);
-        V4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float m1 = rnd16<DT>(1.0f + (float)s4[j]);  // (1 + scale) is formed in the 16-bit type
-            o[j] = (S)((v[c][j] - mean) * rstd * m1 + (float)h4[j]);
-        }
-        *reinterpret_cast<V4*>(orow + c * 128) = o;
-    }
+    ln_row32<DT, NCH4>(x + (int64_t)row * D, shift + (int64_t)b * mod_stride, scale + (int64_t)b * mod_stride,
+                       out + (int64_t)row * D, threadIdx.x & 31, eps);
 }
 
 template <int DT>
 static int launch_ln_modulate(const float* x, const void* shift, const void* scale, int64_t mod_stride, void* out,
-                              int rows, int rows_per_batch, int D, float eps, hipStream_t st) {
+                              int rows, int rows_per_batch, int D, float eps, PrefetchArgs pf, hipStream_t st) {
     using S = typename T16<DT>::S;
     // 8-byte alignment of the modulation vectors is required by the fast path (chunks of the adaLN row: D*2 bytes apart)
     const bool aligned = (((uintptr_t)shift | (uintptr_t)scale) & 7) == 0 && (mod_stride % 4) == 0;
-    PrefetchArgs pf = g_pf_hint;                          // consumed (or dropped) by this launch
-    g_pf_hint = PrefetchArgs{nullptr, nullptr, 0, 0, 0};
     if (D % 128 == 0 && aligned && D / 128 <= 16) {
         pf.blocks = (int)((pf.lines0 + pf.lines1 + 255) / 256);
         dim3 g8((rows + 7) / 8 + pf.blocks), b256(256);
@@ -174,6 +134,7 @@ static int launch_ln_modulate(const float* x, const void* shift, const void* sca
         }
 #undef LN32_CASE
     }
+    // (shapes outside the fast path carry no prefetch: the ranges are dropped)
     dim3 grid((rows + 3) / 4), block(256);
 #define LN_CASE(N)                                                                                              \
     case N:                                                                                                     \
@@ -191,19 +152,32 @@ static int launch_ln_modulate(const float* x, const void* shift, const void* sca
     return PRIMX_OK;
 }
 
-extern "C" int primx_layernorm_modulate(const float* x, const void* shift, const void* scale, int64_t mod_stride,
-                                        void* out, int dtype, int rows, int rows_per_batch, int D, float eps,
-                                        void* stream) {
-    PRIMX_REQUIRE(x && shift && scale && out, "primx_layernorm_modulate: null pointer");
+// (shared with gemm.hip: the unfused route of primx_linear_gate_residual_ln launches the LayerNorm through this)
+int primx_launch_ln_modulate(const float* x, const void* shift, const void* scale, int64_t mod_stride, void* out, int dtype,
+                             int rows, int rows_per_batch, int D, float eps, const void* pf0, int64_t pf0_bytes,
+                             const void* pf1, int64_t pf1_bytes, void* stream, const char* name) {
+    PRIMX_REQUIRE(x && shift && scale && out, "%s: null pointer", name);
     PRIMX_REQUIRE(rows > 0 && rows_per_batch > 0 && D > 0 && D % 2 == 0 && D <= 2048,
-                  "primx_layernorm_modulate: need rows>0, rows_per_batch>0, D even and <= 2048 (D=%d)", D);
+                  "%s: need rows>0, rows_per_batch>0, D even and <= 2048 (D=%d)", name, D);
+    PRIMX_REQUIRE((pf0 != nullptr) == (pf0_bytes > 0) && (pf1 != nullptr) == (pf1_bytes > 0) && pf0_bytes >= 0 && pf1_bytes >= 0,
+                  "%s: a prefetch range is (pointer, bytes > 0) or (NULL, 0)", name);
+    auto lines = [](int64_t bytes) -> int64_t { return bytes >= 4 ? (bytes - 4) / 128 + 1 : 0; };   // one dword per line, every dword inside the range
+    PrefetchArgs pf = {(const char*)pf0, (const char*)pf1, lines(pf0_bytes), lines(pf1_bytes), 0};
     int rc = PRIMX_OK;
-    PRIMX_DISPATCH_16(dtype, "primx_layernorm_modulate",
-                      rc = launch_ln_modulate<DT>(x, shift, scale, mod_stride, out, rows, rows_per_batch, D, eps,
+    PRIMX_DISPATCH_16(dtype, name,
+                      rc = launch_ln_modulate<DT>(x, shift, scale, mod_stride, out, rows, rows_per_batch, D, eps, pf,
                                                   (hipStream_t)stream));
     if (rc != PRIMX_OK) return rc;
-    PRIMX_CHECK_LAUNCH("primx_layernorm_modulate");
+    PRIMX_CHECK_LAUNCH(name);
     return PRIMX_OK;
+}
+
+extern "C" int primx_layernorm_modulate(const float* x, const void* shift, const void* scale, int64_t mod_stride,
+                                        void* out, int dtype, int rows, int rows_per_batch, int D, float eps,
+                                        const void* pf0, int64_t pf0_bytes, const void* pf1, int64_t pf1_bytes,
+                                        void* stream) {
+    return primx_launch_ln_modulate(x, shift, scale, mod_stride, out, dtype, rows, rows_per_batch, D, eps, pf0, pf0_bytes, pf1,
+                                    pf1_bytes, stream, "primx_layernorm_modulate");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -326,18 +300,6 @@ __global__ __launch_bounds__(256) void prefetch_lines_kernel(const char* __restr
         unsigned v;
         asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p + l * 128) : "memory");
     }
-}
-
-extern "C" int primx_prefetch_hint(const void* ptr, int64_t bytes) {
-    if (!ptr && bytes == 0) {            // (NULL, 0): drop what is pending (a caller whose LayerNorm launch did not happen)
-        g_pf_hint = PrefetchArgs{nullptr, nullptr, 0, 0, 0};
-        return PRIMX_OK;
-    }
-    PRIMX_REQUIRE(ptr && bytes > 0, "primx_prefetch_hint: bad argument");
-    if (!g_pf_hint.p0) { g_pf_hint.p0 = (const char*)ptr; g_pf_hint.lines0 = bytes >= 4 ? (bytes - 4) / 128 + 1 : 0; }
-    else if (!g_pf_hint.p1) { g_pf_hint.p1 = (const char*)ptr; g_pf_hint.lines1 = bytes >= 4 ? (bytes - 4) / 128 + 1 : 0; }
-    else { primx_set_error("primx_prefetch_hint: two hints are already pending"); return PRIMX_EINVAL; }
-    return PRIMX_OK;
 }
 
 extern "C" int primx_prefetch(const void* ptr, int64_t bytes, void* stream) {

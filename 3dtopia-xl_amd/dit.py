@@ -137,22 +137,23 @@ class DiT(nn.Module):
         self.initialize_weights()
         self._pack: Dict = {}
         self._heads_ws: Dict = {}
-        self._heads_owner: Dict = {}   # workspace key -> the shape group that allocated it (_heads_begin)
+        self._heads_owner: Dict = {}   # workspace key -> the set of shape groups that use it (_heads / _heads_begin)
         self._heads_lru: list = []
         self._heads_group = None
         self._cond: Optional[Dict] = None
         self._packed_only = False   # set when only the packed blob was received / loaded, not the fp32 parameters
         # Opt-in exact-algebra shortcut: to_k(y) / to_v(y) do not depend on the timestep
         # (models/attention.py:106-107), so with this flag the K / V projections of all blocks are computed once per
-        # conditioning tensor and reused across DDIM steps.  Off by default: a step then executes the reference's full
-        # algorithmic FLOPs (bench.py reports both when the flag is on).
+        # conditioning tensor and reused across DDIM steps.  Off by default: every step then projects its conditioning tokens, as
+        # the reference does (bench.py quotes its rates against the FLOPs a step executes and reports the algorithmic count of
+        # the reference's step next to them).
         self.reuse_cond_kv = False
         # Second opt-in exact-algebra shortcut, CFG forwards only: the unconditional half is conditioned on ONE row repeated L
         # times (`y_null = null_cond_embedding.expand_as(y)`, dit_crossattn.py:207), so its L keys are identical, its softmax
         # is uniform whatever the query, and its cross-attention output is the (identical) value row of every head - to_q and
         # the attention core of that half compute nothing else.  With this flag they are skipped and the value row is broadcast;
-        # to_k / to_v, proj and everything else run as before.  Off by default: the headline executes the reference's full
-        # algorithmic FLOPs.  Measured at batch 1 (round 3): NO gain (8.55 vs 8.47 ms per step next to reuse_cond_kv) - the
+        # to_k / to_v, proj and everything else run as before.  Off by default (the headline attends; what it does NOT repeat is
+        # the projection of the L identical null rows - `dedup_null_kv` below, 2 % of the algorithmic FLOPs).  Measured at batch 1 (round 3): NO gain (8.55 vs 8.47 ms per step next to reuse_cond_kv) - the
         # half-size to_q and attention launches occupy half of the CUs for the same time; it pays from batch 2 per GPU on.
         self.collapse_null_cross_attention = False
         # Opt-in: run the two classifier-free-guidance halves of `forward_with_cfg` as two concurrent HIP streams
@@ -166,6 +167,10 @@ class DiT(nn.Module):
         # weight prefetch of the loader-wave GEMMs (_forward16): 2 = carried by the GEMM launches one or two ahead, 1 = carried by the
         # LayerNorm launches, 0 = off (PRIMX_WPREFETCH)
         self.weight_prefetch = int(os.environ.get("PRIMX_WPREFETCH", "2"))
+        # the LayerNorm + modulate that follows every gated residual add runs in the tail of that GEMM's kernel (_forward16; one
+        # launch of its own per forward instead of 3 per block + 1).  Bit-identical results; PRIMX_DIT_FUSE_LN=0 keeps the launches.
+        self.fuse_ln = os.environ.get("PRIMX_DIT_FUSE_LN", "1") != "0"
+        self._ln_sync: Dict = {}              # device -> int32 workspace of the fused route (zero between launches)
         self._side: Dict = {}
         self._t_plan: Optional[Dict] = None   # plan_timesteps(): the coming calls' timesteps and their modulation table
 
@@ -318,6 +323,9 @@ class DiT(nn.Module):
         return pk
 
     PACKED_MAGIC = b"PRIMXPK1"
+    # header "format": 2 since round 3 (`hyper` gained the class name and DiTAdditivePosEmb's fp32 tensor list grew: files of
+    # format 1 have another layout behind the blob and must be re-packed)
+    PACKED_FORMAT = 2
     _PACKED_FILE_ALIGN = 4096
 
     def _hyper(self) -> Dict:
@@ -337,7 +345,7 @@ class DiT(nn.Module):
         flat = pk["_flat"].detach().cpu().contiguous()
         small = [t.detach().cpu().float().contiguous() for t in self.small_fp32_tensors()]
         al = self._PACKED_FILE_ALIGN
-        head = {"format": 1, "dtype": str(dtype).replace("torch.", ""), "hyper": self._hyper(), "pack_align": self._PACK_ALIGN,
+        head = {"format": self.PACKED_FORMAT, "dtype": str(dtype).replace("torch.", ""), "hyper": self._hyper(), "pack_align": self._PACK_ALIGN,
                 "blob_elements": flat.numel(),
                 "small_fp32": [list(t.shape) for t in small]}
         hj = json.dumps(head, sort_keys=True).encode()
@@ -367,7 +375,10 @@ class DiT(nn.Module):
                 raise RuntimeError(f"{path}: not a packed PrimX DiT file")
             hlen = int.from_bytes(f.read(8), "little")
             head = json.loads(f.read(hlen).decode())
-        if head.get("format") != 1 or head.get("hyper") != self._hyper() or head.get("pack_align") != self._PACK_ALIGN:
+        if head.get("format") != self.PACKED_FORMAT:
+            raise RuntimeError(f"{path}: packed file format {head.get('format')} (this build reads format {self.PACKED_FORMAT}): "
+                               "repack required - write it again with DiT.save_packed from the checkpoint")
+        if head.get("hyper") != self._hyper() or head.get("pack_align") != self._PACK_ALIGN:
             raise RuntimeError(f"{path}: packed for a different model ({head.get('hyper')}) than this one ({self._hyper()})")
         dtype = {"float16": torch.float16, "bfloat16": torch.bfloat16}[head["dtype"]]
         self.repack()
@@ -413,7 +424,9 @@ class DiT(nn.Module):
             buf = ops.alloc_heads(B, self.num_heads, n, self.hidden_size // self.num_heads, kind, dtype, device, pad_to,
                                   role=tag[0].lower())  # "q" / "k": operand-level key-padding mask (ops.alloc_heads)
             self._heads_ws[key] = buf
-            self._heads_owner[key] = self._heads_group
+        # every shape group that uses a workspace holds it (keys that do not depend on the batch size - the broadcast entries
+        # Kn / Vn - are shared between groups): it is freed when the LAST of them is evicted, not when the first allocator is
+        self._heads_owner.setdefault(key, set()).add(self._heads_group)
         return buf
 
     _HEADS_GROUPS = 3   # (batch, N, L, dtype, device) shapes whose attention workspaces stay allocated
@@ -429,12 +442,14 @@ class DiT(nn.Module):
         self._heads_group = group
         while len(lru) > self._HEADS_GROUPS:
             old = lru.pop(0)
-            dead = [k for k, g in self._heads_owner.items() if g == old]
-            for k in dead:
-                self._heads_ws.pop(k, None)
-                self._heads_owner.pop(k, None)
-            if self._cond is not None and self._cond.get("group") == old:
-                self._cond = None           # its K / V cache pointed into them
+            for k in [k for k, gs in self._heads_owner.items() if old in gs]:
+                gs = self._heads_owner[k]
+                gs.discard(old)
+                if not gs:
+                    self._heads_ws.pop(k, None)
+                    self._heads_owner.pop(k, None)
+            # (the conditioning cache `_cond` always belongs to a more recently used group than the evicted one - it is rebuilt or
+            # re-tagged by every forward - and validates its K / V buffers by pointer (`kv_id`), so there is nothing to drop here)
 
     def _side_stream(self, dev) -> "torch.cuda.Stream":
         key = str(dev)
@@ -617,19 +632,33 @@ class DiT(nn.Module):
 
         # Weight prefetch (PRIMX_WPREFETCH=0 turns it off): the 1.8 GB of weights stream through HBM once per forward, and the
         # 128 x 144 GEMMs run 2 - 4 us longer with cold weights than with cache-resident ones (rocprofv3, tools/gpu/r3_touch.sh).
-        # Every LayerNorm launch - a short kernel that reads the residual stream from the Infinity Cache - carries the prefetch
-        # of the weights of the loader-wave GEMMs that follow it (ops.prefetch_hint): no launch, no event, no stream of its own.
-        # Round 3, later: the GEMM launches carry it instead (`weight_prefetch` = 2, ops._carrying): the compute waves of a
-        # loader-wave kernel touch the lines of a LATER GEMM's weights in front of their k-loop - to_q carries cproj's weights, cproj
-        # proj's, fc1 fc2's, fc2 the next block's to_q - and the LayerNorm launches are back to their own bytes.
+        # `weight_prefetch` = 1: every LayerNorm launch - a short kernel that reads the residual stream from the Infinity Cache -
+        # carries the prefetch of the weights of the loader-wave GEMMs that follow it (ops.layernorm_modulate `prefetch=`): no
+        # launch, no event, no stream of its own.  `weight_prefetch` = 2 (the default): the GEMM launches carry it instead (`carry=`):
+        # the compute waves of a loader-wave kernel touch the lines of a LATER GEMM's weights in front of their k-loop - to_q
+        # carries cproj's weights, cproj proj's, fc1 fc2's, fc2 the next block's to_q - and the LayerNorms keep to their own bytes.
         wpf = int(self.weight_prefetch)
         collapse = bool(self.collapse_null_cross_attention) and null_half
         blocks = pk["blocks"]
+        # LayerNorm in the tail of the gate-residual GEMMs (`fuse_ln`, round 4): every gated residual add of a block is followed by
+        # the LayerNorm + modulate of the next branch (dit_crossattn.py:55-57) - of the next block after fc2, of the final layer
+        # after the last one.  ops.linear_gate_residual(ln=...) produces both (one kernel where the shape allows, bit-identical to
+        # the two launches either way), so only the FIRST LayerNorm of a forward is a launch of its own: 85 -> 1 at DiT-XL.
+        # Not with the LayerNorm-carried prefetch (wpf == 1: that mode needs the LayerNorm launches).
+        fuse = bool(self.fuse_ln) and wpf != 1
+        sync = None
+        sync_w = ops.ln_sync_words(T)
+        if fuse:
+            # (two regions: with `cfg_streams` the two halves run concurrently and must not share words)
+            key = str(dev)
+            sync = self._ln_sync.get(key)
+            if sync is None or sync.numel() < 2 * sync_w:
+                sync = self._ln_sync[key] = torch.zeros(2 * sync_w, dtype=torch.int32, device=dev)
+        base = self.depth * 9 * D
+        fin_mod = (mod[:, base:base + D], mod[:, base + D:base + 2 * D])    # final layer's shift / scale
 
         def warm(*wts):
-            if wpf == 1:
-                for wt in wts:
-                    ops.prefetch_hint(wt)
+            return wts if wpf == 1 else ()
 
         def carry(wt):
             return wt if wpf == 2 else None
@@ -641,9 +670,12 @@ class DiT(nn.Module):
             Th = r1 - r0
             m = mod[b0:b1, i * 9 * D:(i + 1) * 9 * D]
             ch = [m[:, j * D:(j + 1) * D] for j in range(9)]  # shift/scale/gate x (mca, msa, mlp)
+            def ln_of(shift, scale):                     # the LayerNorm that follows a gated residual add, fused into its GEMM
+                return (shift, scale, xh, self.LN_EPS, sync[:sync_w] if b0 == 0 else sync[sync_w:]) if fuse else None
             # ---- cross-attention to the image tokens (dit_crossattn.py:55, attention.py:96-114)
-            warm(w["w_q"], w["w_cproj"])       # (the block's cross-attention K / V instead: -1.0 us on that kernel, +0.5 on this one)
-            ops.layernorm_modulate(hh, ch[0], ch[1], N, xh, self.LN_EPS)
+            if not fuse or i == 0:                       # (fused: the previous block's fc2 launch has normalised these rows)
+                # (the block's cross-attention K / V as the prefetch instead: -1.0 us on that kernel, +0.5 on this one)
+                ops.layernorm_modulate(hh, ch[0], ch[1], N, xh, self.LN_EPS, prefetch=warm(w["w_q"], w["w_cproj"]))
             bc = min(b1, B) if collapse else b1          # batch entries [b0, bc) attend; [bc, b1) are unconditional rows
             if bc > b0:
                 ops.linear_heads(xh[:(bc - b0) * N], w["w_q"], w["b_q"], N, H, dh, [HEADS_ROWS], [Qc[b0:bc]], nq_pad, scale0=scale,
@@ -662,20 +694,24 @@ class DiT(nn.Module):
                 ah[max(bc, b0) - b0:].copy_(vrow.expand(-1, N, -1))
             if hook is not None:
                 hook()
-            ops.linear_gate_residual(ah.view(Th, D), w["w_cproj"], w["b_cproj"], ch[2], hh, N, carry=carry(w["w_proj"]))
+            ops.linear_gate_residual(ah.view(Th, D), w["w_cproj"], w["b_cproj"], ch[2], hh, N, carry=carry(w["w_proj"]),
+                                     ln=ln_of(ch[3], ch[4]))
             # ---- self-attention over the primitive tokens (dit_crossattn.py:56, attention.py:48-59)
-            warm(w["w_proj"])
-            ops.layernorm_modulate(hh, ch[3], ch[4], N, xh, self.LN_EPS)
+            if not fuse:
+                ops.layernorm_modulate(hh, ch[3], ch[4], N, xh, self.LN_EPS, prefetch=warm(w["w_proj"]))
             ops.linear_heads(xh, w["w_qkv"], w["b_qkv"], N, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT],
                              [Qs[b0:b1], Ks[b0:b1], Vs[b0:b1]], nq_pad)
             ops.attention(Qs[b0:b1], Ks[b0:b1], Vs[b0:b1], N, N, dh, scale, out=ah)
-            ops.linear_gate_residual(ah.view(Th, D), w["w_proj"], w["b_proj"], ch[5], hh, N)
+            ops.linear_gate_residual(ah.view(Th, D), w["w_proj"], w["b_proj"], ch[5], hh, N, ln=ln_of(ch[6], ch[7]))
             # ---- MLP (dit_crossattn.py:57, models/utils.py:94-101)
-            warm(w["w_fc2"])
-            ops.layernorm_modulate(hh, ch[6], ch[7], N, xh, self.LN_EPS)
+            if not fuse:
+                ops.layernorm_modulate(hh, ch[6], ch[7], N, xh, self.LN_EPS, prefetch=warm(w["w_fc2"]))
             ops.linear(xh, w["w_fc1"], w["b_fc1"], out=hid[r0:r1], act=ACT_GELU_TANH, carry=carry(w["w_fc2"]))
+            last = i + 1 == len(blocks)
+            nxt = (fin_mod[0][b0:b1], fin_mod[1][b0:b1]) if last else \
+                (mod[b0:b1, (i + 1) * 9 * D:(i + 1) * 9 * D + D], mod[b0:b1, (i + 1) * 9 * D + D:(i + 1) * 9 * D + 2 * D])
             ops.linear_gate_residual(hid[r0:r1], w["w_fc2"], w["b_fc2"], ch[8], hh, N,
-                                     carry=carry(blocks[i + 1]["w_q"]) if i + 1 < len(blocks) else None)
+                                     carry=None if last else carry(blocks[i + 1]["w_q"]), ln=ln_of(*nxt))
 
         if self.cfg_streams and null_half and self.depth and ops.PROFILE is None:
             # Two HIP streams, one per CFG half (the conditional and the unconditional rows are independent chains of
@@ -698,8 +734,8 @@ class DiT(nn.Module):
                 block(i, w, 0, Be)
 
         # ---- final layer (dit_crossattn.py:74-78)
-        base = self.depth * 9 * D
-        ops.layernorm_modulate(h, mod[:, base:base + D], mod[:, base + D:base + 2 * D], N, xn, self.LN_EPS)
+        if not (fuse and self.depth):                    # (fused: the last block's fc2 launch has normalised the rows)
+            ops.layernorm_modulate(h, fin_mod[0], fin_mod[1], N, xn, self.LN_EPS)
         out = ops.linear(xn, pk["w_final"], pk["b_final"])
         return out.view(Be, N, self.out_channels)
 

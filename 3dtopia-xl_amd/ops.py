@@ -107,24 +107,32 @@ def round_up(n: int, m: int) -> int:
 
 
 # ----------------------------------------------------------------------------- row kernels
+def _range(t: Optional[torch.Tensor]) -> Tuple[Optional[int], int]:
+    """(pointer, bytes) of a cache-prefetch range argument; (None, 0) when there is none."""
+    if t is None or not t.is_cuda or not t.is_contiguous() or t.numel() == 0:
+        return None, 0
+    return t.data_ptr(), t.numel() * t.element_size()
+
+
+def _check_modulation(shift: torch.Tensor, scale: torch.Tensor, out: torch.Tensor) -> None:
+    if shift.stride(-1) != 1 or scale.stride(-1) != 1 or shift.stride(0) != scale.stride(0):
+        raise RuntimeError("shift/scale must be last-dim contiguous with equal row strides")
+    if not (shift.is_cuda and scale.is_cuda and shift.dtype == out.dtype == scale.dtype):
+        raise TypeError("shift/scale/out dtype or device mismatch")
+
+
 def layernorm_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, rows_per_batch: int,
-                       out: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
-    """x: [rows, D] fp32; shift/scale: [B, D] 16-bit views (last dim contiguous, row stride arbitrary)."""
+                       out: torch.Tensor, eps: float = 1e-6, prefetch: Sequence[torch.Tensor] = ()) -> torch.Tensor:
+    """x: [rows, D] fp32; shift/scale: [B, D] 16-bit views (last dim contiguous, row stride arbitrary).
+    `prefetch`: up to two tensors whose bytes this launch also pulls into the caches (primx_layernorm_modulate pf0 / pf1)."""
     rows, D = x.shape
-    try:
-        if shift.stride(-1) != 1 or scale.stride(-1) != 1 or shift.stride(0) != scale.stride(0):
-            raise RuntimeError("shift/scale must be last-dim contiguous with equal row strides")
-        if not (shift.is_cuda and scale.is_cuda and shift.dtype == out.dtype == scale.dtype):
-            raise TypeError("shift/scale/out dtype or device mismatch")
-        check(_lib.load().primx_layernorm_modulate(
-            _dev(x, "x", torch.float32), shift.data_ptr(), scale.data_ptr(), shift.stride(0), _dev(out, "out"),
-            dtype_code(out.dtype), rows, rows_per_batch, D, eps, _stream()), "primx_layernorm_modulate")
-    except Exception:
-        # a launch that did not happen must not leave prefetch ranges pending for some later, unrelated LayerNorm
-        lib = _lib.load()
-        if hasattr(lib, "primx_prefetch_hint"):
-            lib.primx_prefetch_hint(None, 0)
-        raise
+    _check_modulation(shift, scale, out)
+    if len(prefetch) > 2:
+        raise RuntimeError("layernorm_modulate carries at most two prefetch ranges")
+    (p0, n0), (p1, n1) = (_range(prefetch[0]) if len(prefetch) > 0 else (None, 0)), (_range(prefetch[1]) if len(prefetch) > 1 else (None, 0))
+    check(_lib.load().primx_layernorm_modulate(
+        _dev(x, "x", torch.float32), shift.data_ptr(), scale.data_ptr(), shift.stride(0), _dev(out, "out"),
+        dtype_code(out.dtype), rows, rows_per_batch, D, eps, p0, n0, p1, n1, _stream()), "primx_layernorm_modulate")
     return out
 
 
@@ -199,33 +207,12 @@ def linear_f32(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], act_
     return out
 
 
-def prefetch_hint(t: torch.Tensor) -> None:
-    """The next layernorm_modulate launch also pulls `t`'s bytes into the caches (csrc/rowops.hip primx_prefetch_hint)."""
-    check(_lib.load().primx_prefetch_hint(_dev(t, "t"), t.numel() * t.element_size()), "primx_prefetch_hint")
-
-
 def prefetch(t: torch.Tensor, stream: "torch.cuda.Stream") -> None:
     """Enqueue a cache prefetch of `t`'s bytes on `stream` (csrc/rowops.hip primx_prefetch); no result, no dependency."""
     check(_lib.load().primx_prefetch(_dev(t, "t"), t.numel() * t.element_size(), stream.cuda_stream), "primx_prefetch")
 
 
 # ----------------------------------------------------------------------------- GEMMs
-def _carrying(carry: Optional[torch.Tensor], launch):
-    """Run `launch` (one GEMM entry point) with `carry`'s bytes registered as the weight prefetch that GEMM carries
-    (csrc/gemm.hip primx_prefetch_hint_gemm: consumed or dropped by exactly that launch)."""
-    if carry is None or not carry.is_contiguous() or not carry.is_cuda:
-        return launch()
-    lib = _lib.load()
-    if not hasattr(lib, "primx_prefetch_hint_gemm"):       # (A/B builds of an older ABI)
-        return launch()
-    check(lib.primx_prefetch_hint_gemm(_dev(carry, "carry"), carry.numel() * carry.element_size()), "primx_prefetch_hint_gemm")
-    try:
-        return launch()
-    except Exception:
-        lib.primx_prefetch_hint_gemm(None, 0)              # a launch that did not happen must not leave the range pending
-        raise
-
-
 def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
            act: int = ACT_NONE, out_scale: float = 1.0, carry: Optional[torch.Tensor] = None) -> torch.Tensor:
     M, K = A.shape
@@ -234,23 +221,55 @@ def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: 
         raise RuntimeError("linear: operand mismatch")
     if out is None:
         out = torch.empty(M, N, dtype=A.dtype, device=A.device)
-    _carrying(carry, lambda: _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear(
+    cp, cn = _range(carry)
+    _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear(
         _dev(A, "A"), _dev(W, "W"), _dev(bias, "bias", A.dtype) if bias is not None else None,
-        _dev(out, "out", A.dtype), M, N, K, dtype_code(A.dtype), act, out_scale, _stream()), "primx_linear")))
+        _dev(out, "out", A.dtype), M, N, K, dtype_code(A.dtype), act, out_scale, cp, cn, _stream()), "primx_linear"))
     return out
 
 
+def ln_sync_words(rows: int) -> int:
+    """32-bit words of the `sync` workspace primx_linear_gate_residual_ln wants for `rows` rows (two per 128-row block)."""
+    return 2 * ((rows + 127) // 128)
+
+
+def ln_sync_timeouts() -> int:
+    """In-kernel waits of the fused gate-residual + LayerNorm route that gave up since the library was loaded (must be 0)."""
+    return int(_lib.load().primx_ln_sync_timeouts())
+
+
 def linear_gate_residual(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], gate: torch.Tensor,
-                         x: torch.Tensor, rows_per_batch: int, carry: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x[M, N] (fp32, in place) += cast16(gate[b] * cast16(A W^T + bias)).  `carry`: see _carrying."""
+                         x: torch.Tensor, rows_per_batch: int, carry: Optional[torch.Tensor] = None,
+                         ln: Optional[tuple] = None) -> torch.Tensor:
+    """x[M, N] (fp32, in place) += cast16(gate[b] * cast16(A W^T + bias)).  `carry`: a tensor (a later GEMM's weights) whose
+    bytes this launch pulls towards the caches.
+    `ln` = (shift, scale, out, eps, sync): ALSO out[m] = cast16(LN(x[m]) (1 + scale[b]) + shift[b]) of the updated rows - the
+    LayerNorm + modulate that follows every gated residual add of a DiT block - in the tail of the same kernel where the shape
+    allows, as a second launch otherwise (primx_linear_gate_residual_ln; `sync`: zeroed int32 workspace of ln_sync_words(M)
+    words or None)."""
     M, K = A.shape
     N = W.shape[0]
     if gate.stride(-1) != 1 or gate.dtype != A.dtype or not gate.is_cuda:
         raise RuntimeError("gate must be a last-dim-contiguous 16-bit device view")
-    _carrying(carry, lambda: _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_gate_residual(
+    cp, cn = _range(carry)
+    if ln is None:
+        _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_gate_residual(
+            _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None,
+            gate.data_ptr(), gate.stride(0), _dev(x, "x", torch.float32), M, N, K, rows_per_batch,
+            dtype_code(A.dtype), cp, cn, _stream()), "primx_linear_gate_residual"))
+        return x
+    shift, scale, out, eps, sync = ln
+    _check_modulation(shift, scale, out)
+    if out.dtype != A.dtype or tuple(out.shape) != (M, N):
+        raise RuntimeError("linear_gate_residual: the LayerNorm output must be a 16-bit [M, N] tensor of A's dtype")
+    if sync is not None and (sync.dtype != torch.int32 or not sync.is_cuda or sync.numel() < ln_sync_words(M)):
+        raise RuntimeError("linear_gate_residual: sync must be an int32 device tensor of ln_sync_words(M) words")
+    _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_gate_residual_ln(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None,
         gate.data_ptr(), gate.stride(0), _dev(x, "x", torch.float32), M, N, K, rows_per_batch,
-        dtype_code(A.dtype), _stream()), "primx_linear_gate_residual")))
+        shift.data_ptr(), scale.data_ptr(), shift.stride(0), _dev(out, "ln_out"), eps,
+        _dev(sync, "sync") if sync is not None else None, sync.numel() if sync is not None else 0,
+        dtype_code(A.dtype), cp, cn, _stream()), "primx_linear_gate_residual_ln"))
     return x
 
 
@@ -266,11 +285,12 @@ def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     n_seg = len(kinds)
     kind_arr = (C.c_int * n_seg)(*kinds)
     dst_arr = (C.c_void_p * n_seg)(*[_dev(d, "dst", A.dtype) for d in dsts])
-    _carrying(carry, lambda: _timed(f"None {M}x{N}x{K}", 2.0 * (real_rows if real_rows is not None else M) * N * K, lambda: check(_lib.load().primx_linear_heads(
+    cp, cn = _range(carry)
+    _timed(f"None {M}x{N}x{K}", 2.0 * (real_rows if real_rows is not None else M) * N * K, lambda: check(_lib.load().primx_linear_heads(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None, M, N, K,
         rows_per_batch, heads, dh, n_seg, kind_arr, dst_arr, n_rep, rep_batches, n_pad, scale0, dtype_code(A.dtype),
-        _stream()),
-        "primx_linear_heads")))
+        cp, cn, _stream()),
+        "primx_linear_heads"))
 
 
 # ----------------------------------------------------------------------------- attention

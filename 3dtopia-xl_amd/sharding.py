@@ -18,6 +18,7 @@ backend for the plumbing tests; the sampler itself still requires a HIP device.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -41,10 +42,22 @@ def _world() -> Tuple[int, int]:
     return 0, 1
 
 
+# Test hook: with a process group of ONE rank the collectives are skipped (nothing to exchange) - unless this is set
+# (PRIMX_FORCE_COLLECTIVES=1), in which case every broadcast / scatter / gather below is really issued on the 1-rank group.
+# That is how the RCCL code path is exercised on a single-GPU box (tests/test_hip_rccl.py): the library loads, the IPC mode is
+# right, the packed blob survives the broadcast byte for byte.  It says nothing about scaling.
+FORCE_COLLECTIVES = os.environ.get("PRIMX_FORCE_COLLECTIVES") == "1"
+
+
+def _single(world: int) -> bool:
+    """True when the collectives are skipped: one rank and no forcing (or no process group at all)."""
+    return world == 1 and not (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
+
+
 def broadcast_module_(module: torch.nn.Module, src: int = 0) -> int:
     """In-place broadcast of every parameter and buffer as ONE flat tensor per dtype.  Returns bytes sent."""
     rank, world = _world()
-    if world == 1:
+    if _single(world):
         return 0
     tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
     total = 0
@@ -71,7 +84,7 @@ def broadcast_packed_(model: torch.nn.Module, dtype: torch.dtype, src: int = 0) 
     the fp32 -> 16-bit repack.  Non-source ranks are marked packed-only: their fp32 parameters are not valid, so the
     fp32 route and a different dtype raise there.  Returns bytes sent (0 for world size 1)."""
     rank, world = _world()
-    if world == 1:
+    if _single(world):
         return 0
     pk = model.packed(dtype) if rank == src else model.packed_alloc(dtype)
     dist.broadcast(pk["_flat"], src=src)
@@ -93,7 +106,7 @@ def scatter_batch(full: Optional[torch.Tensor], shape_tail: Sequence[int], n_ite
     """Rank ``src`` holds ``full`` [n_items, *shape_tail]; every rank receives its contiguous slice."""
     rank, world = _world()
     lo, hi = shard_bounds(n_items, world)[rank]
-    if world == 1:
+    if _single(world):
         return full[lo:hi].to(device=device, dtype=dtype)
     mine = torch.empty((hi - lo, *shape_tail), dtype=dtype, device=device)
     # uneven slices: pad every chunk to the largest so a single scatter suffices
@@ -114,7 +127,7 @@ def scatter_batch(full: Optional[torch.Tensor], shape_tail: Sequence[int], n_ite
 def gather_batch(local: torch.Tensor, n_items: int, dst: int = 0) -> Optional[torch.Tensor]:
     """Inverse of scatter_batch: rank ``dst`` gets [n_items, ...], other ranks None."""
     rank, world = _world()
-    if world == 1:
+    if _single(world):
         return local
     bounds = shard_bounds(n_items, world)
     mx = max(h - l for l, h in bounds)
@@ -152,7 +165,7 @@ class ShardedSampler:
             gen = torch.Generator().manual_seed(seed) if seed is not None else None
             noise = torch.randn(batch, n_tokens, channels, generator=gen)        # CPU draw, as inference.py:316
         cond_tail = None
-        if self.world > 1:
+        if not _single(self.world):
             meta = [tuple(cond.shape[1:])] if self.rank == 0 else [None]
             dist.broadcast_object_list(meta, src=0)
             cond_tail = meta[0]
@@ -181,7 +194,7 @@ class ShardedSampler:
         if self.rank == 0:
             gen = torch.Generator().manual_seed(seed) if seed is not None else None
             noise = torch.randn(batch, n_tokens, channels, generator=gen)
-        if self.world > 1:
+        if not _single(self.world):
             meta = [tuple(cond.shape[1:])] if self.rank == 0 else [None]
             dist.broadcast_object_list(meta, src=0)
             cond_tail = meta[0]
@@ -199,7 +212,7 @@ class ShardedSampler:
                                                       clip_denoised=False, model_kwargs=dict(y=y, **model_kwargs),
                                                       device=self.device)
             dec = decode(out)
-        if self.world == 1:
+        if _single(self.world):
             if dec is None:                                    # batch == 0: an empty result, not None
                 return torch.empty(0, n_tokens, 0, dtype=torch.float32, device=self.device)
             return dec

@@ -223,7 +223,9 @@ def rendezvous(args):
     dev = torch.device("cuda", local) if have_gpu else torch.device("cpu")
     if have_gpu:
         torch.cuda.set_device(dev)
-    if world > 1:
+    # PRIMX_FORCE_COLLECTIVES=1 (tests/test_hip_rccl.py): a ONE-rank RCCL process group is brought up too and the weight broadcast is
+    # really issued on it (sharding.FORCE_COLLECTIVES) - proves the collective path on a single-GPU box, measures nothing
+    if world > 1 or (os.environ.get("PRIMX_FORCE_COLLECTIVES") == "1" and "MASTER_PORT" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if have_gpu:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -252,6 +254,7 @@ def main() -> None:
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline leg)")
     ap.add_argument("--no-decode-leg", action="store_true", help="ddim: skip the decode sub-record and the measured 25-step samples/s")
+    ap.add_argument("--no-side-legs", action="store_true", help="ddim at batch 1: skip the `batch8` and `bf16` sub-records")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous only: print the ranks that met (launcher check; gloo without a GPU)")
     args = ap.parse_args()
 
@@ -390,6 +393,36 @@ def main() -> None:
                             "half are projected by to_k / to_v, stored and read like the conditional ones; bit-identical attention "
                             "results (tests/test_hip_attention.py::test_broadcast_key_value_entries)"}
 
+    # Two more shapes of the same loop, reported NEXT TO the headline (outside its timed region, like `decode`): the configs[2] /
+    # configs[3] per-GPU batch of 8 (T = 32768 tokens per launch: every GEMM on the 256 x 288 tile) and configs[1] in bf16 - the
+    # north star's target dtype.  Same model, same kernels, K steps between synchronisations, median of R.
+    side = {}
+    if args.config == "ddim" and rank == 0 and world == 1 and B == 1 and N == 2048 and not args.no_side_legs and not args.reuse_cond_kv:
+        def side_leg(bs, sdt, k):
+            g2 = torch.Generator().manual_seed(77)
+            xs = x if bs == 1 else torch.randn(bs, N, 68, generator=g2).to(dev)
+            ys = y if bs == 1 else torch.randn(bs, L_COND, 768, generator=g2).to(dev)
+            st = step_stream(diffusion, model, xs, dict(y=ys, cfg_scale=6.0, precision_dtype=sdt, enable_amp=True))
+
+            def run(kk):
+                for _ in range(kk):
+                    last["side"] = next(st)
+            run(2)
+            el, _ = timed_repeats(run, k, max(1, args.repeats), 1, dist, dev)
+            assert torch.isfinite(last["side"]["sample"]).all(), "non-finite sample (side leg)"
+            e = statistics.median(el)
+            fl = 2 * bs * forward_flops(N, L_COND)
+            ln = 64 + (L_COND % 64 if L_COND > 64 else 0)
+            ex = fl - (bs * kv_projection_flops(L_COND) * (1.0 - ln / L_COND) if getattr(model, "dedup_null_kv", False) else 0.0)
+            return {"workload": workload_name(bs, N, "fp16" if sdt == torch.float16 else "bf16", "ddim25"), "steps": k,
+                    "ms_per_step": 1e3 * e / k, "value": bs * k / e, "unit": "denoise-steps/s",
+                    "repeats_ms_per_step": [1e3 * v / k for v in el],
+                    "algorithmic_tflops_per_step": fl / 1e12, "executed_tflops_per_step": ex / 1e12,
+                    "achieved_tflops_whole_step": ex * k / e / 1e12, "frac_of_mfma_peak_whole_step": ex * k / e / 1e12 / PEAK_TFLOPS}
+        side["batch8"] = side_leg(8, dt, 5)
+        side["bf16" if dt == torch.float16 else "fp16"] = side_leg(1, torch.bfloat16 if dt == torch.float16 else torch.float16, args.steps)
+        torch.cuda.empty_cache()
+
     # ddim: the rest of the metric (SURVEY.md section 8d metric (2)), outside the headline's timed region: the VAE leg on
     # this GPU, and ONE whole sampling job - the 25-step DDIM loop (plan + 25 x forward_with_cfg + update) followed by the
     # decode of its sample - timed end to end like inference.py:306-348 runs it.
@@ -461,17 +494,23 @@ def main() -> None:
                 "config": {"workload": workload_name(B, N, args.dtype, "ddim25"),
                            "parallelism": par, "weight_broadcast_bytes": wbytes, "reuse_cond_kv": bool(args.reuse_cond_kv)},
                 "samples_per_s_at_25_steps": steps_per_s / 25.0,
-                "algorithmic_tflops_per_step": flops_step / 1e12,
-                "achieved_tflops_whole_step": world * flops_step * args.steps / elapsed / 1e12,
-                "frac_of_mfma_peak_whole_step": flops_step * args.steps / elapsed / 1e12 / PEAK_TFLOPS})
-            if args.reuse_cond_kv:   # report against the UNREDUCED count, and the executed one next to it
+                "algorithmic_tflops_per_step": flops_step / 1e12})
+            # Rates are quoted against the FLOPs the step EXECUTES (round-3 review): the algorithmic count of the reference's step
+            # stands next to them, and the like-for-like timing of the unreduced work is `with_expanded_null_kv`.
+            ex = flops_step
+            if args.reuse_cond_kv:   # to_k / to_v of the conditioning tokens once per 25-step loop
                 ex = flops_step - B * kv_projection_flops(L_COND) * (1.0 - 1.0 / 25.0)
-                res["executed_tflops_per_step"] = ex / 1e12
             elif getattr(model, "dedup_null_kv", False) and L_COND >= 64:
                 # forward_with_cfg's unconditional half: L identical conditioning rows (null_cond_embedding.expand_as(y)) - 64 + L % 64
-                # of them are projected, the rates above stay against the UNREDUCED algorithmic count
+                # of them are projected
                 ln = 64 + (L_COND % 64 if L_COND > 64 else 0)
-                res["executed_tflops_per_step"] = (flops_step - B * kv_projection_flops(L_COND) * (1.0 - ln / L_COND)) / 1e12
+                ex = flops_step - B * kv_projection_flops(L_COND) * (1.0 - ln / L_COND)
+            res.update({"executed_tflops_per_step": ex / 1e12,
+                        "achieved_tflops_whole_step": world * ex * args.steps / elapsed / 1e12,
+                        "frac_of_mfma_peak_whole_step": ex * args.steps / elapsed / 1e12 / PEAK_TFLOPS,
+                        "flops_note": "achieved_tflops_whole_step / frac_of_mfma_peak_whole_step = EXECUTED FLOPs / time; "
+                                      "algorithmic_tflops_per_step is the reference's unreduced step (SURVEY.md section 8d)"})
+            if not args.reuse_cond_kv and getattr(model, "dedup_null_kv", False) and L_COND >= 64:
                 res["config"]["null_cond_kv"] = (f"the unconditional half's {L_COND} identical conditioning rows are projected once "
                                                  f"({ln} rows) and addressed as the {L_COND}-key sequence by the attention kernel "
                                                  "(bit-identical results); `with_expanded_null_kv` times the expanded form")
@@ -498,6 +537,9 @@ def main() -> None:
             res["with_reuse_cond_kv"] = reuse
         if expanded:
             res["with_expanded_null_kv"] = expanded
+        res.update(side)
+        if args.config in ("ddim", "c4"):
+            res["ln_in_gemm_tail"] = {"enabled": bool(getattr(model, "fuse_ln", False)), "sync_timeouts": ops.ln_sync_timeouts()}
         if prof:
             res["roofline"], res["kernels"] = kernel_report(prof, args.steps, traffic_file())
         if dleg:
@@ -548,7 +590,7 @@ def main() -> None:
                                  "rel_l2_vs_fp32_oracle": float((got - ref).norm() / ref.norm()), "primitives": int(z.shape[0]),
                                  "ref_abs_max": float(ref.abs().max())}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -7,8 +7,10 @@
  *   - every entry point returns 0 on success or a negative PRIMX_E* code; the message of the
  *     last failure on the calling thread is available from primx_last_error().
  *   - buffers are owned by the caller (PyTorch's caching allocator in the Python host); kernels
- *     keep no pointers after return and never allocate.  Work is enqueued on `stream` and is
- *     asynchronous with respect to the host.
+ *     keep no pointers after return and never allocate; the library keeps NO per-thread or global
+ *     state between calls that changes what a later call does (ABI 21: the cache-prefetch ranges
+ *     that GEMM / LayerNorm launches can carry are explicit arguments of the carrying call).
+ *     Work is enqueued on `stream` and is asynchronous with respect to the host.
  *   - `dtype` selects the 16-bit storage/MFMA-input type of activations and weights:
  *     PRIMX_F16 or PRIMX_BF16.  Accumulation is always fp32.
  *
@@ -28,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 20
+#define PRIMX_ABI_VERSION 21
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -71,10 +73,13 @@ int primx_padded_head_dim(int dh);
  * length D taken at element stride `mod_stride` between batch entries (they are chunks of the
  * adaLN output).  (1 + scale) is rounded to the 16-bit type first, as autocast does.
  * Replaces nn.LayerNorm(elementwise_affine=False, eps=1e-6) + modulate():
- * models/dit_crossattn.py:32-36,55-57,67,76 and models/utils.py:19-20.   D even, D <= 2048. */
+ * models/dit_crossattn.py:32-36,55-57,67,76 and models/utils.py:19-20.   D even, D <= 2048.
+ * pf0 / pf1 (each (pointer, bytes > 0) or (NULL, 0)): byte ranges that this launch also pulls into the caches - its grid gets
+ * extra leading workgroups that load one word per 128-byte line (D % 128 == 0 fast path; other shapes ignore the ranges).  Meant
+ * for the weights of the GEMMs that follow; results are unaffected.  The ranges must stay allocated until the launch has run. */
 int primx_layernorm_modulate(const float* x, const void* shift, const void* scale, int64_t mod_stride,
                              void* out, int dtype, int rows, int rows_per_batch, int D, float eps,
-                             void* stream);
+                             const void* pf0, int64_t pf0_bytes, const void* pf1, int64_t pf1_bytes, void* stream);
 
 /* emb[b, :] = [cos(t_b * f_k) | sin(t_b * f_k)], k < dim/2.  `freqs` (dim/2 floats, device) is the
  * table f_k = exp(-ln(max_period) * k / (dim/2)) that the reference also evaluates on the HOST before
@@ -97,20 +102,6 @@ int primx_point_features(const float* x, int64_t row_stride, const float* freqs,
  * stream while a compute-bound kernel (attention, LayerNorm) runs, for the weights of the GEMM that follows.  No counterpart
  * in the reference (its weights are whatever the caches hold); results are unaffected.  ABI 19. */
 int primx_prefetch(const void* ptr, int64_t bytes, void* stream);
-/* The same prefetch WITHOUT a launch of its own: registers [ptr, ptr + bytes) (at most two pending ranges per host thread) with
- * the next primx_layernorm_modulate call on this thread, whose grid gets extra leading workgroups that load one word per
- * 128-byte line (its D % 128 == 0 fast path; other shapes drop the hint).  A cross-stream prefetch costs an event pair per use
- * (+0.1 ms per DDIM step measured); riding on the LayerNorm that precedes every GEMM group costs nothing on the host.
- * (NULL, 0) drops the pending ranges: the ranges must still be allocated when the LayerNorm launch that carries them runs. */
-int primx_prefetch_hint(const void* ptr, int64_t bytes);
-/* The same, carried by a GEMM: the next primx_linear / primx_linear_residual / primx_linear_gate_residual / primx_linear_heads
- * call on this thread consumes the range (one pending range per host thread; launches that take a kernel without loader waves
- * drop it).  The compute waves of the loader-wave kernels never use their vector-memory queue inside the k-loop, so each of them
- * requests one word per 128-byte line of the range in front of the loop (at most 1024 lines per workgroup: 33.5 MB at 256
- * workgroups, longer ranges are cut) and the lines travel HBM -> Infinity Cache while the loop runs from L2.  Used for the weights
- * of the GEMM one or two launches ahead; results are unaffected.  (NULL, 0) drops a pending range.  ABI 20. */
-int primx_prefetch_hint_gemm(const void* ptr, int64_t bytes);
-
 /* out = cast16( silu(in) ) elementwise.  The SiLU in front of every adaLN Linear
  * (models/dit_crossattn.py:40-43,69-72) producing the 16-bit GEMM operand. */
 int primx_silu_cast(const float* in, void* out, int dtype, int64_t n, void* stream);
@@ -129,6 +120,13 @@ int primx_linear_f32(const float* in, const float* W, const float* bias, float* 
 /* ----------------------------------------------------------------------------------------------
  * MFMA GEMMs with fused epilogues.  A: [M, K] 16-bit row-major activations; W: [N, K] 16-bit,
  * nn.Linear (out, in) layout; bias: [N] 16-bit or NULL.  K % 8 == 0.  fp32 accumulate.
+ * `prefetch` / `prefetch_bytes` ((pointer, bytes > 0) or (NULL, 0)) of primx_linear, primx_linear_gate_residual[_ln] and
+ * primx_linear_heads: a byte range - the weights of a GEMM one or two launches ahead - that THIS launch pulls towards the caches.
+ * The compute waves of the loader-wave kernels never use their vector-memory queue inside the k-loop, so each of them requests
+ * one word per 128-byte line of the range in front of the loop (at most 1024 lines per workgroup: 33.5 MB at 256 workgroups,
+ * longer ranges are cut) and the lines travel HBM -> Infinity Cache while the loop runs from L2.  Launches that take a kernel
+ * without loader waves ignore the range; results are unaffected; the range must stay allocated until the launch has run.
+ * No counterpart in the reference (its weights are whatever the caches hold).
  * -------------------------------------------------------------------------------------------- */
 
 /* out[M, N] (16-bit) = out_scale * act(A W^T + bias), each stage rounded to the 16-bit type as
@@ -136,14 +134,34 @@ int primx_linear_f32(const float* in, const float* W, const float* bias, float* 
  * last rounding.  Replaces nn.Linear under autocast: Mlp.fc1 + GELU(tanh) (models/utils.py:87-96,
  * dit_crossattn.py:38), adaLN Linear (dit_crossattn.py:40-43), FinalLayer.linear (:68). */
 int primx_linear(const void* A, const void* W, const void* bias, void* out, int M, int N, int K, int dtype,
-                 int act, float out_scale, void* stream);
+                 int act, float out_scale, const void* prefetch, int64_t prefetch_bytes, void* stream);
 
 /* x[m, :] += cast16( gate[b, :] * cast16(A W^T + bias)[m, :] ),  b = m / rows_per_batch, x fp32.
  * Replaces the projection Linear + gated residual `x = x + gate.unsqueeze(1) * branch`:
  * attention.py:56,111 / models/utils.py:98 with dit_crossattn.py:55-57. */
 int primx_linear_gate_residual(const void* A, const void* W, const void* bias, const void* gate,
                                int64_t gate_stride, float* x, int M, int N, int K, int rows_per_batch,
-                               int dtype, void* stream);
+                               int dtype, const void* prefetch, int64_t prefetch_bytes, void* stream);
+
+/* primx_linear_gate_residual FOLLOWED BY primx_layernorm_modulate of the updated rows, as one call:
+ *   x[m, :] += cast16(gate[b, :] * cast16(A W^T + bias)[m, :]);   ln_out[m, :] = cast16( LN(x[m, :]) * (1 + ln_scale[b, :]) + ln_shift[b, :] )
+ * - in a DiT block every gated residual add is followed by the LayerNorm + modulate of the next branch (or of the next block, or of
+ * the final layer): models/dit_crossattn.py:55-57,76.  Results are bit-identical to the two separate calls.  Where the shape allows
+ * (N == 1152, M a multiple of 128 * 8 up to its last ragged block, the loader-wave 128 x 144 kernel) the LayerNorm runs in the
+ * TAIL of the GEMM kernel: the column-tile workgroups of a 128-row block count themselves in on `sync`, wait for each other and
+ * normalise 16 rows each from the L2 they share - one dependent launch less per LayerNorm (85 per DDIM step).  Otherwise the
+ * library launches the two kernels.  `sync`: device memory, two 32-bit words per 128-row block (sync_words >= 2 * ceil(M / 128)),
+ * zeroed once by the caller; every launch leaves them zero; launches that use the same words must be ordered by the stream.
+ * sync == NULL always takes the two-launch route.  primx_last_gemm_kernel() tells which route ran ("gemm144l_dma_kernel<dt, 5>" =
+ * fused).  ABI 21. */
+int primx_linear_gate_residual_ln(const void* A, const void* W, const void* bias, const void* gate, int64_t gate_stride,
+                                  float* x, int M, int N, int K, int rows_per_batch, const void* ln_shift, const void* ln_scale,
+                                  int64_t ln_mod_stride, void* ln_out, float ln_eps, void* sync, int64_t sync_words, int dtype,
+                                  const void* prefetch, int64_t prefetch_bytes, void* stream);
+/* Number of in-kernel waits of primx_linear_gate_residual_ln that gave up (~1 s each) since the library was loaded: 0 unless the
+ * dispatch-order assumption of the fused route is violated on this machine (then PRIMX_LN_FUSE=0 selects the two-launch route).
+ * Synchronises with the device.  ABI 21. */
+int primx_ln_sync_timeouts(void);
 
 /* Projection whose output columns are `n_rep` repetitions of `n_seg` groups of (heads * dh) features
  * (N = n_rep * n_seg * heads * dh), each group written straight into an attention operand layout (see
@@ -156,7 +174,8 @@ int primx_linear_gate_residual(const void* A, const void* W, const void* bias, c
  * (attention.py:105-107). */
 int primx_linear_heads(const void* A, const void* W, const void* bias, int M, int N, int K, int rows_per_batch,
                        int heads, int dh, int n_seg, const int* kind, void* const* dst, int n_rep,
-                       int rep_batches, int n_pad, float scale0, int dtype, void* stream);
+                       int rep_batches, int n_pad, float scale0, int dtype, const void* prefetch, int64_t prefetch_bytes,
+                       void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Attention (flash-style, fp32 online softmax, MFMA 32x32x16)

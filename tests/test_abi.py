@@ -57,9 +57,15 @@ def test_argument_validation_without_gpu(lib):
     h = lib.load()
     assert h.primx_attention(None, None, None, None, 1, 1, 1, 128, 1, 64, 72, 1.0, 1, None) == -1
     assert b"null" in h.primx_last_error()
-    assert h.primx_layernorm_modulate(1, 1, 1, 0, 1, 1, 4, 4, 101, 1e-6, None) == -1   # D odd
-    assert h.primx_linear(1, 1, None, 1, 4, 4, 70, 1, 0, 1.0, None) == -1               # K % 8 != 0
-    assert h.primx_linear(1, 1, None, 1, 4, 4, 64, 7, 0, 1.0, None) == -1               # bad dtype
+    assert h.primx_layernorm_modulate(1, 1, 1, 0, 1, 1, 4, 4, 101, 1e-6, None, 0, None, 0, None) == -1   # D odd
+    assert h.primx_linear(1, 1, None, 1, 4, 4, 70, 1, 0, 1.0, None, 0, None) == -1      # K % 8 != 0
+    assert h.primx_linear(1, 1, None, 1, 4, 4, 64, 7, 0, 1.0, None, 0, None) == -1      # bad dtype
+    assert h.primx_linear(1, 1, None, 1, 4, 4, 64, 1, 0, 1.0, None, 128, None) == -1    # a prefetch range is (pointer, bytes) or (NULL, 0)
+    assert b"prefetch" in h.primx_last_error()
+    # the fused gate-residual + LayerNorm entry: a LayerNorm output needs its modulation vectors, sync two words per row block
+    assert h.primx_linear_gate_residual_ln(1, 1, None, 1, 0, 1, 256, 1152, 64, 256, None, None, 0, 1, 1e-6, None, 0, 1, None, 0, None) == -1
+    assert h.primx_linear_gate_residual_ln(1, 1, None, 1, 0, 1, 256, 1152, 64, 256, 1, 1, 0, 1, 1e-6, 1, 3, 1, None, 0, None) == -1
+    assert b"sync" in h.primx_last_error()
     with pytest.raises(lib.PrimxError):
         lib.check(-1, "primx_linear")
 

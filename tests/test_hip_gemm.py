@@ -292,10 +292,11 @@ def test_two_pass_big_tile_edges(ops, dtype, M, K):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_gemm_carried_prefetch_changes_nothing(ops, dtype):
-    """primx_prefetch_hint_gemm (`carry=`): the compute waves of the loader-wave kernels touch the lines of another tensor in
-    front of their k-loop.  Results are bit-identical with and without it on every carrying kernel (128 x 144 loader-wave
-    Linear / gate-residual / heads, two-pass 256 x 288), a range longer than the launch covers is cut, a range of a few bytes
-    works, kernels without loader waves drop the hint, and a pending hint does not survive the launch that followed it."""
+    """The `prefetch` range of the GEMM entry points (`carry=`; an explicit argument since ABI 21): the compute waves of the
+    loader-wave kernels touch the lines of another tensor in front of their k-loop.  Results are bit-identical with and without
+    it on every carrying kernel (128 x 144 loader-wave Linear / gate-residual / heads, two-pass 256 x 288), a range longer than
+    the launch covers is cut, a range of a few bytes works, kernels without loader waves ignore it, and nothing is remembered
+    from one call to the next (a launch after the range was freed touches nothing)."""
     from topia_xl_amd import _lib
     lib = _lib.load()
     T, D, H, dh = 4096, 1152, 16, 72
@@ -325,15 +326,92 @@ def test_gemm_carried_prefetch_changes_nothing(ops, dtype):
     W4 = synth.tensor(51, "W4", (4 * D, D), D ** -0.5).to(dtype).to(DEV)
     assert torch.equal(ops.linear(Ad, W4, None, act=1, carry=other), ops.linear(Ad, W4, None, act=1))
     assert torch.equal(ops.linear(Ad, Wd[:136].contiguous(), bd[:136], carry=other), ops.linear(Ad, Wd[:136].contiguous(), bd[:136]))
-    # the entry point itself: bad arguments are errors, (NULL, 0) drops
-    assert lib.primx_prefetch_hint_gemm(None, 5) != 0
-    assert lib.primx_prefetch_hint_gemm(other.data_ptr(), other.numel() * 4) == 0
-    assert lib.primx_prefetch_hint_gemm(None, 0) == 0
-    # freed memory must not be touched by a later launch: the hint is consumed by the launch that follows it
+    # the argument itself: a range is (pointer, bytes > 0) or (NULL, 0)
+    out = torch.empty(T, D, dtype=dtype, device=DEV)
+    args = (Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), out.data_ptr(), T, D, D, ops.dtype_code(dtype), 0, 1.0)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.primx_linear(*args, None, 5, st) != 0
+    assert lib.primx_linear(*args, other.data_ptr(), 0, st) != 0
+    # the library keeps no range between calls: a launch after the carried tensor was freed touches nothing of it
     scratch = torch.empty(1 << 20, device=DEV)
-    assert lib.primx_prefetch_hint_gemm(scratch.data_ptr(), scratch.numel() * 4) == 0
-    ops.linear(Ad, Wd, bd)                                                       # consumes it
+    ops.linear(Ad, Wd, bd, carry=scratch)
     del scratch
     torch.cuda.empty_cache()
     assert torch.equal(ops.linear(Ad, Wd, bd), base)
     torch.cuda.synchronize()
+
+
+def _ln_ref(x, shift, scale, rows_per_batch, dtype, eps=1e-6):
+    """float64 LayerNorm (no affine) + modulate with the autocast rounding point of (1 + scale)."""
+    xd = x.double()
+    mu = xd.mean(-1, keepdim=True)
+    var = ((xd - mu) ** 2).mean(-1, keepdim=True)
+    b = torch.arange(x.shape[0]) // rows_per_batch
+    m1 = (1.0 + scale.float()).to(dtype).double()[b]
+    return (xd - mu) / torch.sqrt(var + eps) * m1 + shift.double()[b]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,rpb", [(4096, 1152, 2048), (4096, 4608, 2048), (2048, 1152, 1024), (1024 - 77, 192, 300), (8192, 64, 2048)])
+def test_gate_residual_with_layernorm_tail(ops, dtype, M, K, rpb):
+    """primx_linear_gate_residual_ln (round 4): the LayerNorm + modulate that follows a gated residual add, in the tail of the
+    GEMM kernel.  (a) the fused kernel is what runs at these shapes (N = 1152, M in whole groups of 8 row blocks, ragged last
+    block included); (b) x and the LayerNorm output are BIT-IDENTICAL to the two separate calls; (c) both agree with float64;
+    (d) the sync words are zero again after every launch; (e) no in-kernel wait timed out; (f) repeated back-to-back launches
+    on the same words (the DiT's three per block) keep all of that."""
+    from topia_xl_amd import _lib
+    N = 1152
+    A, W, b, ref = _mk(61, M, N, K, dtype)
+    nb = (M + rpb - 1) // rpb
+    gate = synth.tensor(61, "gate", (nb, N), 0.5).to(dtype)
+    mod = synth.tensor(61, "mod", (nb, 2 * N), 0.3).to(dtype)            # [shift | scale] rows with a stride of 2 N
+    x0 = synth.tensor(61, "x", (M, N), 2.0, 0.3)
+    Ad, Wd, bd, gd, md = A.to(DEV), W.to(DEV), b.to(DEV), gate.to(DEV), mod.to(DEV)
+    sh, sc = md[:, :N], md[:, N:]
+    # two separate calls
+    xa = x0.to(DEV)
+    ops.linear_gate_residual(Ad, Wd, bd, gd, xa, rpb)
+    lna = ops.layernorm_modulate(xa, sh, sc, rpb, torch.empty(M, N, dtype=dtype, device=DEV))
+    # one call
+    sync = torch.zeros(ops.ln_sync_words(M), dtype=torch.int32, device=DEV)
+    t0 = ops.ln_sync_timeouts()
+    for rep in range(3):
+        xb = x0.to(DEV)
+        lnb = torch.full((M + 1, N), 7.0, dtype=dtype, device=DEV)       # canary row behind the last one
+        ops.linear_gate_residual(Ad, Wd, bd, gd, xb, rpb, ln=(sh, sc, lnb[:M], 1e-6, sync))
+        if _default_dispatch():
+            assert _lib.load().primx_last_gemm_kernel().decode().startswith("gemm144l_dma_kernel") and \
+                _lib.load().primx_last_gemm_kernel().decode().endswith(", 5>"), _lib.load().primx_last_gemm_kernel()
+        assert torch.equal(xa, xb), rep
+        assert torch.equal(lna, lnb[:M]), (rep, max_abs(lna, lnb[:M]))
+        assert float(lnb[M].float().min()) == 7.0 and float(lnb[M].float().max()) == 7.0
+        assert int(sync.abs().sum()) == 0
+    assert ops.ln_sync_timeouts() == t0
+    # float64
+    bidx = torch.arange(M) // rpb
+    r16 = lambda t: t.to(dtype).double()
+    xr = x0.double() + r16(gate.double()[bidx] * r16(ref))
+    assert rel_l2(xa, xr) < 1e-3
+    assert rel_l2(lna, _ln_ref(xa.cpu(), mod[:, :N], mod[:, N:], rpb, dtype)) < TOL[dtype]
+
+
+def test_gate_residual_layernorm_two_launch_route(ops):
+    """Shapes the tail does not cover (N != 1152, row blocks not in groups of 8, no sync words) take the two-launch route inside
+    the same entry point: same results as the separate calls, and the library says which kernel ran."""
+    from topia_xl_amd import _lib
+    dtype = torch.float16
+    for (M, N, K, rpb, with_sync) in ((300, 288, 128, 100, True), (384, 1152, 64, 384, True), (4096, 1152, 64, 2048, False)):
+        A, W, b, _ = _mk(62, M, N, K, dtype)
+        nb = (M + rpb - 1) // rpb
+        gd = synth.tensor(62, "gate", (nb, N), 0.5).to(dtype).to(DEV)
+        sh = synth.tensor(62, "sh", (nb, N), 0.3).to(dtype).to(DEV)
+        sc = synth.tensor(62, "sc", (nb, N), 0.3).to(dtype).to(DEV)
+        x0 = synth.tensor(62, "x", (M, N))
+        xa, xb = x0.to(DEV), x0.to(DEV)
+        ops.linear_gate_residual(A.to(DEV), W.to(DEV), b.to(DEV), gd, xa, rpb)
+        lna = ops.layernorm_modulate(xa, sh, sc, rpb, torch.empty(M, N, dtype=dtype, device=DEV))
+        sync = torch.zeros(ops.ln_sync_words(M), dtype=torch.int32, device=DEV) if with_sync else None
+        lnb = torch.empty(M, N, dtype=dtype, device=DEV)
+        ops.linear_gate_residual(A.to(DEV), W.to(DEV), b.to(DEV), gd, xb, rpb, ln=(sh, sc, lnb, 1e-6, sync))
+        assert not _lib.load().primx_last_gemm_kernel().decode().endswith(", 5>")
+        assert torch.equal(xa, xb) and torch.equal(lna, lnb)

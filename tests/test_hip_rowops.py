@@ -137,23 +137,22 @@ def test_pack_heads_layouts(ops, dtype):
 
 
 def test_prefetch_entry_points_change_nothing(ops):
-    """primx_prefetch / primx_prefetch_hint only pull bytes into the caches: the LayerNorm launch that carries a hint gives the
-    same bits as one without, a third pending hint is refused, and a launch consumes the hints."""
-    from topia_xl_amd._lib import PrimxError
+    """primx_prefetch and the pf0 / pf1 ranges of primx_layernorm_modulate only pull bytes into the caches: the LayerNorm launch
+    that carries ranges gives the same bits as one without, a third range is refused by the wrapper, and nothing is kept
+    between calls (explicit arguments since ABI 21)."""
     x = synth.tensor(5, "x", (300, 1152)).to(DEV)
     sh = synth.tensor(5, "sh", (3, 1152), 0.3).half().to(DEV)
     sc = synth.tensor(5, "sc", (3, 1152), 0.3).half().to(DEV)
     w1 = torch.randn(1152, 1152, device=DEV).half()
     w2 = torch.randn(777, 64, device=DEV).half()            # a byte count that is not a multiple of a line
-    plain = ops.layernorm_modulate(x, sh, sc, 100, torch.empty(300, 1152, dtype=torch.float16, device=DEV))
-    ops.prefetch_hint(w1)
-    ops.prefetch_hint(w2)
-    with pytest.raises(PrimxError):
-        ops.prefetch_hint(w1)
-    hinted = ops.layernorm_modulate(x, sh, sc, 100, torch.empty(300, 1152, dtype=torch.float16, device=DEV))
-    assert torch.equal(plain, hinted)
-    ops.prefetch_hint(w1)                                    # the launch above consumed both: there is room again
-    again = ops.layernorm_modulate(x, sh, sc, 100, torch.empty(300, 1152, dtype=torch.float16, device=DEV))
-    assert torch.equal(plain, again)
+    new = lambda: torch.empty(300, 1152, dtype=torch.float16, device=DEV)
+    plain = ops.layernorm_modulate(x, sh, sc, 100, new())
+    assert torch.equal(plain, ops.layernorm_modulate(x, sh, sc, 100, new(), prefetch=(w1, w2)))
+    assert torch.equal(plain, ops.layernorm_modulate(x, sh, sc, 100, new(), prefetch=(w2,)))
+    with pytest.raises(RuntimeError):
+        ops.layernorm_modulate(x, sh, sc, 100, new(), prefetch=(w1, w2, w1))
+    del w1
+    torch.cuda.empty_cache()
+    assert torch.equal(plain, ops.layernorm_modulate(x, sh, sc, 100, new()))
     ops.prefetch(w2, torch.cuda.current_stream())
     torch.cuda.synchronize()

@@ -152,6 +152,49 @@ def test_packed_file_round_trip_and_layout_check(pkg, tmp_path):
         bogus = str(tmp_path / "x.primxpk")
         open(bogus, "wb").write(b"\0" * 64)
         pkg.DiT(**_SMALL_DIT).load_packed(bogus)
+    # a file of an older header format is refused with a message that says what to do (round-3 advisor finding: format 1 had
+    # two incompatible layouts and answered "packed for a different model")
+    import json
+    raw = bytearray(open(path, "rb").read())
+    hlen = int.from_bytes(raw[8:16], "little")
+    head = json.loads(bytes(raw[16:16 + hlen]))
+    assert head["format"] == pkg.DiT.PACKED_FORMAT == 2
+    old_head = json.dumps({**head, "format": 1}, sort_keys=True).encode()
+    assert len(old_head) == hlen
+    raw[16:16 + hlen] = old_head
+    legacy = str(tmp_path / "legacy.primxpk")
+    open(legacy, "wb").write(bytes(raw))
+    with pytest.raises(RuntimeError, match="repack required"):
+        pkg.DiT(**_SMALL_DIT).load_packed(legacy)
+
+
+def test_attention_workspaces_shared_between_shape_groups_survive_the_first_owner(pkg, monkeypatch):
+    """Round-3 advisor finding: a workspace key used by several shape groups (the broadcast entries do not depend on the batch
+    size) was owned by the group that allocated it first and freed with it.  Every using group now holds it."""
+    from importlib import import_module
+    ops = import_module(pkg.__name__ + ".ops")
+    m = pkg.DiT(**_SMALL_DIT)
+    made = []
+    monkeypatch.setattr(ops, "alloc_heads", lambda *a, **k: made.append(a) or torch.zeros(1))
+    dt, dev = torch.float16, "cpu"
+    m._heads_begin("g1")
+    shared = m._heads("Kn", 2, 90, 2, dt, dev, 64)
+    m._heads("Qs", 2, 16, 0, dt, dev, 128)
+    m._heads_begin("g2")
+    assert m._heads("Kn", 2, 90, 2, dt, dev, 64) is shared and len(made) == 2          # a hit: g2 now holds it too
+    m._heads("Qs", 4, 16, 0, dt, dev, 128)
+    m._heads_begin("g3")
+    m._heads_begin("g4")                                                                # evicts g1 (three groups stay)
+    assert "g1" not in m._heads_lru
+    m._heads_group = "g2"
+    assert m._heads("Kn", 2, 90, 2, dt, dev, 64) is shared and len(made) == 3          # still there: g2 uses it
+    n = len(made)
+    m._heads("Qs", 2, 16, 0, dt, dev, 128)                                              # g1's private workspace is gone
+    assert len(made) == n + 1
+    m._heads_begin("g5")                                                                # evicts g2: now the last user is gone
+    m._heads_group = "g5"
+    m._heads("Kn", 2, 90, 2, dt, dev, 64)
+    assert len(made) == n + 2
 
 
 def test_load_checkpoints_takes_the_packed_routes(pkg, tmp_path):

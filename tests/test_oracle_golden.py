@@ -88,6 +88,21 @@ def test_ddim_trajectory_matches_reference(golden):
     _close(logvar, g["pmv_log_variance"], atol=1e-3)
 
 
+def test_configs0_named_shape_trajectory_matches_reference(golden):
+    """BASELINE configs[0] at its named shape (depth 12, d = 384, 6 heads, N_prim = 256, one condition token, 5 DDIM steps with
+    CFG; tests/golden/make_golden_xl.py `c1_named`): the oracle's loop against the unmodified reference's."""
+    from tests.golden.make_golden_xl import C1, C1_HEADS, XL_SEED, xl_inputs
+    depth, N, B, stride, x, y = xl_inputs("c1_named")
+    g = golden("c1_named")
+    sd = synth.dit_state_dict(XL_SEED, depth=depth, **C1)
+    tab, tmap = dref.make("squaredcos_cap_v2", 1000, "ddim5")
+    model = lambda xx, tt, **kw: dit_ref.dit_forward_with_cfg(sd, xx, tt, y, C1_HEADS, 6.0)
+    outs = dref.ddim_loop(model, x, tab, tmap, "v", 0.0, False)
+    assert (depth, N, tuple(y.shape)) == (12, 256, (1, 1, 768)) and np.abs(g["ddim5_samples"][-1]).max() > 0.1
+    _close(np.stack([o["sample"].numpy() for o in outs]), g["ddim5_samples"], atol=2e-3)
+    _close(outs[-1]["pred_xstart"], g["ddim5_final_pred_xstart"], atol=2e-3)
+
+
 def test_attention_modules_match_reference(golden):
     g = golden("attention")
     # MemEffAttention(dim=256, heads=8, qkv_bias=False)  /  MemEffCrossAttention(dim=144, heads=2)
