@@ -48,44 +48,8 @@ constexpr int QPAD = 128;   // granularity of nq_pad (the Q operand buffers)
 constexpr int NW = 8;       // waves per workgroup: all of them share every K / V^T tile the workgroup stages
 constexpr int BQ = 32 * NW; // query rows per workgroup
 constexpr int BKV = 64;     // keys per tile
-#ifndef PRIMX_ATTN_LDS_EPI
-#define PRIMX_ATTN_LDS_EPI 1     // output tile transposed through LDS: 16-byte row-major stores
-#endif
-#ifndef PRIMX_ATTN_NSTAGE
-#define PRIMX_ATTN_NSTAGE 3
-#endif
-#ifndef PRIMX_ATTN_ALLREADS_L
-#define PRIMX_ATTN_ALLREADS_L 1   // 1: the second V^T half is read in the light segment too (matrix segment without LDS reads; same box 58.5 -> 56.9 us)
-#endif
-#ifndef PRIMX_ATTN_PRIO
-#define PRIMX_ATTN_PRIO 1   // 1: s_setprio 1 around every matrix segment (same-box: 58.1 vs 59.5 us); 2: static prio for group 1 (no gain); 0: off
-#endif
-constexpr int NSTAGE = PRIMX_ATTN_NSTAGE;   // LDS ring depth (3..6 fit one workgroup per CU)
-#ifndef PRIMX_ATTN_QKPV_MIX
-#define PRIMX_ATTN_QKPV_MIX 1   // 1 (with EXP0_IN_L): the first PV MFMAs are interleaved with the QK^T MFMAs
-#endif
-#ifndef PRIMX_ATTN_EXP0_IN_L
-#define PRIMX_ATTN_EXP0_IN_L 1   // 1: the exponentials of a tile's first 32 keys are formed in the light segment (needs MAX_IN_M or max in light before it)
-#endif
-#ifndef PRIMX_ATTN_DMA_IN_M
-#define PRIMX_ATTN_DMA_IN_M 1   // 1: the LDS-DMA of the next pair is issued in the MATRIX segment (behind the QK^T MFMAs) instead of the light one
-#endif
-#ifndef PRIMX_ATTN_MAX_IN_M
-#define PRIMX_ATTN_MAX_IN_M 0   // 1: the row max of the next tile's scores is taken at the end of the matrix segment instead of in the light one
-#endif
-#ifndef PRIMX_ATTN_REGSTAGE
-#define PRIMX_ATTN_REGSTAGE 0   // 1: K / V^T tiles staged through registers (global_load + ds_write) instead of LDS-DMA - measured neutral (54.1 vs 53.9 us)
-#endif
-#ifndef PRIMX_ATTN_QCOL
-#define PRIMX_ATTN_QCOL 1   // 1: running max subtracted by the MFMA through Q's spare columns (dh = 72), see attn_kernel (alone it unbalances the two segments: 58 - 65 vs 54 us; with DMA_IN_M + EXP0_IN_L + QKPV_MIX 49 us)
-#endif
-#ifndef PRIMX_ATTN_RTZ
-#define PRIMX_ATTN_RTZ 1   // 1: probabilities packed to 16 bits with round-toward-zero (full-rate v_cvt_pkrtz_f16_f32 / v_perm_b32; the
-#endif                     // round-to-nearest pack is quarter rate); the half-ulp bias cancels in the normalisation (same values sum to the denominator)
-#ifndef PRIMX_ATTN_RESCALE_THR
-#define PRIMX_ATTN_RESCALE_THR 8.0f
-#endif
-constexpr float RESCALE_THR = PRIMX_ATTN_RESCALE_THR;   // exp2-domain growth of the row max tolerated before O is rescaled
+constexpr int NSTAGE = 3;  // LDS ring depth (3..6 fit one workgroup per CU; deeper rings measured no better)
+constexpr float RESCALE_THR = 8.0f;   // exp2-domain growth of the row max tolerated before O is rescaled
 constexpr int WAITCNT_LGKM0 = 0xC07F;   // s_waitcnt simm16 on gfx9: vmcnt = 63 (no wait), expcnt = 7 (no wait), lgkmcnt = 0
 
 template <typename V8>
@@ -94,8 +58,10 @@ __device__ __forceinline__ V8 ldg16(const void* ptr) {
     return *reinterpret_cast<GV8*>(reinterpret_cast<uintptr_t>(ptr));
 }
 
-// PROF: phase profile - s_memtime stamps at the segment boundaries, summed per wave into g_attn_prof (PRIMX_ATTN_PROF):
-// 1 = all waves, 2 = group 1 only keeps the barriers (what does a matrix segment cost without a partner?)
+// PROF = 1: phase profile - cycle stamps at the segment boundaries, summed per wave into g_attn_prof (PRIMX_ATTN_PROF=1).
+// (The schedule variants that lost their same-box A/Bs - register staging, DMA issue / first exponentials / second V^T half in
+// the other segment, deeper rings, static priorities, round-to-nearest pack, the "one wave group idle" probe - were build-time
+// switches until round 4; their measurements are in DESIGN_LOG.md section 5.)
 __device__ unsigned long long g_attn_prof[8];
 
 template <int DT, int KSTEPS, int DTILES, int KMASK, int PROF = 0>
@@ -154,7 +120,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     // -m_hi / -m_lo - the running row max split into two 16-bit halves - against constant ones in K (ops.alloc_heads): the
     // MFMA itself subtracts the max (exact products, fp32 accumulation) and a probability is ONE v_exp_f32 of an accumulator
     // register: no scale / subtract VALU work (16 v_pk_fma_f32 per wave and tile before).
-    constexpr bool QCOL = PRIMX_ATTN_QCOL && !KMASK && (16 * KSTEPS - 3 >= 16 * (KSTEPS - 1) + 8);   // the three columns lie in the hi half of the last fragment
+    constexpr bool QCOL = !KMASK && (16 * KSTEPS - 3 >= 16 * (KSTEPS - 1) + 8);   // the three columns lie in the hi half of the last fragment
     // (loaded by load_q() BEHIND the prologue's DMA issue: with the Q loads first hipcc waited vmcnt(0) for them - and for the three K(0)
     // pieces issued after them - before it scaled Q, and only then issued pairs 0 and 1: two memory round trips in series in front
     // of the first MFMA of every launch)
@@ -215,30 +181,6 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
         }
     };
     [[maybe_unused]] auto issue_pair = [&](int jp, int stage) { issue_run(jp + 1 - grp, stage); };   // {K(jp+1), V(jp)}
-#if PRIMX_ATTN_REGSTAGE
-    // Register staging of the same pieces into the same LDS image: global_load_dwordx4 in the light segment of step j,
-    // ds_write_b128 at the start of the light segment of step j+1 (visible behind the barriers in front of step j+2, where
-    // the pair is read - the timeline of the DMA form).  One global_load_lds costs its wave 150 - 330 ISSUE cycles in the
-    // light segment (PRIMX_ATTN_PROF: 445 - 1000 cycles for three, more the denser the partner's matrix segment issues); a
-    // load + ds_write pair ~20.  With the matrix segment down to ~720 - 750 cycles (QCOL) the light segment is the pole.
-    V8 stg[NSLOT];
-    int pend_stage = -1;                                        // stage the registers' pair belongs to (wave-uniform)
-    auto gload_run = [&](int tile) {
-        const S* tb = role_base + (int64_t)tile_at(tile) * tile_stride;
-#pragma unroll
-        for (int i = 0; i < NSLOT; ++i) {
-            const int pc = run_first + min(i, run_len - 1);
-            stg[i] = ldg16<V8>(tb + pc * piece_stride + ((pc & 1) ? lane_off1 : lane_off0));
-        }
-    };
-    auto write_run = [&](int stage) {
-#pragma unroll
-        for (int i = 0; i < NSLOT; ++i) {
-            const int pc = run_first + min(i, run_len - 1);
-            *reinterpret_cast<V8*>(smem + stage * BUF + (grp * NK + pc) * 512 + lane * 8) = stg[i];
-        }
-    };
-#endif
 
     f32x16 o[DTILES];
 #pragma unroll
@@ -304,9 +246,8 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
-                if constexpr (QCOL) {   // the score already is (s * c - m): one exponential, round-toward-zero pack (PRIMX_ATTN_RTZ)
+                if constexpr (QCOL) {   // the score already is (s * c - m): one exponential, round-toward-zero pack
                     const float p0 = __builtin_amdgcn_exp2f(sh[8 * k2 + e]), p1 = __builtin_amdgcn_exp2f(sh[8 * k2 + e + 1]);
-#if PRIMX_ATTN_RTZ
                     if constexpr (DT == PRIMX_F16) {
                         const auto h2 = __builtin_amdgcn_cvt_pkrtz(p0, p1);
                         pb[k2][e] = h2[0];
@@ -318,10 +259,6 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
                         pb[k2][e] = h2[0];
                         pb[k2][e + 1] = h2[1];
                     }
-#else
-                    pb[k2][e] = (S)p0;
-                    pb[k2][e + 1] = (S)p1;
-#endif
                 } else {
                     const f32x2 sv = {sh[8 * k2 + e], sh[8 * k2 + e + 1]};
                     const f32x2 arg = __builtin_elementwise_fma(sv, (f32x2){c, c}, (f32x2){-mc, -mc});   // v_pk_fma_f32
@@ -346,11 +283,10 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     } while (0)
 #define PRIMX_ATTN_WAITB() PRIMX_ATTN_WAITB_N(NFLY)
     constexpr int NFLY = NSLOT * (NSTAGE - 2);   // DMAs of the pairs newer than the one the next light segment reads
-    // The barrier BEHIND a light segment.  DMA in the light segment: the pair the segment just issued may fly (NFLY).  DMA in
-    // the matrix segment (PRIMX_ATTN_DMA_IN_M): nothing was issued since the previous matrix segment, and what that one
+    // The barrier BEHIND a light segment.  The DMA of the next pair is issued in the MATRIX segment: nothing was issued since the previous matrix segment, and what that one
     // issued is read by the OTHER group's next light segment, which starts behind this very barrier - everything must
     // have landed (a first build waited vmcnt(NFLY) here too: stale tiles, NaNs on some launches).
-    constexpr int NFLY_L = (PRIMX_ATTN_DMA_IN_M && !PRIMX_ATTN_REGSTAGE) ? 0 : NFLY;
+    constexpr int NFLY_L = 0;
     unsigned long long pt = 0, pl = 0, pm = 0, pw = 0, pn = 0, pl_dma = 0, pl_rd = 0;
     auto stamp = [&](unsigned long long& acc) {
         if (PROF) {
@@ -359,8 +295,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
             pt = now;
         }
     };
-    const bool idle = PROF == 2 && grp;   // profiling only: this wave keeps the barriers and does nothing else
-    [[maybe_unused]] V8 pb0_l[2];   // PRIMX_ATTN_EXP0_IN_L: probabilities of the first 32 keys, formed in the light segment
+    [[maybe_unused]] V8 pb0_l[2];   // probabilities of the first 32 keys, formed in the light segment
     auto fold_max = [&](f32x16 (&sc)[2], bool first) {   // row max of a fresh score tile + the (rare) rescale
         float mx = fmaxf(sc[0][0], sc[1][0]);
 #pragma unroll
@@ -409,31 +344,17 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     // row max of S(j) and the (rare) rescale of O.
     auto seg_light = [&](int st, int st_refill, int jp, f32x16 (&sc)[2], V8 (&kf)[2][KSTEPS], V8 (&vf0)[DTILES][2],
                          V8 (&vf1)[DTILES][2], bool first) {
-        if (idle) return;
-#if PRIMX_ATTN_REGSTAGE
-        if (pend_stage >= 0) write_run(pend_stage);   // the pair fetched one step ago
-        gload_run(jp + 1 - grp);
-        pend_stage = st_refill;
-#elif !PRIMX_ATTN_DMA_IN_M
-        issue_pair(jp, st_refill);
-#endif
         if (PROF) { __builtin_amdgcn_sched_barrier(0); stamp(pl_dma); }
         read_k(st, kf);
         read_v(st, 0, vf0);
-#if PRIMX_ATTN_ALLREADS_L
         read_v(st, 1, vf1);
-#endif
         if (PROF) { __builtin_amdgcn_sched_barrier(0); stamp(pl_rd); }
-#if !PRIMX_ATTN_MAX_IN_M
         fold_max(sc, first);
-#endif
-#if PRIMX_ATTN_EXP0_IN_L
         {   // the exponentials of the tile's first 32 keys here: the matrix segment is at its issue bound, this one is not
             float psum0 = 0.f;
             probs(sc[0], m_run * c, psum0, pb0_l);
             if (KMASK) l_run += psum0;
         }
-#endif
     };
     // MATRIX segment of step j: QK^T(j+1) with the exponentials of the first 32 keys of tile j in its shadow, PV of
     // those keys with the exponentials of the other 32 in its shadow, PV of the rest.  All operands of the first 16
@@ -441,17 +362,10 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     // (Moving the first exponentials into the light segment was measured: the matrix segment did not get shorter.)
     auto seg_matrix = [&](int st, int t_next, const f32x16 (&sc)[2], f32x16 (&sn)[2], const V8 (&kf)[2][KSTEPS],
                           const V8 (&vf0)[DTILES][2], V8 (&vf1)[DTILES][2], int jp, int st_refill) {
-        if (idle) return;
-#if PRIMX_ATTN_PRIO == 1
         __builtin_amdgcn_s_setprio(1);   // the matrix segment outranks its partner's light segment at the issue arbiter
-#endif
         const float mc = m_run * c;
         float psum = 0.f;
         V8 pb0[2], pb1[2];
-#if !PRIMX_ATTN_ALLREADS_L
-        read_v(st, 1, vf1);
-#endif
-#if PRIMX_ATTN_EXP0_IN_L && PRIMX_ATTN_QKPV_MIX
         // P of the first 32 keys is ready on entry: its 6 PV MFMAs are woven into the 10 QK^T MFMAs, so that no MFMA depends on
         // the one two slots before it (the two score chains alone sit exactly one MFMA latency apart: ~10 stall cycles each)
         pb0[0] = pb0_l[0];
@@ -475,45 +389,18 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
                         if (kbase + kt * 32 + (r & 3) + 8 * (r >> 2) >= nkv) sn[kt][r] = -1e30f;
             }
         }
-#if PRIMX_ATTN_DMA_IN_M && !PRIMX_ATTN_REGSTAGE
         issue_pair(jp, st_refill);
-#endif
-#else
-        qk(kf, t_next, sn);
-#if PRIMX_ATTN_DMA_IN_M && !PRIMX_ATTN_REGSTAGE
-        issue_pair(jp, st_refill);      // among the MFMAs (~60 issue cycles each there, 150 - 330 in the light segment)
-#endif
-#if PRIMX_ATTN_EXP0_IN_L
-        pb0[0] = pb0_l[0];
-        pb0[1] = pb0_l[1];
-#else
-        probs(sc[0], mc, psum, pb0);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        pv(vf0, pb0);
-#endif
         probs(sc[1], mc, psum, pb1);
         fence_lds();
         pv(vf1, pb1);
         if (KMASK) l_run += psum;
-#if PRIMX_ATTN_MAX_IN_M
-        fold_max(sn, false);            // max of the NEXT tile's scores here, in the shadow of the PV MFMAs just issued
-#endif
-#if PRIMX_ATTN_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
-#endif
     };
 
     // ---- prologue: K(0) parks in the last stage, pairs 0 and 1 are issued; S(0) = K(0) Q^T
-#if PRIMX_ATTN_REGSTAGE
-    if (!grp) { gload_run(0); write_run(NSTAGE - 1); }
-#pragma unroll
-    for (int pr = 0; pr < NSTAGE - 1; ++pr) { gload_run(pr + 1 - grp); write_run(pr); }
-#else
     if (!grp) issue_run(0, NSTAGE - 1);
 #pragma unroll
     for (int pr = 0; pr < NSTAGE - 1; ++pr) issue_pair(pr, pr);
-#endif
     load_q();
     if (QCOL) set_q_cols(0.f);
     f32x16 sA[2], sB[2];
@@ -525,12 +412,6 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
         asm volatile("s_barrier" ::: "memory");   // group 0's L(0) refills this stage: everyone's K(0) reads are home first
         qk(kf0, 0, sA);                   // S(0)
     }
-#if PRIMX_ATTN_MAX_IN_M
-    fold_max(sA, true);
-#endif
-#if PRIMX_ATTN_PRIO == 2
-    if (grp) __builtin_amdgcn_s_setprio(1);
-#endif
     if (PROF) pt = __builtin_readcyclecounter();
     // ---- main loop.  Group 0 runs  L B M B,  group 1 runs  B L B M  per step: the same number of barriers, group 1 half
     // a step late.  Ring safety (NSTAGE = 3): pair j+2 goes to the stage of pair j-1, whose K part was last read in
@@ -573,7 +454,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): drain the clamped tail DMAs before the workgroup retires
 #undef PRIMX_ATTN_WAITB
 #undef PRIMX_ATTN_WAITB_N
-    if (PROF && lane == 0 && !idle) {
+    if (PROF && lane == 0) {
         atomicAdd(&g_attn_prof[0], pl); atomicAdd(&g_attn_prof[1], pm); atomicAdd(&g_attn_prof[2], pw);
         atomicAdd(&g_attn_prof[3], pn); atomicAdd(&g_attn_prof[4], pl_dma); atomicAdd(&g_attn_prof[5], pl_rd);
     }
@@ -597,7 +478,6 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     const float inv = 1.0f / l_tot;
     const int q = q0 + wave * 32 + l31;
     const int b = bh / H, h = bh - b * H;
-#if PRIMX_ATTN_LDS_EPI
     // Row-major stores through LDS.  A lane owns one query row, so storing from the accumulators is 64 separate 8-byte
     // requests per instruction (9 instructions per wave at dh = 72, every wave at once at the end of the kernel); each wave
     // instead parks its 32 x dh tile in the idle ring (row stride DP + 8 halves) and walks it in 16-byte pieces, dh / 8
@@ -629,7 +509,6 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
         }
         return;
     }
-#endif
     if (q < nq) {
         S* orow = out + ((int64_t)b * nq + q) * ((int64_t)H * dh) + (int64_t)h * dh;
 #pragma unroll
@@ -650,7 +529,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
 // (Round 2 also built a ONE-wave-per-SIMD variant - 64 query rows per wave, O in the accumulator file, register-staged K / V^T,
 // hand-placed VALU fillers between MFMAs - and measured it slower.  A single wave per SIMD issues one VALU instruction per
 // ~4 cycles, half the rate two waves reach, and this kernel is bound by VALU issue (exp, pack, max), not by the matrix pipe.
-// Removed in round 3; the measurements are in DESIGN.md section 5.)
+// Removed in round 3; the measurements are in DESIGN_LOG.md section 5.)
 
 // ---------------------------------------------------------------------------------------------------
 // Small problems: nq, nkv <= 64 at dh = 32 - the VAE mid-block attention over the 64 voxels of a 4^3 primitive
@@ -741,7 +620,7 @@ __global__ __launch_bounds__(256) void attn64_kernel(const typename T16<DT>::S* 
     }
 }
 
-// PRIMX_ATTN_PROF=1|2: run the instrumented variant (dh 72, fp16) synchronously and print the per-segment cycle profile
+// PRIMX_ATTN_PROF=1: run the instrumented variant (dh 72, fp16) synchronously and print the per-segment cycle profile
 static const int g_attn_prof_on = [] {
     const char* e = getenv("PRIMX_ATTN_PROF");
     return e ? atoi(e) : 0;
@@ -760,8 +639,7 @@ void launch_attn(const void* Qp, const void* Kp, const void* Vt, void* out, int 
         if (g_attn_prof_on) {
             unsigned long long z[8] = {0}, r[8];
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), z, sizeof(z));
-            if (g_attn_prof_on == 2) PRIMX_ATTN_LAUNCH(2);
-            else PRIMX_ATTN_LAUNCH(1);
+            PRIMX_ATTN_LAUNCH(1);
             (void)hipStreamSynchronize(st);
             (void)hipMemcpyFromSymbol(r, HIP_SYMBOL(g_attn_prof), sizeof(r));
             const double n = r[3] ? (double)r[3] : 1.0;

@@ -370,7 +370,7 @@ __device__ __forceinline__ typename T16<DT>::V4 linear_out4(const GemmArgs<DT>& 
     // The activation's own rounding is folded into the final conversion when no scale follows (rounding twice to the
     // same type is the identity), and the scale is a real uniform branch: if-converted it cost every element a
     // multiply, two conversions and a select on top of the ~13 issue slots of the activation itself (the fc1 epilogue
-    // is bound by exactly this arithmetic: DESIGN.md section 4).
+    // is bound by exactly this arithmetic: DESIGN_LOG.md section 4).
     if (p.act == PRIMX_ACT_GELU_TANH) {          // one uniform branch per four elements (see PRIMX_APPLY_ACT)
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -444,7 +444,7 @@ __device__ __forceinline__ void epilogue_row4(const GemmArgs<DT>& p, int m, int 
 }
 
 // MF: MFMA edge (32 -> 32x32x16, 16 -> 16x16x32); WM x WN waves, each MI x NI MFMA tiles
-template <int DT, int EPI, int MF, int WM, int WN, int MI, int NI, int GATHER, int KTAIL>
+template <int DT, int EPI, int MF, int WM, int WN, int MI, int NI, int GATHER>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs<DT> p) {
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
@@ -515,11 +515,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs<DT> p) {
                 ra[i] = ldg16<V8, S>(gbase[i] + off, ok);
             }
         } else {
-            const bool k_ok = !KTAIL || kt * BK + kc < p.K;  // K tail (K % 64 != 0): zero chunk
+            const bool k_ok = kt * BK + kc < p.K;  // K tail (K % 64 != 0): zero chunk
 #pragma unroll
             for (int i = 0; i < NA; ++i) ra[i] = ldg16<V8, S>(ga[i] + (k_ok ? kt * BK : 0), k_ok);
         }
-        const bool k_ok = !KTAIL || kt * BK + kc < p.K;
+        const bool k_ok = kt * BK + kc < p.K;
 #pragma unroll
         for (int i = 0; i < NW; ++i) rw[i] = ldg16<V8, S>(gw[i] + (k_ok ? kt * BK : 0), k_ok);
     };
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs<DT> p) {
 // per SIMD hide each other's LDS/barrier latency at ~190 VGPRs, and each wave stages only 1/8 of a tile.
 // The two K halves are summed through LDS at the end; ownership of the 9 column tiles is split 5 / 4
 // between the halves so both run the epilogue.
-template <int DT, int EPI, int KTAIL>
+template <int DT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm144_kernel(const GemmArgs<DT> p) {
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const GemmArgs<DT> p) {
     const bool w_last = tid + 512 * (NW - 1) < BN * 8;  // 1152 W chunks = 2.25 per thread (waves 0,1 take the rest)
 
     auto load_tile = [&](int kt, V8 (&ra)[NA], V8 (&rw)[NW]) {
-        const bool k_ok = !KTAIL || kt * BK + kc < p.K;
+        const bool k_ok = kt * BK + kc < p.K;
         const int koff = k_ok ? kt * BK : 0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = ldg16<V8, S>(ga[i] + koff, k_ok);
@@ -1172,6 +1172,9 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                   // D
         asm volatile("s_barrier" ::: "memory");                                          // E
+        if constexpr (EPI == EPI_GATE_RESIDUAL_LN) {
+            if (pl_rest.ln_light & 8) asm volatile("s_barrier\n\ts_barrier" ::: "memory");   // F, G of the LayerNorm tail (every wave executes every barrier)
+        }
         return;
     }
 
@@ -1304,37 +1307,57 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     if constexpr (EPI == EPI_GATE_RESIDUAL_LN) {
         // ---------------- LayerNorm + modulate of the 128-row block, in the tail of the GEMM that completes its rows
         // (dit_crossattn.py:55-57: every gated residual add is followed by the LayerNorm of the next branch).  The nt column
-        // tiles of a row block are nt workgroups; a row is complete when all of them have stored.  Every compute wave (nt x 8
-        // per block) releases its stores, counts itself in on sync[2 g], waits until all have arrived and then normalises ITS
-        // share of the block's rows - 128 / (8 nt) pairs, one row per half-wave, the row body of ln_modulate_row32_kernel
-        // (ln_row.h: same bits).  What this saves is a dependent launch per LayerNorm (~4.5 us fixed + the boundary, 85 per
-        // DDIM step) for ~1k cycles of tail; the rows come from the L2 that the block's tiles share (xcd_remap: consecutive
-        // tile ids = one XCD).  Waiting inside a kernel is safe here because the waited-for workgroups never depend on the
-        // waiting ones and are dispatched no later than them: the workgroups of a block have consecutive ids on one XCD, the
-        // dispatcher hands out ids in order, so whenever the XCD's CUs are all held by waiting workgroups the oldest block among
-        // them is complete (32 CUs >= 3 whole blocks of 8) - the host additionally keeps the grid within one round of the
-        // CUs (launch144_dma).  A bounded spin (~1 s) turns a violated assumption into a counted error (primx_ln_sync_timeouts)
-        // instead of a hang.  Fences: agent-scope release / acquire as the HSA memory model wants them between workgroups
-        // (L2 write-back + invalidate); `ln_light` (PRIMX_LN_FENCE=light) keeps only what same-XCD workgroups need - stores
-        // acknowledged by the shared L2, L1 invalidated.  Departures are counted on sync[2 g + 1]; the last wave to leave
-        // zeroes both words, so a block's words are zero between launches whatever nt the next launch has.
-        const unsigned per = (unsigned)nt * 8u;
+        // tiles of a row block are nt workgroups; a row is complete when all of them have stored.  The waves of a workgroup meet
+        // at a barrier, wave 0 counts the workgroup in on sync[2 g] and waits until all nt have arrived, a second barrier releases
+        // the others, and every wave normalises ITS share of the block's rows - 128 / (8 nt) pairs, one row per half-wave, the row
+        // body of ln_modulate_row32_kernel (ln_row.h: same bits).  Departures are counted on sync[2 g + 1]; the last one zeroes both
+        // words, so a block's words are zero between launches whatever nt the next launch has.
+        // MEASURED (round 4, same box, configs[1] step): bit-identical to the two launches and SLOWER in every protocol - one
+        // arrival per wave 12.8 ms, one per workgroup 10.25 ms (agent-scope or same-XCD fences, L1 / L2 invalidate or none, sleep 2
+        // or 8, counter read by load or by returning atomic: all within 0.03 ms), agent-scope release with its L2 write-back
+        // 13.8 - 14.8 ms, against 8.99 ms with the LayerNorm as a launch of its own.  The fused kernel lasts 50 us where the GEMM
+        // (28) and the LayerNorm (7) + a boundary (1.3) take 36: serialized same-address atomics cost ~0.5 us each and a waiting
+        // workgroup sees the last arrival only microseconds later - a dependent kernel launch is the cheaper hand-over between CUs
+        // on this part.  The route therefore runs only when the caller passes `sync` words (DiT.ln_in_kernel, off by default).
+        // Why the in-kernel wait is safe: the waited-for workgroups never depend on the waiting ones and are dispatched no later
+        // than them - the workgroups of a block have consecutive ids on one XCD (mt % 8 == 0, checked by the host; the id -> XCD
+        // mapping itself by a probe launch, xcd_mapping_ok), the dispatcher hands out ids in order, so whenever the XCD's CUs are
+        // all held by waiting workgroups the oldest block among them is complete (32 CUs >= 3 whole blocks of 8).  A bounded spin
+        // (~1 s) turns a violated assumption into a counted error (primx_ln_sync_timeouts) instead of a hang.
+        // p.ln_light (PRIMX_LN_MODE): bit 0 = same-XCD release (stores acknowledged by the shared L2, no L2 write-back), bits 1-2 =
+        // acquire (0: agent-scope fence = L2 invalidate, 1: this CU's L1 only, 2: none), bit 3 = ONE arrival per workgroup (the
+        // waves meet at a workgroup barrier, wave 0 counts in and waits, a second barrier releases the others) instead of one per
+        // wave, bits 4-7 = s_sleep argument of the wait loop
+        const int mode = p.ln_light;
+        const bool per_wg = (mode & 8) != 0;
+        const unsigned per = per_wg ? (unsigned)nt : (unsigned)nt * 8u;
         unsigned* cnt = p.sync + 2 * (m0 / BM);
-        if (p.ln_light) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (mode & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (lane == 0) {
+        if (per_wg) asm volatile("s_barrier" ::: "memory");                             // F: every wave's stores are out
+        if (lane == 0 && (!per_wg || wave == 0)) {
             __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int spins = 0;
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per) {
-                __builtin_amdgcn_s_sleep(2);
+            const int nap = (mode >> 4) & 15;
+            // (reading the counter with a returning atomic instead of the agent-scope load measured the same step time; an L1
+            // invalidate + plain load never saw the arrivals: round 4, profiles/r4_experiments.txt)
+            auto seen = [&]() -> unsigned { return __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            while (seen() < per) {
+                if (nap >= 8) __builtin_amdgcn_s_sleep(8);
+                else if (nap >= 4) __builtin_amdgcn_s_sleep(4);
+                else if (nap >= 2) __builtin_amdgcn_s_sleep(2);
+                else __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1 << 20)) {
                     atomicAdd(&g_ln_sync_timeouts, 1u);
                     break;
                 }
             }
         }
-        if (p.ln_light) asm volatile("buffer_inv sc1" ::: "memory");
-        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (per_wg) asm volatile("s_barrier" ::: "memory");                             // G: the block's rows are complete
+        const int acq = (mode >> 1) & 3;
+        if (acq == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        else if (acq == 1) asm volatile("buffer_inv sc0" ::: "memory");
+        else asm volatile("" ::: "memory");
         const int q = (n0 / BN) * 8 + wave;                   // this wave among the block's `per`
         for (int r = 2 * q + (lane >> 5); r < BM; r += 2 * (int)per) {
             const int m = m0 + r;
@@ -1342,7 +1365,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
             const int64_t bo = (int64_t)(m / p.rows_per_batch) * p.ln_mod_stride;
             ln_row32<DT, 9>(p.x + (int64_t)m * pl_N, p.ln_shift + bo, p.ln_scale + bo, p.ln_out + (int64_t)m * pl_N, lane & 31, p.ln_eps);
         }
-        if (lane == 0) {
+        if (lane == 0 && (!per_wg || wave == 0)) {
             const unsigned d = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (d == per - 1) {                                // everybody has passed the wait: the words go back to zero
                 __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1693,7 +1716,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
 // loader waves run ahead across the pass boundary (the ring holds the second pass's first tiles when the first epilogue
 // ends), and only the second half of the output is exposed.  The price is bytes per FLOP - (256 + 144) x 128 B per 64-wide
 // k-tile = 50 DMA instructions x 24.5 cycles = 1225 against 1152 cycles of MFMA per SIMD: the loop sits at the DMA unit's rate,
-// which the loader waves reach where the 8-wave 256 x 288 loop measured 3100 per (twice as large) k-tile.
+// which the loader waves reach (DESIGN_LOG.md section 4) where the 8-wave 256 x 288 loop measured 3100 per (twice as large) k-tile.
 // Pipeline: the unit is a 32-wide k-step (18 MFMAs per wave).  Fragments of step u + 1 are read while step u multiplies; the
 // ONE barrier per k-tile sits between its two steps: B_g = "reads of tile g are home (its stage may be refilled), tile g + 1 has
 // landed" - the same two-tiles-of-flight ring protocol as gemm144l_dma_kernel, all ten waves execute every barrier.
@@ -1853,6 +1876,327 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// PERSISTENT big tile (round 4): 256 x 288 per tile as in gemm288q, but FOUR waves of 128 x 144 with the whole register file (one
+// wave per SIMD: 512 registers - 288 accumulators + two fragment sets + one staged slice) and a workgroup that walks MANY tiles,
+// one continuous stream of 32-wide k-slices through a 4-stage LDS ring.
+// Why (round-3 timelines, DESIGN_LOG.md section 4): (1) the 8-wave tile reads every A fragment twice and every W fragment four
+// times from LDS - 106 KB of fragment reads + 35 KB of staging writes per slice against the 1152 cycles of its MFMAs is 122 B/clk
+// of the array's 128: its loop cannot run at the matrix rate (measured 1650 cycles per slice); four waves of 128 x 144 read 70 KB.
+// (2) with several tiles per CU (T >= 8192: every GEMM of the large-batch configurations) a one-tile workgroup pays its ring fill
+// (~6k cycles) and its store drain (~5k) un-overlapped for every tile, because the next workgroup cannot start before the LDS is
+// free.  Here the operand stream simply continues into the next tile - its first slices are in flight or landed while the epilogue
+// of the previous tile runs - and nothing ever waits for the stores.
+// Operands go THROUGH REGISTERS (global_load_dwordx4 -> ds_write_b128), not by LDS-DMA: the first form of this kernel issued the DMA
+// from the compute waves and measured 1917 cycles per slice - with one wave per SIMD nobody covers a wave that sits in the DMA
+// unit's queue (~65 cycles per issue x 9 issues per slice), and a 512-register wave leaves no room for a loader wave
+// (profiles/r4_experiments.txt section 2).  A plain load is asynchronous at issue; its 36 staging registers fit the budget, and
+// every wait on it is a compiler-counted vmcnt that never includes a younger store.
+// Phase p (slice p of the stream): barrier | MFMA group 0 | ds_write of the staged slice p + 3 into the stage slice p - 1 vacated |
+// global loads of slice p + 4 into the staging registers | fragment reads of slice p + 1 into the other set | MFMA groups 1..8.
+// Operands swapped (accumulator = C^T: a lane owns one row and four consecutive columns), dense-output epilogues from registers;
+// the gate-residual epilogue requests the residual rows of row group i + 1 BEFORE it stores group i (the in-order counter then
+// never makes a load wait for a store).  Accumulators are pinned: columns 0..127 of the wave tile in AGPRs, 128..143 in VGPRs
+// (inline-asm MFMAs: left to the allocator the 32 that overflow the 256 AGPRs wander between the files, 70 moves per phase).
+template <int DT, bool IN_AGPR>
+__device__ __forceinline__ void mfma16_pin(f32x4& acc, const typename T16<DT>::V8 a, const typename T16<DT>::V8 b) {
+    if constexpr (DT == PRIMX_F16) {
+        if constexpr (IN_AGPR) asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+        else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    } else {
+        if constexpr (IN_AGPR) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+        else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    }
+}
+
+template <int DT, int EPI>
+__global__ __launch_bounds__(256, 1) void gemm288w_dma_kernel(PRIMX_GEMM_PARAMS(DT)) {
+    PRIMX_GEMM_ARGS(DT);
+    static_assert(EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_RES, "dense-output epilogues only");
+    unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, p_loop = 0, p_epi = 0;   // PRIMX_GEMM_PROF=1 timeline (see g_gemm_prof)
+    if (pl_prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
+    using S = typename T16<DT>::S;
+    using V8 = typename T16<DT>::V8;
+    using V4e = typename T16<DT>::V4;
+    constexpr int BM = 256, BN = 288, MI = 8, NI = 9, KS = 32, NST = 4;
+    constexpr int ROWS = BM + BN, STAGE = ROWS * KS, NINST = ROWS / 16, NSLOT = (NINST + 3) / 4;   // 34 wave-instructions per slice: 9 (waves 0, 1) / 8
+    static_assert(NST * STAGE * 2 <= 160 * 1024 && NSLOT == 9, "LDS budget / slot split");
+    __shared__ __attribute__((aligned(16))) S smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int nt = pl_N / BN, mt = (pl_M + BM - 1) / BM, ntiles = nt * mt;
+    const int nks = pl_K / KS;                                      // even, >= 8 (host)
+    const int G = gridDim.x;                                        // a multiple of 8 when a workgroup has more than one tile: tile v = blockIdx.x + r G stays on this XCD
+    auto tile_at = [&](int v, int& m0, int& n0) {
+        int mi_t, ni_t;
+        if (pl_xcd_gm > 0) {
+            xcd_tile2d(v, mt, nt, pl_xcd_gm, mi_t, ni_t);
+        } else {
+            const int id = xcd_remap(v, ntiles);
+            mi_t = id / nt;
+            ni_t = id - mi_t * nt;
+        }
+        m0 = mi_t * BM;
+        n0 = ni_t * BN;
+    };
+    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / G + 1 : 0;
+    if (my_tiles == 0) return;
+
+    // ---- the operand stream.  Slot i of this wave moves 16 rows of the 544-row stage image (rows < 256: activations, the rest:
+    // weights; 64 bytes per row and slice, four lanes per row, the 16-byte chunk swizzled on the SOURCE address so that the LDS image
+    // is lane-linear).  `gp` holds the slot's source BYTE OFFSETS from A or from W (an instruction is all activation or all weight
+    // rows, so the base is wave-uniform; 32-bit - the host keeps M K and N K below 2^30 elements) for the tile being fetched.
+    unsigned gp[NSLOT];
+    auto point_at = [&](int r) {
+        int m0, n0;
+        tile_at((int)blockIdx.x + r * G, m0, n0);
+        int ln = lane;                                              // (opaque copy: hoisted out of the tile loop these values stayed live through the k-loop and spilled)
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int t = min(wave + 4 * i, NINST - 1);
+            const int row = 16 * t + (ln >> 2);
+            const int c = (ln & 3) ^ (((row >> 3) & 1) << 1);
+            gp[i] = 2u * (unsigned)((row < BM) ? min(m0 + row, pl_M - 1) * pl_K + c * 8 : (n0 + row - BM) * pl_K + c * 8);
+        }
+    };
+    const bool last_slot = wave + 4 * (NSLOT - 1) < NINST;         // wave-uniform (waves 0, 1)
+    V8 stg[NSLOT];                                                  // one staged slice: 36 registers
+    auto fetch = [&](int ks) {                                      // global -> registers: k-slice ks of the tile `gp` points at
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            if (i < NSLOT - 1 || last_slot) {
+                const char* base = reinterpret_cast<const char*>((min(wave + 4 * i, NINST - 1) < BM / 16) ? pl_A : pl_W) + ks * (KS * 2);   // (uniform)
+                stg[i] = ldg16<V8, S>(reinterpret_cast<const S*>(base + gp[i]), true);
+            }
+        }
+    };
+    auto park = [&](int stage) {                                    // registers -> LDS stage (lane-linear 16 bytes per lane)
+        // (explicit: everything this wave has requested - the staged slice, issued a whole phase ago - has arrived.  The compiler's
+        // own counted waits were one short for one of the nine registers in the first build, profiles/r4_experiments.txt section 3;
+        // behind an epilogue this also waits for that tile's stores, which have had the epilogue itself to drain)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i)
+            if (i < NSLOT - 1 || last_slot) *reinterpret_cast<V8*>(smem + stage * STAGE + (wave + 4 * i) * 512 + lane * 8) = stg[i];
+    };
+    point_at(0);
+#pragma unroll 1
+    for (int pre = 0; pre < NST - 1; ++pre) {                       // slices 0 .. 2 into stages 0 .. 2, slice 3 stays staged
+        fetch(pre);
+        park(pre);
+    }
+    fetch(NST - 1);
+
+    const int sw2 = ((lr >> 3) & 1) << 1;
+    const int a_off = (wm * 128 + lr) * KS + ((lg ^ sw2) << 3);            // + i * 16 rows
+    const int w_off = (BM + wn * 144 + lr) * KS + ((lg ^ sw2) << 3);       // + j * 16 rows
+    f32x4 acc[MI][NI];                                               // [..][0..7] pinned to AGPRs, [..][8] to VGPRs (mfma16_pin)
+    // Fragment registers: the A fragments and the first NPF W fragments of slice p + 1 are read one phase ahead (44 registers), the
+    // other W fragments at the top of their own phase, where the first NPF MFMA groups cover their latency (a full second set - 68
+    // more registers - pushed the kernel over 256 VGPRs and put scratch traffic into the loop)
+    constexpr int NPF = 3;
+    V8 a_n[MI], b_n[NPF];
+    int st = 0;                                                      // stage of the slice whose MFMAs run next
+    auto read_ahead = [&](int stage) {
+        const S* base = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a_n[i] = *reinterpret_cast<const V8*>(base + a_off + i * 16 * KS);
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) b_n[j] = *reinterpret_cast<const V8*>(base + w_off + j * 16 * KS);
+    };
+    // Phase p.  `ks_fetch`: the k-slice of the tile under `gp` that is requested now (= slice p + 4 of the stream); the staged
+    // slice p + 3 goes into the stage that slice p - 1 vacated.  NEXT = false: the last phase of a tile reads nothing ahead (the
+    // registers are the epilogue's).
+    auto phase = [&](auto next_c, int ks_fetch) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int st_next = (st == NST - 1) ? 0 : st + 1;
+        const int st_prev = (st == 0) ? NST - 1 : st - 1;
+        const S* base = smem + st * STAGE;
+        V8 a[MI], b[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = a_n[i];
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) b[j] = b_n[j];
+#pragma unroll
+        for (int j = NPF; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(base + w_off + j * 16 * KS);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if (j < NI - 1) mfma16_pin<DT, true>(acc[i][j], b[j], a[i]);
+                else mfma16_pin<DT, false>(acc[i][j], b[j], a[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (j == 0) {
+                park(st_prev);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(ks_fetch);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (j == NPF) {   // the read-ahead registers are free now (their values were copied / consumed above)
+                if constexpr (decltype(next_c)::value) {
+                    read_ahead(st_next);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        st = st_next;
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slices 0 .. 2 are in LDS
+    if (pl_prof) pc1 = __builtin_readcyclecounter();
+
+#pragma unroll 1
+    for (int r = 0; r < my_tiles; ++r) {
+        unsigned long long pt0 = 0;
+        if (pl_prof) pt0 = __builtin_readcyclecounter();
+        // (slice 3 of this tile sits in the staging registers since the previous tile's last phase - requested BEFORE that tile's
+        // stores, so that the wait in front of its ds_write does not include them; the price is 36 registers live across the epilogue)
+        read_ahead(st);                                              // slice 0 of this tile (in LDS since two phases ago)
+        int m0, n0;
+        tile_at((int)blockIdx.x + r * G, m0, n0);
+        const int nb = n0 + wn * 144 + 4 * lg;
+        // the accumulators start from the bias (fp32): no bias registers in the epilogue
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                const V4e bv = *reinterpret_cast<const V4e*>(p.bias + nb + j * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b4[q] = (float)bv[q];
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                acc[i][j] = b4;
+                // (an empty VOLATILE asm that owns the accumulator: the initialisation must be materialised HERE.  Left free, hipcc
+                // sank every v_accvgpr_write to just in front of the accumulator's first MFMA - an inline-asm MFMA it cannot see,
+                // so nothing provided the wait states between the VALU write and the matrix unit's SrcC read: a random ~0.7 % of
+                // a tile's elements came out wrong, profiles/r4_experiments.txt section 3)
+                if (j < NI - 1) asm volatile("" : "+a"(acc[i][j]));
+                else asm volatile("" : "+v"(acc[i][j]));
+            }
+        }
+        asm volatile("s_nop 7" ::: "memory");                        // (VALU / accvgpr write -> MFMA SrcC read)
+#pragma unroll 1
+        for (int ks = 0; ks < nks - 4; ++ks) phase(std::true_type{}, ks + 4);
+        // the last four phases of a tile request the first slices of the NEXT one (no next tile: the last slice again, into
+        // stages nobody reads)
+        const bool has_next = r + 1 < my_tiles;
+        if (has_next) point_at(r + 1);
+        phase(std::true_type{}, has_next ? 0 : nks - 1);
+        phase(std::true_type{}, has_next ? 1 : nks - 1);
+        phase(std::true_type{}, has_next ? 2 : nks - 1);
+        phase(std::false_type{}, has_next ? 3 : nks - 1);
+        // wait states between the last MFMA's write and the first read of an accumulator (the MFMAs are invisible to the recognizer)
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long pt1 = 0;
+        if (pl_prof) { pt1 = __builtin_readcyclecounter(); p_loop += pt1 - pt0; }
+
+        // ---- epilogue from registers: acc[i][j][q] = (C + bias)[m0 + wm*128 + i*16 + lr][n0 + wn*144 + j*16 + 4*lg + q]
+        const V4e bz = V4e{};                                         // (the shared epilogue helpers add a bias vector: zeros, the accumulators carry it)
+        if constexpr (EPI == EPI_GATE_RESIDUAL) {
+            // residual rows one row group ahead: loads (i + 1) are issued BEFORE stores (i), so the counted wait for them never
+            // includes a store (vmcnt is one in-order counter for both)
+            f32x4 xa[NI], xb[NI];
+            // (one gate row per tile: the host sends gate-residual launches here only when rows_per_batch % 256 == 0, so a 256-row
+            // tile lies in one batch entry; loaded before any store of this tile)
+            V4e gv[NI];
+            {
+                const S* grow = p.gate + (int64_t)(min(m0, pl_M - 1) / p.rows_per_batch) * p.gate_stride + nb;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) gv[j] = *reinterpret_cast<const V4e*>(grow + j * 16);
+            }
+            auto rows_of = [&](int i, int& mc, bool& ok) {
+                const int m = m0 + wm * 128 + i * 16 + lr;
+                ok = m < pl_M;
+                mc = ok ? m : pl_M - 1;
+            };
+            auto load_x = [&](int i, f32x4 (&xv)[NI]) {
+                int mc; bool ok;
+                rows_of(i, mc, ok);
+                const float* xrow = p.x + (int64_t)mc * pl_N + nb;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) xv[j] = *reinterpret_cast<const f32x4*>(xrow + j * 16);
+            };
+            auto finish = [&](int i, f32x4 (&xv)[NI]) {
+                int mc; bool ok;
+                rows_of(i, mc, ok);
+                float* xrow = p.x + (int64_t)mc * pl_N + nb;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        xv[j][q] += rnd16<DT>((float)gv[j][q] * rnd16<DT>(acc[i][j][q]));
+                    if (ok) out_store(reinterpret_cast<f32x4*>(xrow + j * 16), xv[j]);
+                }
+            };
+            load_x(0, xa);
+#pragma unroll
+            for (int i = 0; i < MI; i += 2) {
+                load_x(i + 1, xb);
+                __builtin_amdgcn_sched_barrier(0);
+                finish(i, xa);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 2 < MI) load_x(i + 2, xa);
+                __builtin_amdgcn_sched_barrier(0);
+                finish(i + 1, xb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * 128 + i * 16 + lr;
+                const bool ok = m < pl_M;
+                const int mc = ok ? m : pl_M - 1;
+                if constexpr (EPI == EPI_LINEAR) {
+                    // (16-byte stores: the lane groups of a row trade halves of neighbouring 16-column tiles, see gemm288q_dma_kernel)
+                    typedef unsigned int u32;
+                    S* orow = p.out + (int64_t)mc * pl_N + n0 + wn * 144;
+#pragma unroll
+                    for (int j = 0; j + 1 < NI; j += 2) {
+                        const u32x2 a = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j], bz));
+                        const u32x2 b = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j + 1], bz));
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                        const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
+                        if (ok) out_store(reinterpret_cast<u32x4*>(orow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
+                    }
+                    if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), linear_out4<DT>(p, acc[i][NI - 1], bz));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        if (ok) epilogue_row4<DT, EPI>(p, m, nb + j * 16, acc[i][j], bz);
+                }
+            }
+        }
+        if (pl_prof) p_epi += __builtin_readcyclecounter() - pt1;
+        // (the source offsets are recomputed instead of kept: nine registers the epilogue then has for itself - a spill there is
+        // reloaded behind the tile's stores, and the in-order counter makes that reload wait for every one of them)
+        if (has_next) point_at(r + 1);
+    }
+    if (pl_prof) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long pc3 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            atomicMin(&g_gemm_prof[0], pr0); atomicMax(&g_gemm_prof[1], pr1);
+            atomicAdd(&g_gemm_prof[2], pc1 - pc0); atomicAdd(&g_gemm_prof[3], p_loop);
+            atomicAdd(&g_gemm_prof[4], p_epi); atomicAdd(&g_gemm_prof[5], 1ull); atomicAdd(&g_gemm_prof[6], pr0);
+            atomicAdd(&g_gemm_prof[8], pr1 - pr0); atomicAdd(&g_gemm_prof[9], pc3 - pc0);
+            if (blockIdx.x < 4096) {
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                g_gemm_wg[blockIdx.x][0] = pr0; g_gemm_wg[blockIdx.x][1] = pr1 - pr0; g_gemm_wg[blockIdx.x][2] = pc3 - pc0;
+                g_gemm_wg[blockIdx.x][3] = ((unsigned long long)(xcc & 15) << 32) | (unsigned)(p_epi);
+            }
+        }
+    }
+}
+
 static const bool g_no_big = [] {   // PRIMX_GEMM_NOBIG=1 disables the 256x288 tile (A/B measurements)
     const char* e = getenv("PRIMX_GEMM_NOBIG");
     return e && e[0] == '1';
@@ -1878,26 +2222,55 @@ static const bool g_two_pass = [] {   // PRIMX_GEMM_P2=0: the Linear epilogue's 
     return !(e && e[0] == '0');
 }();
 
+static const int g_big_w = [] {   // PRIMX_GEMM_W: the persistent 4-wave 256x288 kernel (gemm288w) for the dense-output epilogues - 0 never,
+    const char* e = getenv("PRIMX_GEMM_W");   // 1 launches with more tiles than CUs, 2 every big-tile launch
+    return e ? atoi(e) : 1;
+}();
+
 static const bool g_xcd2d = [] {   // PRIMX_GEMM_XCD2D=0: whole tile rows per XCD in the 256x288 kernel (A/B measurements)
     const char* e = getenv("PRIMX_GEMM_XCD2D");
     return !(e && e[0] == '0');
 }();
 
 // LayerNorm in the tail of the gate-residual GEMM (primx_linear_gate_residual_ln): PRIMX_LN_FUSE=0 always takes the two-launch
-// route; PRIMX_LN_FENCE=light keeps only the same-XCD part of the release / acquire pair (A/B measurements);
+// route; PRIMX_LN_MODE selects the fences and the arrival protocol (A/B measurements);
 // PRIMX_LN_FUSE_MAXGRID bounds the grid of a fused launch.
 static const bool g_ln_fuse = [] {
     const char* e = getenv("PRIMX_LN_FUSE");
     return !(e && e[0] == '0');
 }();
-static const bool g_ln_light = [] {
-    const char* e = getenv("PRIMX_LN_FENCE");
-    return e && e[0] == 'l';
+static const int g_ln_mode = [] {   // PRIMX_LN_MODE: see the tail of gemm144l_dma_kernel (bit 0 light release | acquire kind << 1 | per-workgroup arrival 8 | sleep << 4)
+    const char* e = getenv("PRIMX_LN_MODE");
+    return e ? atoi(e) : (1 | (0 << 1) | 8 | (2 << 4));   // 41: same-XCD release (stores acknowledged by the shared L2), agent-scope acquire, one arrival per workgroup
 }();
 static const int g_ln_maxgrid = [] {
     const char* e = getenv("PRIMX_LN_FUSE_MAXGRID");
     return e ? atoi(e) : 2048;
 }();
+// The fused route's same-XCD fences rest on the workgroup -> XCD mapping that xcd_remap assumes everywhere (workgroup id mod 8 =
+// XCD): checked ONCE per device by a probe launch (every workgroup reports the XCC it runs on) before the first fused launch; a
+// device that maps differently (another partition mode, fewer XCDs) takes the two-launch route.
+__device__ unsigned g_xcd_probe[256];
+__global__ void xcd_probe_kernel() {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) g_xcd_probe[blockIdx.x] = xcc & 15;
+}
+static bool xcd_mapping_ok() {
+    static int state[64] = {0};   // per device: 0 unknown, 1 ok, -1 not
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (state[dev] == 0) {
+        unsigned h[256];
+        hipLaunchKernelGGL(xcd_probe_kernel, dim3(256), dim3(64), 0, 0);
+        bool ok = hipMemcpyFromSymbol(h, HIP_SYMBOL(g_xcd_probe), sizeof(h)) == hipSuccess;
+        for (int i = 0; ok && i < 256; ++i) ok = h[i] == h[i & 7];
+        for (int i = 0; ok && i < 8; ++i)
+            for (int j = 0; j < i; ++j) ok = ok && h[i] != h[j];
+        state[dev] = ok ? 1 : -1;
+    }
+    return state[dev] == 1;
+}
 thread_local bool g_ln_fused = false;   // did the last launch144_dma on this thread run the LayerNorm in the GEMM's tail?
 
 static const bool g_gemm_prof_on = [] {   // PRIMX_GEMM_PROF=1: synchronous launches + per-workgroup timeline print (8-wave kernels)
@@ -1908,6 +2281,7 @@ static const bool g_gemm_prof_on = [] {   // PRIMX_GEMM_PROF=1: synchronous laun
 // The kernel instantiation the last GEMM entry point called on this thread selected, spelled as rocprofv3 prints it
 // (primx_last_gemm_kernel(), include/primx_hip.h): bench.py tags its per-launch timings with what the C side actually
 // launched instead of a Python restatement of the dispatch rules below.
+static const bool g_gemm_prof_w_off = false;
 thread_local char g_last_gemm_kernel[112] = "";
 #define PRIMX_NOTE_KERNEL(...) snprintf(g_last_gemm_kernel, sizeof(g_last_gemm_kernel), __VA_ARGS__)
 
@@ -1928,7 +2302,7 @@ template <int DT, int EPI, int BIG = 0>
 void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     const dim3 grid(BIG ? ((a.M + 255) / 256) * (a.N / 288) : mt * (a.N / 144));
     GemmArgs<DT> a2 = a;
-    a2.ln_light = g_ln_light ? 1 : 0;
+    a2.ln_light = g_ln_mode;
     if (BIG && g_xcd2d) {
         // XCD block shape: minimise (A bytes x column groups + W bytes x row groups) over the splits the tile grid allows
         const int mtb = (a.M + 255) / 256, ntb = a.N / 288;
@@ -1955,7 +2329,18 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
         // two passes only when the launch is ONE round of workgroups (fc1 at T = 4096: exactly 256): there the first pass's stores
         // drain under the second pass (the step 8.97 -> 8.92 ms same box); with several rounds per CU the next workgroup already
         // overlaps the previous one's drain and the one-pass tile's fewer bytes per FLOP win (T = 32768: 428 vs 451 us)
-        if (BIG && EPI == EPI_LINEAR && g_two_pass && (int)grid.x <= 256) {
+        constexpr bool W_OK = EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_RES;
+        const int ntiles = (int)grid.x;
+        if (BIG && W_OK && !g_gemm_prof_w_off && x.K >= 256 && (int64_t)x.M * x.K < (1ll << 30) && (int64_t)x.N * x.K < (1ll << 30) &&
+            (EPI != EPI_GATE_RESIDUAL || x.rows_per_batch % 256 == 0) &&
+            (g_big_w == 2 || (g_big_w == 1 && ntiles > 256))) {
+            if constexpr (W_OK) {
+                // persistent: at most one workgroup per CU, a multiple of 8 so that tile v = blockIdx.x + r G stays on one XCD
+                const dim3 pg(ntiles >= 256 ? 256 : ntiles);
+                PRIMX_NOTE_KERNEL("gemm288w_dma_kernel<%d, %d>", DT, EPI);
+                hipLaunchKernelGGL((gemm288w_dma_kernel<DT, EPI>), pg, dim3(256), 0, st, PRIMX_GEMM_PASS(x));
+            }
+        } else if (BIG && EPI == EPI_LINEAR && g_two_pass && (int)grid.x <= 256) {
             PRIMX_NOTE_KERNEL("gemm288p_dma_kernel<%d>", DT);
             hipLaunchKernelGGL((gemm288p_dma_kernel<DT>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
         } else if (BIG) {
@@ -1968,7 +2353,8 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
                 // xcd_remap hands each XCD mt / 8 whole blocks) - see the kernel for why the in-kernel wait is safe then
                 const int nt = x.N / 144;
                 if (x.ln_out && x.sync && g_ln_fuse && x.N == 1152 && mt % 8 == 0 && (int)grid.x <= g_ln_maxgrid && nt * 8 <= 128 &&
-                    (((uintptr_t)x.ln_shift | (uintptr_t)x.ln_scale | (uintptr_t)x.ln_out) & 7) == 0 && x.ln_mod_stride % 4 == 0) {
+                    (((uintptr_t)x.ln_shift | (uintptr_t)x.ln_scale | (uintptr_t)x.ln_out) & 7) == 0 && x.ln_mod_stride % 4 == 0 &&
+                    xcd_mapping_ok()) {
                     PRIMX_NOTE_KERNEL("gemm144l_dma_kernel<%d, %d>", DT, EPI_GATE_RESIDUAL_LN);
                     hipLaunchKernelGGL((gemm144l_dma_kernel<DT, EPI_GATE_RESIDUAL_LN>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
                     g_ln_fused = true;
@@ -2005,7 +2391,7 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     fprintf(stderr, "%s<%d,%d> M=%d N=%d K=%d: %llu workgroups, events %.1f us, first start -> last end %.1f us, mean start offset "
                     "%.1f us, shader clock %.2f GHz (core cycles / 100 MHz ticks per workgroup); per workgroup (core cycles): entry->tile0 %.0f | main loop "
                     "%.0f | epilogue %.0f (LDS staging %.0f, read+store issue %.0f)\n",
-            BIG ? (EPI == EPI_LINEAR && g_two_pass && (int)grid.x <= 256 ? "gemm288p_dma" : "gemm288q_dma") : "gemm144_dma", DT, EPI, a.M, a.N, a.K,
+            BIG ? g_last_gemm_kernel : "gemm144_dma", DT, EPI, a.M, a.N, a.K,
             r[5], ms * 1e3, (r[1] - r[0]) * 0.01, (r[6] / n - (double)r[0]) * 0.01, r[8] ? (double)r[9] / (double)r[8] * 0.1 : 0.0,
             r[2] / n, r[3] / n, r[4] / n, (r[7] >> 32) / n,
             (r[7] & 0xffffffffull) / n);
@@ -2055,30 +2441,27 @@ int launch(const GemmArgs<DT>& a_in, hipStream_t st, const char* name) {
         use_big = a.N % 288 == 0 && per % 288 == 0 && 288 % a.dh == 0 && a.dh % 8 == 0 && a.dh >= 32 && a.rows_per_batch % 256 == 0 &&
                   (a.M / 256) * (a.N / 288) >= g_big_heads_min;
     }
-#define PRIMX_GEMM_LAUNCH(KT)                                                                                         \
-    do {                                                                                                              \
-        if (a.N <= 32) {                                                                                              \
-            PRIMX_NOTE_KERNEL("gemm_kernel<%d, %d, 32, 4, 1, 1, 1, %d, %d>", DT, EPI, GATHER, KT);                    \
-            hipLaunchKernelGGL((gemm_kernel<DT, EPI, 32, 4, 1, 1, 1, GATHER, KT>), dim3(mt * ((a.N + 31) / 32)),      \
-                               dim3(256), 0, st, a);                                                                  \
-        } else if (use_big && KT == 0 && !GATHER) {                                                                   \
-            launch144_dma<DT, EPI, 1>(a, mt, st);                                                                     \
-        } else if (a.N % 144 == 0 && !GATHER) {                                                                       \
-            if (KT == 0) {                                                                                            \
-                launch144_dma<DT, EPI>(a, mt, st);                                                                    \
-            } else {                                                                                                  \
-                PRIMX_NOTE_KERNEL("gemm144_kernel<%d, %d, %d>", DT, EPI, KT);                                         \
-                hipLaunchKernelGGL((gemm144_kernel<DT, EPI, KT>), dim3(mt * (a.N / 144)), dim3(512), 0, st, a);       \
-            }                                                                                                         \
-        } else {                                                                                                      \
-            PRIMX_NOTE_KERNEL("gemm_kernel<%d, %d, 32, 2, 2, 2, 2, %d, %d>", DT, EPI, GATHER, KT);                    \
-            hipLaunchKernelGGL((gemm_kernel<DT, EPI, 32, 2, 2, 2, 2, GATHER, KT>), dim3(mt * ((a.N + 127) / 128)),    \
-                               dim3(256), 0, st, a);                                                                  \
-        }                                                                                                             \
-    } while (0)
-    if (tail) PRIMX_GEMM_LAUNCH(1);
-    else PRIMX_GEMM_LAUNCH(0);
-#undef PRIMX_GEMM_LAUNCH
+    // (the register-staged kernels check every 16-byte chunk against K: one compare per load buys half the instantiations of a
+    // compile-time "K has a tail" flag; the LDS-DMA kernels need K % 64 == 0.  The narrow 128 x 32 tile exists for the epilogues
+    // that meet N <= 32 - the VAE's convolutions and plain Linear)
+    if (a.N <= 32 && (EPI == EPI_RES || EPI == EPI_LINEAR)) {
+        if constexpr (EPI == EPI_RES || EPI == EPI_LINEAR) {
+            PRIMX_NOTE_KERNEL("gemm_kernel<%d, %d, 32, 4, 1, 1, 1, %d>", DT, EPI, GATHER);
+            hipLaunchKernelGGL((gemm_kernel<DT, EPI, 32, 4, 1, 1, 1, GATHER>), dim3(mt * ((a.N + 31) / 32)), dim3(256), 0, st, a);
+        }
+    } else if (use_big && !tail && !GATHER) {
+        launch144_dma<DT, EPI, 1>(a, mt, st);
+    } else if (a.N % 144 == 0 && !GATHER) {
+        if (!tail) {
+            launch144_dma<DT, EPI>(a, mt, st);
+        } else {
+            PRIMX_NOTE_KERNEL("gemm144_kernel<%d, %d>", DT, EPI);
+            hipLaunchKernelGGL((gemm144_kernel<DT, EPI>), dim3(mt * (a.N / 144)), dim3(512), 0, st, a);
+        }
+    } else {
+        PRIMX_NOTE_KERNEL("gemm_kernel<%d, %d, 32, 2, 2, 2, 2, %d>", DT, EPI, GATHER);
+        hipLaunchKernelGGL((gemm_kernel<DT, EPI, 32, 2, 2, 2, 2, GATHER>), dim3(mt * ((a.N + 127) / 128)), dim3(256), 0, st, a);
+    }
     PRIMX_CHECK_LAUNCH(name);
     return PRIMX_OK;
 }

@@ -293,7 +293,7 @@ extern "C" int primx_cast16(const float* in, void* out, int dtype, int64_t n, vo
 
 // One 4-byte load per 128-byte line: pulls [ptr, ptr + bytes) into the Infinity Cache (and the L2 of the XCDs that run it).  Meant
 // for a SIDE stream while a compute-bound kernel runs on the main one: the weights of the next GEMM then come from the cache
-// instead of HBM (the 128 x 144 GEMMs ran 2 - 4 us longer inside the step than with resident weights).
+// instead of HBM (the 128 x 144 GEMMs ran 2 - 4 us longer inside the step than with resident weights, DESIGN_LOG.md section 4).
 __global__ __launch_bounds__(256) void prefetch_lines_kernel(const char* __restrict__ p, int64_t lines) {
     const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (l < lines) {

@@ -15,7 +15,7 @@ Same constructor kwargs, same ``state_dict`` keys (515 tensors for the shipped c
   writing a [depth, ...] K / V^T cache - fixed per-launch cost dominates these small-K GEMMs;
 * rounding points follow the reference's fp16/bf16 autocast topology (fp32 residual stream and
   LayerNorm, 16-bit Linear/attention outputs, 16-bit modulation vectors, 16-bit CFG combine), see
-  DESIGN.md "Numerics".
+  DESIGN.md section 6.
 
 Two numeric routes, selected exactly as the reference selects them (dit_crossattn.py:184,197):
 ``enable_amp=True`` with fp16 / bf16 -> the autocast topology on the 16-bit MFMA path (production, everything above);
@@ -167,9 +167,13 @@ class DiT(nn.Module):
         # weight prefetch of the loader-wave GEMMs (_forward16): 2 = carried by the GEMM launches one or two ahead, 1 = carried by the
         # LayerNorm launches, 0 = off (PRIMX_WPREFETCH)
         self.weight_prefetch = int(os.environ.get("PRIMX_WPREFETCH", "2"))
-        # the LayerNorm + modulate that follows every gated residual add runs in the tail of that GEMM's kernel (_forward16; one
-        # launch of its own per forward instead of 3 per block + 1).  Bit-identical results; PRIMX_DIT_FUSE_LN=0 keeps the launches.
+        # the LayerNorm + modulate that follows every gated residual add is requested from the SAME entry point as the GEMM
+        # (primx_linear_gate_residual_ln; PRIMX_DIT_FUSE_LN=0: separate primx_layernorm_modulate calls).  `ln_in_kernel`
+        # (PRIMX_DIT_LN_TAIL=1) additionally hands the library the sync words that let it run the LayerNorm in the TAIL of the GEMM
+        # kernel: bit-identical, and measured SLOWER than the launch it saves in every arrival protocol tried in round 4 (10.25 vs
+        # 8.99 ms per step at best, DESIGN.md section 4 / DESIGN_LOG.md section 10) - off by default, kept as a measured experiment.
         self.fuse_ln = os.environ.get("PRIMX_DIT_FUSE_LN", "1") != "0"
+        self.ln_in_kernel = os.environ.get("PRIMX_DIT_LN_TAIL", "0") == "1"
         self._ln_sync: Dict = {}              # device -> int32 workspace of the fused route (zero between launches)
         self._side: Dict = {}
         self._t_plan: Optional[Dict] = None   # plan_timesteps(): the coming calls' timesteps and their modulation table
@@ -640,15 +644,16 @@ class DiT(nn.Module):
         wpf = int(self.weight_prefetch)
         collapse = bool(self.collapse_null_cross_attention) and null_half
         blocks = pk["blocks"]
-        # LayerNorm in the tail of the gate-residual GEMMs (`fuse_ln`, round 4): every gated residual add of a block is followed by
-        # the LayerNorm + modulate of the next branch (dit_crossattn.py:55-57) - of the next block after fc2, of the final layer
-        # after the last one.  ops.linear_gate_residual(ln=...) produces both (one kernel where the shape allows, bit-identical to
-        # the two launches either way), so only the FIRST LayerNorm of a forward is a launch of its own: 85 -> 1 at DiT-XL.
-        # Not with the LayerNorm-carried prefetch (wpf == 1: that mode needs the LayerNorm launches).
+        # `fuse_ln` (round 4): every gated residual add of a block is followed by the LayerNorm + modulate of the next branch
+        # (dit_crossattn.py:55-57) - of the next block after fc2, of the final layer after the last one - so both are requested
+        # from one entry point, ops.linear_gate_residual(ln=...): bit-identical to the separate calls, and only the FIRST LayerNorm
+        # of a forward is a call of its own.  Whether the library runs the LayerNorm as a second launch (default) or in the tail of
+        # the GEMM kernel is decided by the `sync` words (`ln_in_kernel`).  Not with the LayerNorm-carried prefetch (wpf == 1: that
+        # mode needs the LayerNorm launches to carry the ranges).
         fuse = bool(self.fuse_ln) and wpf != 1
         sync = None
         sync_w = ops.ln_sync_words(T)
-        if fuse:
+        if fuse and self.ln_in_kernel:
             # (two regions: with `cfg_streams` the two halves run concurrently and must not share words)
             key = str(dev)
             sync = self._ln_sync.get(key)
@@ -671,7 +676,9 @@ class DiT(nn.Module):
             m = mod[b0:b1, i * 9 * D:(i + 1) * 9 * D]
             ch = [m[:, j * D:(j + 1) * D] for j in range(9)]  # shift/scale/gate x (mca, msa, mlp)
             def ln_of(shift, scale):                     # the LayerNorm that follows a gated residual add, fused into its GEMM
-                return (shift, scale, xh, self.LN_EPS, sync[:sync_w] if b0 == 0 else sync[sync_w:]) if fuse else None
+                if not fuse:
+                    return None
+                return (shift, scale, xh, self.LN_EPS, None if sync is None else (sync[:sync_w] if b0 == 0 else sync[sync_w:]))
             # ---- cross-attention to the image tokens (dit_crossattn.py:55, attention.py:96-114)
             if not fuse or i == 0:                       # (fused: the previous block's fc2 launch has normalised these rows)
                 # (the block's cross-attention K / V as the prefetch instead: -1.0 us on that kernel, +0.5 on this one)
@@ -716,7 +723,7 @@ class DiT(nn.Module):
         if self.cfg_streams and null_half and self.depth and ops.PROFILE is None:
             # Two HIP streams, one per CFG half (the conditional and the unconditional rows are independent chains of
             # kernels): every GEMM of this path ends with a write burst that nothing of ITS OWN kernel can overlap
-            # (DESIGN.md section 4); with the second chain a few kernels behind the first, one chain's burst drains
+            # (DESIGN_LOG.md section 4); with the second chain a few kernels behind the first, one chain's burst drains
             # under the other chain's matrix phase.  Same kernels, same arithmetic per row.
             main = torch.cuda.current_stream()
             side = self._side_stream(dev)

@@ -539,7 +539,8 @@ def main() -> None:
             res["with_expanded_null_kv"] = expanded
         res.update(side)
         if args.config in ("ddim", "c4"):
-            res["ln_in_gemm_tail"] = {"enabled": bool(getattr(model, "fuse_ln", False)), "sync_timeouts": ops.ln_sync_timeouts()}
+            res["ln_in_gemm_tail"] = {"enabled": bool(getattr(model, "fuse_ln", False) and getattr(model, "ln_in_kernel", False)),
+                                      "sync_timeouts": ops.ln_sync_timeouts()}
         if prof:
             res["roofline"], res["kernels"] = kernel_report(prof, args.steps, traffic_file())
         if dleg:

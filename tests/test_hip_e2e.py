@@ -17,3 +17,16 @@ def test_generate_small():
     last = r.stdout.strip().splitlines()[-1]
     assert "tokens (1, 17, 96)" in last and "samples (1, 64, 68)" in last and "recon_param (1, 64, 3076)" in last
     assert "sdf grid (24, 24, 24)" in last and "preview (1, 4, 48, 48)" in last
+
+
+def test_validate_checkpoint_script():
+    """tools/validate_checkpoint.py (the real-checkpoint comparison to run where the released files exist) on a SYNTHETIC small
+    fp16 checkpoint: checkpoint -> strict load / packed route -> forward_with_cfg, a 3-step trajectory and the VAE decode against
+    the fp32 CPU side, one JSON report that says PASS."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "validate_checkpoint.py"), "--selftest"], capture_output=True,
+                       text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    rep = json.loads(r.stdout[r.stdout.index("{"):])
+    assert rep["pass"] and rep["forward_with_cfg"]["packed_route_bit_identical"] and rep["vae_decode"]["pass"]
+    assert len(rep["ddim_trajectory"]["rel_l2_per_step"]) == 3

@@ -21,11 +21,12 @@ def ops():
 
 
 def _default_dispatch() -> bool:
-    """False when a kernel-selection switch of DESIGN.md section 8 is set: the arithmetic checks still run (that is what
+    """False when a kernel-selection switch of DESIGN_LOG.md section 8 is set: the arithmetic checks still run (that is what
     tools/gpu/gpu_verify.sh --switches is for), the assertions on WHICH kernel was launched do not apply."""
     import os
     return not any(os.environ.get(v) for v in ("PRIMX_GEMM_LOADER", "PRIMX_GEMM_NOBIG", "PRIMX_GEMM_P2", "PRIMX_GEMM_BIG_MIN",
-                                               "PRIMX_GEMM_BIGHEADS_MIN", "PRIMX_GEMM_NOGEMV", "PRIMX_GEMM_PROF", "PRIMX_LIB"))
+                                               "PRIMX_GEMM_BIGHEADS_MIN", "PRIMX_GEMM_NOGEMV", "PRIMX_GEMM_PROF", "PRIMX_LIB", "PRIMX_GEMM_W",
+                                               "PRIMX_LN_FUSE", "PRIMX_LN_FUSE_MAXGRID"))
 
 
 def _mk(seed, M, N, K, dtype):
@@ -225,7 +226,7 @@ def test_big_tile_edges(ops, dtype, M, K):
 def test_reported_kernel_names_of_the_headline_shapes(ops):
     """bench.py's per-kernel lines and profiles/r*_traffic.json are keyed by the kernel name the LIBRARY reports for a launch
     (primx_last_gemm_kernel: what csrc/gemm.hip's dispatch actually selected, as rocprofv3 prints it) + the launch shape.
-    The BASELINE configs[1] shapes must land on the kernels DESIGN.md section 4 says they do."""
+    The BASELINE configs[1] shapes must land on the kernels DESIGN_LOG.md section 4 says they do."""
     from topia_xl_amd import _lib
     if not _default_dispatch():
         pytest.skip("a kernel-selection switch is set")
@@ -243,7 +244,7 @@ def test_reported_kernel_names_of_the_headline_shapes(ops):
     ops.linear(A[:, :D].contiguous(), W[:, :D].contiguous(), b)
     assert name() == "gemm288p_dma_kernel<1>"                                              # fc1: 256 workgroups of 256 x 288, two passes
     ops.linear(A[:, :D].contiguous(), W[:136, :D].contiguous(), b[:136])
-    assert name().startswith("gemm_kernel<1, 0, 32, 2, 2, 2, 2")                           # final layer
+    assert name().startswith("gemm_kernel<1, 0, 32, 2, 2, 2, 2, 0>")                           # final layer
     ops.linear(A[:2, :D].contiguous(), W[:, :D].contiguous(), b)
     assert name() == "gemv16_kernel<1, 4>"                                                 # adaLN modulation rows
     q = ops.alloc_heads(2, H, 2048, dh, _lib.HEADS_ROWS, f16, DEV, 256, role="q")
@@ -415,3 +416,48 @@ def test_gate_residual_layernorm_two_launch_route(ops):
         ops.linear_gate_residual(A.to(DEV), W.to(DEV), b.to(DEV), gd, xb, rpb, ln=(sh, sc, lnb, 1e-6, sync))
         assert not _lib.load().primx_last_gemm_kernel().decode().endswith(", 5>")
         assert torch.equal(xa, xb) and torch.equal(lna, lnb)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_persistent_big_tile_kernel(ops, dtype):
+    """gemm288w_dma_kernel (round 4): the persistent 4-wave 256 x 288 kernel that the dense-output epilogues take when a launch
+    has more tiles than CUs (T >= 8192 at the DiT's widths).  Linear + GELU, gate-residual and residual epilogues at multi-tile
+    shapes - several tiles per workgroup, a ragged last row tile, tile counts that do not divide by the grid - against float64
+    matmuls computed on the GPU (the CPU would need minutes at these sizes)."""
+    from topia_xl_amd import _lib
+    name = lambda: _lib.load().primx_last_gemm_kernel().decode()
+    r16 = lambda t: t.to(dtype).double()
+    for (M, N, K) in ((32768, 1152, 1152), (16384 + 300, 1152, 256), (8192, 4608, 1152), (20000, 2304, 512)):
+        g = torch.Generator(device=DEV).manual_seed(M + N)
+        A = torch.randn(M, K, device=DEV, generator=g).to(dtype)
+        W = (torch.randn(N, K, device=DEV, generator=g) * K ** -0.5).to(dtype)
+        b = (torch.randn(N, device=DEV, generator=g) * 0.3).to(dtype)
+        ref = A.double() @ W.double().t() + b.double()
+        many = ((M + 255) // 256) * (N // 288) > 256
+        # Linear + tanh-GELU
+        got = ops.linear(A, W, b, act=1)
+        if _default_dispatch():
+            assert name().startswith("gemm288w_dma_kernel") == many, (name(), M, N, K)
+        want = r16(F.gelu(r16(ref).float(), approximate="tanh"))
+        assert rel_l2(got, want) < 2 * TOL[dtype], (M, N, K, rel_l2(got, want))
+        # canary row behind a ragged end
+        out = torch.full((M + 1, N), 7.0, dtype=dtype, device=DEV)
+        ops.linear(A, W, b, out=out[:M])
+        assert float(out[M].float().min()) == 7.0 and float(out[M].float().max()) == 7.0 and rel_l2(out[:M], r16(ref)) < TOL[dtype]
+        # gate-residual (fp32 stream, two batch entries)
+        rpb = (M + 1) // 2
+        gate = (torch.randn(2, N, device=DEV, generator=g) * 0.5).to(dtype)
+        x0 = torch.randn(M, N, device=DEV, generator=g)
+        x = x0.clone()
+        ops.linear_gate_residual(A, W, b, gate, x, rpb)
+        if _default_dispatch():
+            assert name().startswith("gemm288w_dma_kernel") == many, name()
+        bidx = torch.arange(M, device=DEV) // rpb
+        xr = x0.double() + r16(gate.double()[bidx] * r16(ref))
+        assert rel_l2(x, xr) < 1e-3, (M, N, K, rel_l2(x, xr))
+        # residual epilogue (the VAE's Linear + residual)
+        res = torch.randn(M, N, device=DEV, generator=g).to(dtype)
+        got = ops.linear_residual(A, W, b, res, 0.70710678)
+        assert rel_l2(got, (ref + res.double()) * 0.70710678) < TOL[dtype]
+        del A, W, ref, want, out, x, x0, xr, res, got
+        torch.cuda.empty_cache()

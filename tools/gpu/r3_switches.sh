@@ -1,5 +1,5 @@
 #!/bin/bash
-# the switch matrix of DESIGN.md section 8 on the final tree (the parity tests of the GEMM / DiT / VAE / attention files under each alternate path)
+# the switch matrix of DESIGN_LOG.md section 8 on the final tree (the parity tests of the GEMM / DiT / VAE / attention files under each alternate path)
 OUT=gpurun_out/switches
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

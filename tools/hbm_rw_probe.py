@@ -1,4 +1,4 @@
-"""HBM write vs read bandwidth with plain torch kernels (context for the write-drain-bound GEMM epilogues)."""
+"""HBM write vs read bandwidth with plain torch kernels (context for the write-drain-bound GEMM epilogues, DESIGN_LOG.md section 4)."""
 import torch
 dev = "cuda:0"
 def t(fn, n=20):

@@ -1,6 +1,6 @@
 """Model of one loader wave's in-order DMA queue in gemm144l_dma_kernel built with -DPRIMX_G144L_XLDS=1 (csrc/gemm.hip): checks that
 the `s_waitcnt vmcnt(N)` in front of every barrier implies the data the barrier publishes, for every K / 64 >= 2, and that no more
-than 63 instructions are ever outstanding (the counter's range).  Host-only; the kernel itself is untested."""
+than 63 instructions are ever outstanding (the counter's range).  Host-only; the kernel itself is untested (DESIGN_LOG.md section 9)."""
 NL = 17   # DMA wave-instructions per tile and loader wave
 
 
