@@ -671,137 +671,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs<DT> p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// T144: 128 x 144 tile, 8 waves = 4 (M) x 2 (K halves).  Wave (kg, wm) multiplies rows wm*32..+31 by all
-// 144 columns over k-half kg (32 of the 64 k's of every k-tile) with 2 x 9 tiles of 16x16x32 - two waves
-// per SIMD hide each other's LDS/barrier latency at ~190 VGPRs, and each wave stages only 1/8 of a tile.
-// The two K halves are summed through LDS at the end; ownership of the 9 column tiles is split 5 / 4
-// between the halves so both run the epilogue.
-template <int DT, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm144_kernel(const GemmArgs<DT> p) {
-    using S = typename T16<DT>::S;
-    using V8 = typename T16<DT>::V8;
-    constexpr int BM = 128, BN = 144, MI = 2, NI = 9;
-    constexpr int TA = BM * 64, TW = BN * 64;
-    constexpr int NA = 2, NW = 3;                       // 16-byte chunks per thread (512 threads)
-    constexpr int RED_HALVES = BM * BN * 2;             // fp32 reduction scratch, in halves (73,728 B)
-    constexpr int LDS_HALVES = (2 * (TA + TW) > RED_HALVES) ? 2 * (TA + TW) : RED_HALVES;
-    __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kg = wave >> 2, wm = wave & 3;
-    const int lr = lane & 15, lg = lane >> 4;
-
-    const int nt = p.N / BN, mt = (p.M + BM - 1) / BM;
-    const int id = xcd_remap(blockIdx.x, nt * mt);
-    const int m0 = (id / nt) * BM, n0 = (id % nt) * BN;
-
-    const int kc = (tid & 7) * 8;
-    const S* ga[NA];
-    const S* gw[NW];
-    int offa[NA], offw[NW];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int row = (tid + 512 * i) >> 3;
-        ga[i] = p.A + (int64_t)min(m0 + row, p.M - 1) * p.K + kc;
-        offa[i] = lds_off(row, tid & 7);
-    }
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        const int row = min((tid + 512 * i) >> 3, BN - 1);
-        gw[i] = p.W + (int64_t)(n0 + row) * p.K + kc;
-        offw[i] = lds_off(row, tid & 7);
-    }
-    const bool w_last = tid + 512 * (NW - 1) < BN * 8;  // 1152 W chunks = 2.25 per thread (waves 0,1 take the rest)
-
-    auto load_tile = [&](int kt, V8 (&ra)[NA], V8 (&rw)[NW]) {
-        const bool k_ok = kt * BK + kc < p.K;
-        const int koff = k_ok ? kt * BK : 0;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = ldg16<V8, S>(ga[i] + koff, k_ok);
-#pragma unroll
-        for (int i = 0; i < NW; ++i) rw[i] = ldg16<V8, S>(gw[i] + koff, k_ok);
-    };
-    auto store_tile = [&](int buf, V8 (&ra)[NA], V8 (&rw)[NW]) {
-        S* base = smem + buf * (TA + TW);
-#pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<V8*>(base + offa[i]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < NW; ++i)
-            if (i < NW - 1 || w_last) *reinterpret_cast<V8*>(base + TA + offw[i]) = rw[i];
-    };
-
-    f32x4 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int a_row = wm * 32 + lr;
-    const int chunk = kg * 4 + lg;  // this wave's k-half: k = kg*32 + lg*8 .. +7
-    auto compute = [&](int buf) {
-        const S* As = smem + buf * (TA + TW);
-        const S* Ws = As + TA;
-        V8 a[MI], b[NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const V8*>(As + lds_off(a_row + i * 16, chunk));
-#pragma unroll
-        for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(Ws + lds_off(lr + j * 16, chunk));
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(a[i], b[j], acc[i][j]);
-    };
-
-    const int nk = (p.K + BK - 1) / BK;
-    V8 ra0[NA], rw0[NW], ra1[NA], rw1[NW];
-    load_tile(0, ra0, rw0);
-    load_tile(min(1, nk - 1), ra1, rw1);
-    store_tile(0, ra0, rw0);
-    __syncthreads();
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {  // branch-free body (see gemm_kernel): keeps the counted vmcnt waits
-        load_tile(min(kt + 2, nk - 1), ra0, rw0);
-        compute(0);
-        store_tile(1, ra1, rw1);
-        __syncthreads();
-        load_tile(min(kt + 3, nk - 1), ra1, rw1);
-        compute(1);
-        store_tile(0, ra0, rw0);
-        __syncthreads();
-    }
-    if (kt < nk) compute(0);
-    __syncthreads();
-
-    // ---- sum the two K halves through LDS: K-half 0 owns column tiles 0..4, K-half 1 owns 5..8
-    float* red = reinterpret_cast<float*>(smem);  // [wm][mi][ni][r][lane]: lane-contiguous, conflict-free
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const bool mine = (ni < 5) == (kg == 0);
-            if (!mine) {
-                float* dst = red + (((wm * MI + mi) * NI + ni) * 4) * 64 + lane;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dst[r * 64] = acc[mi][ni][r];
-            }
-        }
-    __syncthreads();
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const bool mine = (ni < 5) == (kg == 0);
-        if (!mine) continue;
-        const ColInfo c = make_col<DT, EPI>(p, n0 + ni * 16 + lr);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const float* src = red + (((wm * MI + mi) * NI + ni) * 4) * 64 + lane;
-            const float q[4] = {acc[mi][ni][0] + src[0], acc[mi][ni][1] + src[64], acc[mi][ni][2] + src[128],
-                                acc[mi][ni][3] + src[192]};
-            epilogue_quad<DT, EPI>(p, c, m0 + wm * 32 + mi * 16 + 4 * lg, q);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
+// T144: 128 x 144 tile, 8 waves = 4 (M) x 2 (K halves).  Wave (kg, wm) multiplies rows wm*32..+31 by all 144 columns over k-half kg
+// (32 of the 64 k's of every k-tile) with 2 x 9 tiles of 16x16x32; the two halves meet in LDS.  (A register-staged form of this tile
+// served K tails until round 4; those launches - small test models only - now take the generic 128 x 128 kernel above.)
 // T144 with LDS-DMA staging (K % 64 == 0): same tile / wave roles / reduction as gemm144_kernel, but the
 // operand tiles go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a
 // 3-stage ring: no staging VGPRs, no ds_write pass (272 of the 640 LDS-array cycles per k-tile measured on
@@ -1876,326 +1748,12 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// PERSISTENT big tile (round 4): 256 x 288 per tile as in gemm288q, but FOUR waves of 128 x 144 with the whole register file (one
-// wave per SIMD: 512 registers - 288 accumulators + two fragment sets + one staged slice) and a workgroup that walks MANY tiles,
-// one continuous stream of 32-wide k-slices through a 4-stage LDS ring.
-// Why (round-3 timelines, DESIGN_LOG.md section 4): (1) the 8-wave tile reads every A fragment twice and every W fragment four
-// times from LDS - 106 KB of fragment reads + 35 KB of staging writes per slice against the 1152 cycles of its MFMAs is 122 B/clk
-// of the array's 128: its loop cannot run at the matrix rate (measured 1650 cycles per slice); four waves of 128 x 144 read 70 KB.
-// (2) with several tiles per CU (T >= 8192: every GEMM of the large-batch configurations) a one-tile workgroup pays its ring fill
-// (~6k cycles) and its store drain (~5k) un-overlapped for every tile, because the next workgroup cannot start before the LDS is
-// free.  Here the operand stream simply continues into the next tile - its first slices are in flight or landed while the epilogue
-// of the previous tile runs - and nothing ever waits for the stores.
-// Operands go THROUGH REGISTERS (global_load_dwordx4 -> ds_write_b128), not by LDS-DMA: the first form of this kernel issued the DMA
-// from the compute waves and measured 1917 cycles per slice - with one wave per SIMD nobody covers a wave that sits in the DMA
-// unit's queue (~65 cycles per issue x 9 issues per slice), and a 512-register wave leaves no room for a loader wave
-// (profiles/r4_experiments.txt section 2).  A plain load is asynchronous at issue; its 36 staging registers fit the budget, and
-// every wait on it is a compiler-counted vmcnt that never includes a younger store.
-// Phase p (slice p of the stream): barrier | MFMA group 0 | ds_write of the staged slice p + 3 into the stage slice p - 1 vacated |
-// global loads of slice p + 4 into the staging registers | fragment reads of slice p + 1 into the other set | MFMA groups 1..8.
-// Operands swapped (accumulator = C^T: a lane owns one row and four consecutive columns), dense-output epilogues from registers;
-// the gate-residual epilogue requests the residual rows of row group i + 1 BEFORE it stores group i (the in-order counter then
-// never makes a load wait for a store).  Accumulators are pinned: columns 0..127 of the wave tile in AGPRs, 128..143 in VGPRs
-// (inline-asm MFMAs: left to the allocator the 32 that overflow the 256 AGPRs wander between the files, 70 moves per phase).
-template <int DT, bool IN_AGPR>
-__device__ __forceinline__ void mfma16_pin(f32x4& acc, const typename T16<DT>::V8 a, const typename T16<DT>::V8 b) {
-    if constexpr (DT == PRIMX_F16) {
-        if constexpr (IN_AGPR) asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-        else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-    } else {
-        if constexpr (IN_AGPR) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-        else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-    }
-}
-
-template <int DT, int EPI>
-__global__ __launch_bounds__(256, 1) void gemm288w_dma_kernel(PRIMX_GEMM_PARAMS(DT)) {
-    PRIMX_GEMM_ARGS(DT);
-    static_assert(EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_RES, "dense-output epilogues only");
-    unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, p_loop = 0, p_epi = 0;   // PRIMX_GEMM_PROF=1 timeline (see g_gemm_prof)
-    if (pl_prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
-    using S = typename T16<DT>::S;
-    using V8 = typename T16<DT>::V8;
-    using V4e = typename T16<DT>::V4;
-    constexpr int BM = 256, BN = 288, MI = 8, NI = 9, KS = 32, NST = 4;
-    constexpr int ROWS = BM + BN, STAGE = ROWS * KS, NINST = ROWS / 16, NSLOT = (NINST + 3) / 4;   // 34 wave-instructions per slice: 9 (waves 0, 1) / 8
-    static_assert(NST * STAGE * 2 <= 160 * 1024 && NSLOT == 9, "LDS budget / slot split");
-    __shared__ __attribute__((aligned(16))) S smem[NST * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 15, lg = lane >> 4;
-    const int nt = pl_N / BN, mt = (pl_M + BM - 1) / BM, ntiles = nt * mt;
-    const int nks = pl_K / KS;                                      // even, >= 8 (host)
-    const int G = gridDim.x;                                        // a multiple of 8 when a workgroup has more than one tile: tile v = blockIdx.x + r G stays on this XCD
-    auto tile_at = [&](int v, int& m0, int& n0) {
-        int mi_t, ni_t;
-        if (pl_xcd_gm > 0) {
-            xcd_tile2d(v, mt, nt, pl_xcd_gm, mi_t, ni_t);
-        } else {
-            const int id = xcd_remap(v, ntiles);
-            mi_t = id / nt;
-            ni_t = id - mi_t * nt;
-        }
-        m0 = mi_t * BM;
-        n0 = ni_t * BN;
-    };
-    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / G + 1 : 0;
-    if (my_tiles == 0) return;
-
-    // ---- the operand stream.  Slot i of this wave moves 16 rows of the 544-row stage image (rows < 256: activations, the rest:
-    // weights; 64 bytes per row and slice, four lanes per row, the 16-byte chunk swizzled on the SOURCE address so that the LDS image
-    // is lane-linear).  `gp` holds the slot's source BYTE OFFSETS from A or from W (an instruction is all activation or all weight
-    // rows, so the base is wave-uniform; 32-bit - the host keeps M K and N K below 2^30 elements) for the tile being fetched.
-    unsigned gp[NSLOT];
-    auto point_at = [&](int r) {
-        int m0, n0;
-        tile_at((int)blockIdx.x + r * G, m0, n0);
-        int ln = lane;                                              // (opaque copy: hoisted out of the tile loop these values stayed live through the k-loop and spilled)
-        asm volatile("" : "+v"(ln));
-#pragma unroll
-        for (int i = 0; i < NSLOT; ++i) {
-            const int t = min(wave + 4 * i, NINST - 1);
-            const int row = 16 * t + (ln >> 2);
-            const int c = (ln & 3) ^ (((row >> 3) & 1) << 1);
-            gp[i] = 2u * (unsigned)((row < BM) ? min(m0 + row, pl_M - 1) * pl_K + c * 8 : (n0 + row - BM) * pl_K + c * 8);
-        }
-    };
-    const bool last_slot = wave + 4 * (NSLOT - 1) < NINST;         // wave-uniform (waves 0, 1)
-    V8 stg[NSLOT];                                                  // one staged slice: 36 registers
-    auto fetch = [&](int ks) {                                      // global -> registers: k-slice ks of the tile `gp` points at
-#pragma unroll
-        for (int i = 0; i < NSLOT; ++i) {
-            if (i < NSLOT - 1 || last_slot) {
-                const char* base = reinterpret_cast<const char*>((min(wave + 4 * i, NINST - 1) < BM / 16) ? pl_A : pl_W) + ks * (KS * 2);   // (uniform)
-                stg[i] = ldg16<V8, S>(reinterpret_cast<const S*>(base + gp[i]), true);
-            }
-        }
-    };
-    auto park = [&](int stage) {                                    // registers -> LDS stage (lane-linear 16 bytes per lane)
-        // (explicit: everything this wave has requested - the staged slice, issued a whole phase ago - has arrived.  The compiler's
-        // own counted waits were one short for one of the nine registers in the first build, profiles/r4_experiments.txt section 3;
-        // behind an epilogue this also waits for that tile's stores, which have had the epilogue itself to drain)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < NSLOT; ++i)
-            if (i < NSLOT - 1 || last_slot) *reinterpret_cast<V8*>(smem + stage * STAGE + (wave + 4 * i) * 512 + lane * 8) = stg[i];
-    };
-    point_at(0);
-#pragma unroll 1
-    for (int pre = 0; pre < NST - 1; ++pre) {                       // slices 0 .. 2 into stages 0 .. 2, slice 3 stays staged
-        fetch(pre);
-        park(pre);
-    }
-    fetch(NST - 1);
-
-    const int sw2 = ((lr >> 3) & 1) << 1;
-    const int a_off = (wm * 128 + lr) * KS + ((lg ^ sw2) << 3);            // + i * 16 rows
-    const int w_off = (BM + wn * 144 + lr) * KS + ((lg ^ sw2) << 3);       // + j * 16 rows
-    f32x4 acc[MI][NI];                                               // [..][0..7] pinned to AGPRs, [..][8] to VGPRs (mfma16_pin)
-    // Fragment registers: the A fragments and the first NPF W fragments of slice p + 1 are read one phase ahead (44 registers), the
-    // other W fragments at the top of their own phase, where the first NPF MFMA groups cover their latency (a full second set - 68
-    // more registers - pushed the kernel over 256 VGPRs and put scratch traffic into the loop)
-    constexpr int NPF = 3;
-    V8 a_n[MI], b_n[NPF];
-    int st = 0;                                                      // stage of the slice whose MFMAs run next
-    auto read_ahead = [&](int stage) {
-        const S* base = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a_n[i] = *reinterpret_cast<const V8*>(base + a_off + i * 16 * KS);
-#pragma unroll
-        for (int j = 0; j < NPF; ++j) b_n[j] = *reinterpret_cast<const V8*>(base + w_off + j * 16 * KS);
-    };
-    // Phase p.  `ks_fetch`: the k-slice of the tile under `gp` that is requested now (= slice p + 4 of the stream); the staged
-    // slice p + 3 goes into the stage that slice p - 1 vacated.  NEXT = false: the last phase of a tile reads nothing ahead (the
-    // registers are the epilogue's).
-    auto phase = [&](auto next_c, int ks_fetch) {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const int st_next = (st == NST - 1) ? 0 : st + 1;
-        const int st_prev = (st == 0) ? NST - 1 : st - 1;
-        const S* base = smem + st * STAGE;
-        V8 a[MI], b[NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a[i] = a_n[i];
-#pragma unroll
-        for (int j = 0; j < NPF; ++j) b[j] = b_n[j];
-#pragma unroll
-        for (int j = NPF; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(base + w_off + j * 16 * KS);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                if (j < NI - 1) mfma16_pin<DT, true>(acc[i][j], b[j], a[i]);
-                else mfma16_pin<DT, false>(acc[i][j], b[j], a[i]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (j == 0) {
-                park(st_prev);
-                __builtin_amdgcn_sched_barrier(0);
-                fetch(ks_fetch);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (j == NPF) {   // the read-ahead registers are free now (their values were copied / consumed above)
-                if constexpr (decltype(next_c)::value) {
-                    read_ahead(st_next);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        st = st_next;
-    };
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slices 0 .. 2 are in LDS
-    if (pl_prof) pc1 = __builtin_readcyclecounter();
-
-#pragma unroll 1
-    for (int r = 0; r < my_tiles; ++r) {
-        unsigned long long pt0 = 0;
-        if (pl_prof) pt0 = __builtin_readcyclecounter();
-        // (slice 3 of this tile sits in the staging registers since the previous tile's last phase - requested BEFORE that tile's
-        // stores, so that the wait in front of its ds_write does not include them; the price is 36 registers live across the epilogue)
-        read_ahead(st);                                              // slice 0 of this tile (in LDS since two phases ago)
-        int m0, n0;
-        tile_at((int)blockIdx.x + r * G, m0, n0);
-        const int nb = n0 + wn * 144 + 4 * lg;
-        // the accumulators start from the bias (fp32): no bias registers in the epilogue
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) {
-                const V4e bv = *reinterpret_cast<const V4e*>(p.bias + nb + j * 16);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) b4[q] = (float)bv[q];
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                acc[i][j] = b4;
-                // (an empty VOLATILE asm that owns the accumulator: the initialisation must be materialised HERE.  Left free, hipcc
-                // sank every v_accvgpr_write to just in front of the accumulator's first MFMA - an inline-asm MFMA it cannot see,
-                // so nothing provided the wait states between the VALU write and the matrix unit's SrcC read: a random ~0.7 % of
-                // a tile's elements came out wrong, profiles/r4_experiments.txt section 3)
-                if (j < NI - 1) asm volatile("" : "+a"(acc[i][j]));
-                else asm volatile("" : "+v"(acc[i][j]));
-            }
-        }
-        asm volatile("s_nop 7" ::: "memory");                        // (VALU / accvgpr write -> MFMA SrcC read)
-#pragma unroll 1
-        for (int ks = 0; ks < nks - 4; ++ks) phase(std::true_type{}, ks + 4);
-        // the last four phases of a tile request the first slices of the NEXT one (no next tile: the last slice again, into
-        // stages nobody reads)
-        const bool has_next = r + 1 < my_tiles;
-        if (has_next) point_at(r + 1);
-        phase(std::true_type{}, has_next ? 0 : nks - 1);
-        phase(std::true_type{}, has_next ? 1 : nks - 1);
-        phase(std::true_type{}, has_next ? 2 : nks - 1);
-        phase(std::false_type{}, has_next ? 3 : nks - 1);
-        // wait states between the last MFMA's write and the first read of an accumulator (the MFMAs are invisible to the recognizer)
-        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        unsigned long long pt1 = 0;
-        if (pl_prof) { pt1 = __builtin_readcyclecounter(); p_loop += pt1 - pt0; }
-
-        // ---- epilogue from registers: acc[i][j][q] = (C + bias)[m0 + wm*128 + i*16 + lr][n0 + wn*144 + j*16 + 4*lg + q]
-        const V4e bz = V4e{};                                         // (the shared epilogue helpers add a bias vector: zeros, the accumulators carry it)
-        if constexpr (EPI == EPI_GATE_RESIDUAL) {
-            // residual rows one row group ahead: loads (i + 1) are issued BEFORE stores (i), so the counted wait for them never
-            // includes a store (vmcnt is one in-order counter for both)
-            f32x4 xa[NI], xb[NI];
-            // (one gate row per tile: the host sends gate-residual launches here only when rows_per_batch % 256 == 0, so a 256-row
-            // tile lies in one batch entry; loaded before any store of this tile)
-            V4e gv[NI];
-            {
-                const S* grow = p.gate + (int64_t)(min(m0, pl_M - 1) / p.rows_per_batch) * p.gate_stride + nb;
-#pragma unroll
-                for (int j = 0; j < NI; ++j) gv[j] = *reinterpret_cast<const V4e*>(grow + j * 16);
-            }
-            auto rows_of = [&](int i, int& mc, bool& ok) {
-                const int m = m0 + wm * 128 + i * 16 + lr;
-                ok = m < pl_M;
-                mc = ok ? m : pl_M - 1;
-            };
-            auto load_x = [&](int i, f32x4 (&xv)[NI]) {
-                int mc; bool ok;
-                rows_of(i, mc, ok);
-                const float* xrow = p.x + (int64_t)mc * pl_N + nb;
-#pragma unroll
-                for (int j = 0; j < NI; ++j) xv[j] = *reinterpret_cast<const f32x4*>(xrow + j * 16);
-            };
-            auto finish = [&](int i, f32x4 (&xv)[NI]) {
-                int mc; bool ok;
-                rows_of(i, mc, ok);
-                float* xrow = p.x + (int64_t)mc * pl_N + nb;
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        xv[j][q] += rnd16<DT>((float)gv[j][q] * rnd16<DT>(acc[i][j][q]));
-                    if (ok) out_store(reinterpret_cast<f32x4*>(xrow + j * 16), xv[j]);
-                }
-            };
-            load_x(0, xa);
-#pragma unroll
-            for (int i = 0; i < MI; i += 2) {
-                load_x(i + 1, xb);
-                __builtin_amdgcn_sched_barrier(0);
-                finish(i, xa);
-                __builtin_amdgcn_sched_barrier(0);
-                if (i + 2 < MI) load_x(i + 2, xa);
-                __builtin_amdgcn_sched_barrier(0);
-                finish(i + 1, xb);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int m = m0 + wm * 128 + i * 16 + lr;
-                const bool ok = m < pl_M;
-                const int mc = ok ? m : pl_M - 1;
-                if constexpr (EPI == EPI_LINEAR) {
-                    // (16-byte stores: the lane groups of a row trade halves of neighbouring 16-column tiles, see gemm288q_dma_kernel)
-                    typedef unsigned int u32;
-                    S* orow = p.out + (int64_t)mc * pl_N + n0 + wn * 144;
-#pragma unroll
-                    for (int j = 0; j + 1 < NI; j += 2) {
-                        const u32x2 a = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j], bz));
-                        const u32x2 b = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j + 1], bz));
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-                        const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
-                        if (ok) out_store(reinterpret_cast<u32x4*>(orow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
-                    }
-                    if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), linear_out4<DT>(p, acc[i][NI - 1], bz));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        if (ok) epilogue_row4<DT, EPI>(p, m, nb + j * 16, acc[i][j], bz);
-                }
-            }
-        }
-        if (pl_prof) p_epi += __builtin_readcyclecounter() - pt1;
-        // (the source offsets are recomputed instead of kept: nine registers the epilogue then has for itself - a spill there is
-        // reloaded behind the tile's stores, and the in-order counter makes that reload wait for every one of them)
-        if (has_next) point_at(r + 1);
-    }
-    if (pl_prof) {
-        __builtin_amdgcn_s_waitcnt(0);
-        const unsigned long long pc3 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0) {
-            atomicMin(&g_gemm_prof[0], pr0); atomicMax(&g_gemm_prof[1], pr1);
-            atomicAdd(&g_gemm_prof[2], pc1 - pc0); atomicAdd(&g_gemm_prof[3], p_loop);
-            atomicAdd(&g_gemm_prof[4], p_epi); atomicAdd(&g_gemm_prof[5], 1ull); atomicAdd(&g_gemm_prof[6], pr0);
-            atomicAdd(&g_gemm_prof[8], pr1 - pr0); atomicAdd(&g_gemm_prof[9], pc3 - pc0);
-            if (blockIdx.x < 4096) {
-                unsigned xcc;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                g_gemm_wg[blockIdx.x][0] = pr0; g_gemm_wg[blockIdx.x][1] = pr1 - pr0; g_gemm_wg[blockIdx.x][2] = pc3 - pc0;
-                g_gemm_wg[blockIdx.x][3] = ((unsigned long long)(xcc & 15) << 32) | (unsigned)(p_epi);
-            }
-        }
-    }
-}
+// (Round 4 built a PERSISTENT form of the big tile here - four waves of 128 x 144 with the whole register file, one per SIMD, walking
+// many tiles as one operand stream, first fed by LDS-DMA, then through registers - to overlap ring fill and store drain at T >= 8192,
+// where every CU runs eight tiles back to back.  Both forms were correct and both lost to the 8-wave kernel above (fc1 at T = 32768:
+// 583 / 620 vs 453 us; the batch-8 step 66.8 / 70.4 vs 62.7 ms): with one wave per SIMD nobody covers the wave while it sits in the
+// DMA unit's queue or waits for its staged slice, and nobody covers it in the epilogue.  Removed; measurements, timelines and the
+// inline-asm-MFMA hazard found on the way: profiles/r4_experiments.txt sections 2 - 3, DESIGN_LOG.md section 10.)
 
 static const bool g_no_big = [] {   // PRIMX_GEMM_NOBIG=1 disables the 256x288 tile (A/B measurements)
     const char* e = getenv("PRIMX_GEMM_NOBIG");
@@ -2220,11 +1778,6 @@ static const int g_big_heads_min = [] {   // fewest 256x288 workgroups for which
 static const bool g_two_pass = [] {   // PRIMX_GEMM_P2=0: the Linear epilogue's big tile on the one-pass 8-wave kernel (gemm288q) instead of gemm288p
     const char* e = getenv("PRIMX_GEMM_P2");
     return !(e && e[0] == '0');
-}();
-
-static const int g_big_w = [] {   // PRIMX_GEMM_W: the persistent 4-wave 256x288 kernel (gemm288w) for the dense-output epilogues - 0 never,
-    const char* e = getenv("PRIMX_GEMM_W");   // 1 launches with more tiles than CUs, 2 every big-tile launch
-    return e ? atoi(e) : 1;
 }();
 
 static const bool g_xcd2d = [] {   // PRIMX_GEMM_XCD2D=0: whole tile rows per XCD in the 256x288 kernel (A/B measurements)
@@ -2281,7 +1834,6 @@ static const bool g_gemm_prof_on = [] {   // PRIMX_GEMM_PROF=1: synchronous laun
 // The kernel instantiation the last GEMM entry point called on this thread selected, spelled as rocprofv3 prints it
 // (primx_last_gemm_kernel(), include/primx_hip.h): bench.py tags its per-launch timings with what the C side actually
 // launched instead of a Python restatement of the dispatch rules below.
-static const bool g_gemm_prof_w_off = false;
 thread_local char g_last_gemm_kernel[112] = "";
 #define PRIMX_NOTE_KERNEL(...) snprintf(g_last_gemm_kernel, sizeof(g_last_gemm_kernel), __VA_ARGS__)
 
@@ -2329,18 +1881,7 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
         // two passes only when the launch is ONE round of workgroups (fc1 at T = 4096: exactly 256): there the first pass's stores
         // drain under the second pass (the step 8.97 -> 8.92 ms same box); with several rounds per CU the next workgroup already
         // overlaps the previous one's drain and the one-pass tile's fewer bytes per FLOP win (T = 32768: 428 vs 451 us)
-        constexpr bool W_OK = EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_RES;
-        const int ntiles = (int)grid.x;
-        if (BIG && W_OK && !g_gemm_prof_w_off && x.K >= 256 && (int64_t)x.M * x.K < (1ll << 30) && (int64_t)x.N * x.K < (1ll << 30) &&
-            (EPI != EPI_GATE_RESIDUAL || x.rows_per_batch % 256 == 0) &&
-            (g_big_w == 2 || (g_big_w == 1 && ntiles > 256))) {
-            if constexpr (W_OK) {
-                // persistent: at most one workgroup per CU, a multiple of 8 so that tile v = blockIdx.x + r G stays on one XCD
-                const dim3 pg(ntiles >= 256 ? 256 : ntiles);
-                PRIMX_NOTE_KERNEL("gemm288w_dma_kernel<%d, %d>", DT, EPI);
-                hipLaunchKernelGGL((gemm288w_dma_kernel<DT, EPI>), pg, dim3(256), 0, st, PRIMX_GEMM_PASS(x));
-            }
-        } else if (BIG && EPI == EPI_LINEAR && g_two_pass && (int)grid.x <= 256) {
+        if (BIG && EPI == EPI_LINEAR && g_two_pass && (int)grid.x <= 256) {
             PRIMX_NOTE_KERNEL("gemm288p_dma_kernel<%d>", DT);
             hipLaunchKernelGGL((gemm288p_dma_kernel<DT>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
         } else if (BIG) {
@@ -2391,7 +1932,7 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     fprintf(stderr, "%s<%d,%d> M=%d N=%d K=%d: %llu workgroups, events %.1f us, first start -> last end %.1f us, mean start offset "
                     "%.1f us, shader clock %.2f GHz (core cycles / 100 MHz ticks per workgroup); per workgroup (core cycles): entry->tile0 %.0f | main loop "
                     "%.0f | epilogue %.0f (LDS staging %.0f, read+store issue %.0f)\n",
-            BIG ? g_last_gemm_kernel : "gemm144_dma", DT, EPI, a.M, a.N, a.K,
+            BIG ? (EPI == EPI_LINEAR && g_two_pass && (int)grid.x <= 256 ? "gemm288p_dma" : "gemm288q_dma") : "gemm144_dma", DT, EPI, a.M, a.N, a.K,
             r[5], ms * 1e3, (r[1] - r[0]) * 0.01, (r[6] / n - (double)r[0]) * 0.01, r[8] ? (double)r[9] / (double)r[8] * 0.1 : 0.0,
             r[2] / n, r[3] / n, r[4] / n, (r[7] >> 32) / n,
             (r[7] & 0xffffffffull) / n);
@@ -2451,13 +1992,8 @@ int launch(const GemmArgs<DT>& a_in, hipStream_t st, const char* name) {
         }
     } else if (use_big && !tail && !GATHER) {
         launch144_dma<DT, EPI, 1>(a, mt, st);
-    } else if (a.N % 144 == 0 && !GATHER) {
-        if (!tail) {
-            launch144_dma<DT, EPI>(a, mt, st);
-        } else {
-            PRIMX_NOTE_KERNEL("gemm144_kernel<%d, %d>", DT, EPI);
-            hipLaunchKernelGGL((gemm144_kernel<DT, EPI>), dim3(mt * (a.N / 144)), dim3(512), 0, st, a);
-        }
+    } else if (a.N % 144 == 0 && !GATHER && !tail) {
+        launch144_dma<DT, EPI>(a, mt, st);
     } else {
         PRIMX_NOTE_KERNEL("gemm_kernel<%d, %d, 32, 2, 2, 2, 2, %d>", DT, EPI, GATHER);
         hipLaunchKernelGGL((gemm_kernel<DT, EPI, 32, 2, 2, 2, 2, GATHER>), dim3(mt * ((a.N + 127) / 128)), dim3(256), 0, st, a);

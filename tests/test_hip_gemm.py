@@ -25,7 +25,7 @@ def _default_dispatch() -> bool:
     tools/gpu/gpu_verify.sh --switches is for), the assertions on WHICH kernel was launched do not apply."""
     import os
     return not any(os.environ.get(v) for v in ("PRIMX_GEMM_LOADER", "PRIMX_GEMM_NOBIG", "PRIMX_GEMM_P2", "PRIMX_GEMM_BIG_MIN",
-                                               "PRIMX_GEMM_BIGHEADS_MIN", "PRIMX_GEMM_NOGEMV", "PRIMX_GEMM_PROF", "PRIMX_LIB", "PRIMX_GEMM_W",
+                                               "PRIMX_GEMM_BIGHEADS_MIN", "PRIMX_GEMM_NOGEMV", "PRIMX_GEMM_PROF", "PRIMX_LIB",
                                                "PRIMX_LN_FUSE", "PRIMX_LN_FUSE_MAXGRID"))
 
 
@@ -419,13 +419,12 @@ def test_gate_residual_layernorm_two_launch_route(ops):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_persistent_big_tile_kernel(ops, dtype):
-    """gemm288w_dma_kernel (round 4): the persistent 4-wave 256 x 288 kernel that the dense-output epilogues take when a launch
-    has more tiles than CUs (T >= 8192 at the DiT's widths).  Linear + GELU, gate-residual and residual epilogues at multi-tile
-    shapes - several tiles per workgroup, a ragged last row tile, tile counts that do not divide by the grid - against float64
-    matmuls computed on the GPU (the CPU would need minutes at these sizes)."""
-    from topia_xl_amd import _lib
-    name = lambda: _lib.load().primx_last_gemm_kernel().decode()
+def test_large_batch_big_tile_launches(ops, dtype):
+    """The dense-output epilogues at the LARGE-BATCH shapes (T = 8192 ... 32768 tokens: BASELINE configs[2] / [3] / [4] per GPU), where
+    the 256 x 288 kernel runs several rounds of workgroups per CU: Linear + GELU, gate-residual and residual epilogues, a ragged last
+    row tile, tile counts that do not divide by the CU count - against float64 matmuls computed on the GPU (the CPU would need
+    minutes at these sizes).  (Written in round 4 for the persistent 4-wave kernel, which passed it and was removed for being
+    slower; the shapes stay covered.)"""
     r16 = lambda t: t.to(dtype).double()
     for (M, N, K) in ((32768, 1152, 1152), (16384 + 300, 1152, 256), (8192, 4608, 1152), (20000, 2304, 512)):
         g = torch.Generator(device=DEV).manual_seed(M + N)
@@ -433,11 +432,8 @@ def test_persistent_big_tile_kernel(ops, dtype):
         W = (torch.randn(N, K, device=DEV, generator=g) * K ** -0.5).to(dtype)
         b = (torch.randn(N, device=DEV, generator=g) * 0.3).to(dtype)
         ref = A.double() @ W.double().t() + b.double()
-        many = ((M + 255) // 256) * (N // 288) > 256
         # Linear + tanh-GELU
         got = ops.linear(A, W, b, act=1)
-        if _default_dispatch():
-            assert name().startswith("gemm288w_dma_kernel") == many, (name(), M, N, K)
         want = r16(F.gelu(r16(ref).float(), approximate="tanh"))
         assert rel_l2(got, want) < 2 * TOL[dtype], (M, N, K, rel_l2(got, want))
         # canary row behind a ragged end
@@ -450,8 +446,6 @@ def test_persistent_big_tile_kernel(ops, dtype):
         x0 = torch.randn(M, N, device=DEV, generator=g)
         x = x0.clone()
         ops.linear_gate_residual(A, W, b, gate, x, rpb)
-        if _default_dispatch():
-            assert name().startswith("gemm288w_dma_kernel") == many, name()
         bidx = torch.arange(M, device=DEV) // rpb
         xr = x0.double() + r16(gate.double()[bidx] * r16(ref))
         assert rel_l2(x, xr) < 1e-3, (M, N, K, rel_l2(x, xr))
