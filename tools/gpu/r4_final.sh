@@ -1,0 +1,46 @@
+#!/bin/bash
+# round-4 end artefacts: whole GPU suite + smoke; same-box A/B of the headline step against the round-3 tree (prev_tree/, built from
+# commit a173a3f); benches (default line incl. decode / job / batch8 / bf16 legs, decode, c4, other BASELINE shapes); kernel traces;
+# PMC passes (FETCH_SIZE / WRITE_SIZE traffic, MFMA utilisation) - each PMC pass on its own, with --kernel-trace only
+R=r4
+OUT=gpurun_out/final_$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+DESEL=""; [ -f tests/golden/xl_c3_ddim5.npz ] || DESEL="--deselect tests/test_hip_fullconfig.py::test_configs2_batch8_ddim5_trajectory"
+timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -s $DESEL > $OUT/gpu_tests.log 2>&1; echo "pytest exit $?" >> $OUT/gpu_tests.log; tail -2 $OUT/gpu_tests.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu | tail -2 | tee $OUT/smoke.txt
+show() { python -c "import json,sys;r=json.load(open(sys.argv[1]));print('%.3f' % r['ms_per_step'], ['%.3f' % v for v in r['repeats_ms_per_step']])" $1; }
+H="bench.py --steps 25 --warmup 5 --no-cpu-baseline --no-parity --no-decode-leg --no-kernel-events"
+if [ -d prev_tree ]; then for rep in 1 2; do
+  (cd prev_tree && timeout 300 python $H > ../$OUT/ab_r3_$rep.json 2>> ../$OUT/ab.err); echo "round-3 tree: $(show $OUT/ab_r3_$rep.json)"
+  timeout 300 python $H --no-side-legs > $OUT/ab_r4_$rep.json 2>> $OUT/ab.err; echo "round-4 tree: $(show $OUT/ab_r4_$rep.json)"
+done; fi
+timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench exit $?"; cut -c1-300 $OUT/bench_default.json
+timeout 600 python bench.py --config decode > $OUT/bench_decode.json 2> $OUT/bench_decode.err; echo "decode exit $?"
+timeout 900 python bench.py --config c4 --no-cpu-baseline > $OUT/bench_c4.json 2> $OUT/bench_c4.err; echo "c4 exit $?"
+: > $OUT/bench_other.jsonl
+X="--no-cpu-baseline --no-parity --no-decode-leg --no-side-legs"
+timeout 400 python bench.py --batch 8 --steps 6 --warmup 2 $X >> $OUT/bench_other.jsonl 2>/dev/null
+timeout 400 python bench.py --batch 8 --dtype bf16 --steps 6 --warmup 2 $X >> $OUT/bench_other.jsonl 2>/dev/null
+timeout 400 python bench.py --batch 4 --n-prim 4096 --dtype bf16 --steps 6 --warmup 2 $X >> $OUT/bench_other.jsonl 2>/dev/null
+timeout 400 python bench.py --dtype bf16 --steps 20 --warmup 5 $X >> $OUT/bench_other.jsonl 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python bench.py $X --steps 25 > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o trace_decode -- python bench.py --config decode --no-cpu-baseline --no-parity > $OUT/bench_trace_decode.json 2> $OUT/bench_trace_decode.err
+B="python bench.py $X --steps 3 --warmup 1 --repeats 1 --no-kernel-events"
+D="python bench.py --config decode --no-cpu-baseline --no-parity --steps 2 --warmup 1 --repeats 1 --no-kernel-events"
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- $B > /dev/null 2> $OUT/fetch.err
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- $B > /dev/null 2> $OUT/write.err
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch_decode -- $D > /dev/null 2> $OUT/fetch_decode.err
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o write_decode -- $D > /dev/null 2> $OUT/write_decode.err
+M="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
+timeout 300 rocprofv3 --kernel-trace --pmc $M --output-format csv -d $OUT -o mfma -- $B > /dev/null 2> $OUT/mfma.err
+f() { find $PWD/$OUT -name "$1" | head -1; }
+for db in $(find $OUT -name "*.db"); do python tools/rocprof_summary.py $db ${db%.db}_summary.txt > /dev/null; done
+FC=$(f fetch_counter_collection.csv); WC=$(f write_counter_collection.csv); FD=$(f fetch_decode_counter_collection.csv); WD=$(f write_decode_counter_collection.csv)
+MC=$(f mfma_counter_collection.csv); O=$PWD/$OUT
+(cd tools && python pmc_traffic.py $FC $WC $O/traffic_ddim.json > $O/traffic_ddim.txt; python pmc_traffic.py $FD $WD $O/traffic_decode.json > $O/traffic_decode.txt
+ python pmc_mfma_util.py $MC - $O/mfma_util_ddim.txt > /dev/null)
+head -14 $OUT/mfma_util_ddim.txt | cut -c1-170
+for c in $(find $OUT -name "*_counter_collection.csv"); do rm -f "$c"; done
+find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "*.db" -size +20M -delete
+du -sh $OUT; ls $OUT | head -60
