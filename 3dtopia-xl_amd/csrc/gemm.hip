@@ -514,14 +514,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs<DT> p) {
                 const int64_t off = ok ? (((int64_t)((z * p.S3 + y) * p.S3 + x) << p.cin_log2) + ci) : 0;
                 ra[i] = ldg16<V8, S>(gbase[i] + off, ok);
             }
-        } else {
-            const bool k_ok = kt * BK + kc < p.K;  // K tail (K % 64 != 0): zero chunk
-#pragma unroll
-            for (int i = 0; i < NA; ++i) ra[i] = ldg16<V8, S>(ga[i] + (k_ok ? kt * BK : 0), k_ok);
         }
-        const bool k_ok = kt * BK + kc < p.K;
+        // K tail (K % 64 != 0): only the LAST k-tile can be partial.  A uniform branch keeps the per-lane predicate (compare, address
+        // select, eight value selects per chunk) out of every full tile: predicated everywhere, the final Linear of the DiT
+        // (4096 x 136 x 1152) ran 34.7 instead of 21 us (profiles/r4_experiments.txt section 4).  The empty asm keeps it a branch.
+        const bool full = (kt + 1) * BK <= p.K;
+        if (full) {
+            asm volatile("" ::: "memory");
+            if (!GATHER) {
 #pragma unroll
-        for (int i = 0; i < NW; ++i) rw[i] = ldg16<V8, S>(gw[i] + (k_ok ? kt * BK : 0), k_ok);
+                for (int i = 0; i < NA; ++i) ra[i] = ldg16<V8, S>(ga[i] + kt * BK, true);
+            }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) rw[i] = ldg16<V8, S>(gw[i] + kt * BK, true);
+        } else {
+            asm volatile("" ::: "memory");
+            const bool k_ok = kt * BK + kc < p.K;  // zero chunk past K
+            if (!GATHER) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) ra[i] = ldg16<V8, S>(ga[i] + (k_ok ? kt * BK : 0), k_ok);
+            }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) rw[i] = ldg16<V8, S>(gw[i] + (k_ok ? kt * BK : 0), k_ok);
+        }
     };
     auto store_tile = [&](int buf, V8 (&ra)[NA], V8 (&rw)[NW]) {
         S* base = smem + buf * (TA + TW);
