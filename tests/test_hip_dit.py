@@ -202,7 +202,7 @@ def test_layernorm_in_the_gemm_tail_changes_no_bit(pkg):
     t0 = ops.ln_sync_timeouts()
     outs = {}
     import os
-    switched = any(os.environ.get(v) for v in ("PRIMX_DIT_FUSE_LN", "PRIMX_DIT_LN_TAIL", "PRIMX_LN_FUSE", "PRIMX_GEMM_LOADER", "PRIMX_GEMM_PROF"))
+    switched = any(os.environ.get(v) for v in ("PRIMX_DIT_FUSE_LN", "PRIMX_DIT_LN_TAIL", "PRIMX_LN_FUSE", "PRIMX_GEMM_LOADER", "PRIMX_GEMM_PROF", "PRIMX_WPREFETCH"))
     if not switched:
         assert m.fuse_ln and not m.ln_in_kernel      # defaults: one entry point, the LayerNorm as the library's second launch
     for fuse in (True, False):
