@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs<DT> p) {
 // T144: 128 x 144 tile, 8 waves = 4 (M) x 2 (K halves).  Wave (kg, wm) multiplies rows wm*32..+31 by all 144 columns over k-half kg
 // (32 of the 64 k's of every k-tile) with 2 x 9 tiles of 16x16x32; the two halves meet in LDS.  (A register-staged form of this tile
 // served K tails until round 4; those launches - small test models only - now take the generic 128 x 128 kernel above.)
-// T144 with LDS-DMA staging (K % 64 == 0): same tile / wave roles / reduction as gemm144_kernel, but the
+// T144 with LDS-DMA staging (K % 64 == 0): same tile / wave roles / reduction as described above, but the
 // operand tiles go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a
 // 3-stage ring: no staging VGPRs, no ds_write pass (272 of the 640 LDS-array cycles per k-tile measured on
 // the register-staged kernel, profiles/r1_gemm_pmc.txt), two tiles in flight across every barrier.

@@ -1,7 +1,8 @@
 """Micro-benchmark of the big-tile GEMM kernels at the large-batch shapes (T = 32768 tokens: BASELINE configs[2] / [3] / [4] per GPU)
 and at the headline's T = 4096: Linear + GELU (fc1), gate-residual (proj, fc2), plain Linear - HIP-event timing over rotating
 buffers (8 output / input sets, so that nothing stays resident from one launch to the next), and the kernel the library selected.
-    PRIMX_GEMM_W=0|1|2 python tools/gemm_bench_big.py      # same-box A/B: 8-wave 256x288 kernels | default | persistent everywhere"""
+    PRIMX_LIB=<other build> python tools/gemm_bench_big.py      # same-box A/B against another library of the same ABI
+(written for the round-4 persistent-kernel experiment, whose PRIMX_GEMM_W switch is gone with the kernel)"""
 import os
 import sys
 
