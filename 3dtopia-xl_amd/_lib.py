@@ -35,7 +35,7 @@ SIGNATURES = {
     "primx_prefetch": [_p, _l, _p],
     "primx_silu_cast": [_p, _p, _i, _l, _p],
     "primx_cast16": [_p, _p, _i, _l, _p],
-    "primx_linear_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "primx_linear_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "primx_linear": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _l, _p],
     "primx_linear_gate_residual": [_p, _p, _p, _p, _l, _p, _i, _i, _i, _i, _i, _p, _l, _p],
     "primx_linear_gate_residual_ln": [_p, _p, _p, _p, _l, _p, _i, _i, _i, _i, _p, _p, _l, _p, _f, _p, _l, _i, _p, _l, _p],

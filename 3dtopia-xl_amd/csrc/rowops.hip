@@ -325,9 +325,11 @@ extern "C" int primx_silu_cast(const float* in, void* out, int dtype, int64_t n,
 // ---------------------------------------------------------------------------------------------
 // Small fp32 linear (LDS-tiled, 64x64 tile, 4x4 outputs per thread).  Not MFMA: these layers run
 // in fp32 outside autocast in the reference and are < 0.1 % of the step's FLOPs.
+// `out2` (may be null): a second destination that receives the same rows - `forward_with_cfg` embeds cat([x, x]), i.e. the same tokens
+// into both halves of the residual stream (dit_crossattn.py:205, 191): one kernel writes both instead of a kernel + a copy.
 __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ in, const float* __restrict__ W,
                                                          const float* __restrict__ bias, float* __restrict__ out,
-                                                         int M, int N, int K, int act_out) {
+                                                         float* __restrict__ out2, int M, int N, int K, int act_out) {
     constexpr int BK = 16;
     __shared__ float As[BK][64 + 4];
     __shared__ float Bs[BK][64 + 4];
@@ -355,17 +357,30 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
         }
         __syncthreads();
     }
+    const int nq = n0 + tc * 4;
+    const bool vec = (N & 3) == 0 && nq + 3 < N;          // four consecutive columns: one 16-byte store per row
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + tr * 4 + i;
         if (m >= M) continue;
+        f32x4 v4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + tc * 4 + j;
-            if (n >= N) continue;
-            float v = acc[i][j] + (bias ? bias[n] : 0.f);
+            const int n = nq + j;
+            float v = acc[i][j] + ((bias && n < N) ? bias[n] : 0.f);
             if (act_out == 1) v = silu_f(v);
-            out[(int64_t)m * N + n] = v;
+            v4[j] = v;
+        }
+        if (vec) {
+            *reinterpret_cast<f32x4*>(out + (int64_t)m * N + nq) = v4;
+            if (out2) *reinterpret_cast<f32x4*>(out2 + (int64_t)m * N + nq) = v4;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (nq + j >= N) continue;
+                out[(int64_t)m * N + nq + j] = v4[j];
+                if (out2) out2[(int64_t)m * N + nq + j] = v4[j];
+            }
         }
     }
 }
@@ -406,17 +421,18 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__
     }
 }
 
-extern "C" int primx_linear_f32(const float* in, const float* W, const float* bias, float* out, int M, int N, int K,
+extern "C" int primx_linear_f32(const float* in, const float* W, const float* bias, float* out, float* out2, int M, int N, int K,
                                 int act_out, void* stream) {
     PRIMX_REQUIRE(in && W && out, "primx_linear_f32: null pointer");
     PRIMX_REQUIRE(M > 0 && N > 0 && K > 0 && K % 4 == 0, "primx_linear_f32: need K%%4==0 (K=%d)", K);
+    PRIMX_REQUIRE(!out2 || M > GEMV_MAX_ROWS, "primx_linear_f32: the second destination is for the tiled kernel (M > %d)", GEMV_MAX_ROWS);
     if (M <= GEMV_MAX_ROWS) {   // timestep-embedder MLP (M = B_e): stream the weight matrix once over the whole chip
         hipLaunchKernelGGL(gemv_f32_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, in, W, bias, out, M, N, K, act_out);
         PRIMX_CHECK_LAUNCH("primx_linear_f32");
         return PRIMX_OK;
     }
     dim3 grid((N + 63) / 64, (M + 63) / 64);
-    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, W, bias, out, M, N, K, act_out);
+    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, W, bias, out, out2, M, N, K, act_out);
     PRIMX_CHECK_LAUNCH("primx_linear_f32");
     return PRIMX_OK;
 }

@@ -582,9 +582,8 @@ class DiT(nn.Module):
 
         xf = x.reshape(B * N, Cin).float().contiguous()
         h = torch.empty(T, D, dtype=torch.float32, device=dev)
-        self._embed_tokens(xf, h[:B * N])
-        if null_half:
-            h[B * N:].copy_(h[:B * N])       # cat([x, x]) embeds to the same rows twice (dit_crossattn.py:205,191): one copy
+        # cat([x, x]) embeds to the same rows twice (dit_crossattn.py:205,191): the embedding kernel writes both halves
+        self._embed_tokens(xf, h[:B * N], h[B * N:] if null_half else None)
         plan = self._t_plan
         if plan is not None and plan["row"] is not None:
             # the sampling loop announced its timesteps (plan_timesteps): this call's modulation is a row of the per-loop
@@ -794,9 +793,14 @@ class DiT(nn.Module):
         out = ops.gemm_f32(xn, f(fl.linear.weight), f(fl.linear.bias))
         return out.view(Be, N, self.out_channels)
 
-    def _embed_tokens(self, xf: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-        """[T, C] fp32 -> out [T, D] fp32, outside autocast in the reference (dit_crossattn.py:191-192)."""
-        return ops.linear_f32(xf, self.x_embedder.weight.detach(), self.x_embedder.bias.detach(), out=out)
+    def _embed_tokens(self, xf: torch.Tensor, out: torch.Tensor, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[T, C] fp32 -> out [T, D] fp32 (and the same rows into `out2`), outside autocast in the reference
+        (dit_crossattn.py:191-192)."""
+        if out2 is not None and xf.shape[0] <= 8:      # (the few-row kernel has one destination)
+            ops.linear_f32(xf, self.x_embedder.weight.detach(), self.x_embedder.bias.detach(), out=out)
+            out2.copy_(out)
+            return out
+        return ops.linear_f32(xf, self.x_embedder.weight.detach(), self.x_embedder.bias.detach(), out=out, out2=out2)
 
     @ops.on_input_device
     def forward_with_cfg(self, x, t, y, cfg_scale=0.0, precision_dtype=torch.float32, enable_amp=False):
@@ -839,7 +843,7 @@ class DiTAdditivePosEmb(DiT):
                          gradient_checkpointing=gradient_checkpointing)
         self.point_emb = PointEmbed(hidden_dim=48, dim=hidden_size)
 
-    def _embed_tokens(self, xf: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    def _embed_tokens(self, xf: torch.Tensor, out: torch.Tensor, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
         pe = self.point_emb
         n = pe.embedding_dim // 6
         feat = ops.point_features(xf, pe.basis[0, :n].contiguous())       # the non-zero entries of the block-diagonal basis
@@ -847,6 +851,8 @@ class DiTAdditivePosEmb(DiT):
         w = torch.nn.functional.pad(w, (0, feat.shape[1] - w.shape[1]))   # K padded like the features (zero column)
         out.copy_(ops.linear_f32(xf, self.x_embedder.weight.detach(), self.x_embedder.bias.detach()) +
                   ops.linear_f32(feat, w.contiguous(), pe.mlp.bias.detach()))
+        if out2 is not None:
+            out2.copy_(out)
         return out
 
     def _small_fp32_params(self):

@@ -194,16 +194,18 @@ def cast16(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = No
 
 
 def linear_f32(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], act_out: int = 0,
-               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`out2`: a second [M, N] fp32 destination that receives the same rows (M > 8)."""
     M, K = x.shape
     N = W.shape[0]
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=x.device)
-    elif tuple(out.shape) != (M, N) or out.dtype != torch.float32 or not out.is_contiguous():
-        raise RuntimeError("linear_f32: out must be a contiguous fp32 [M, N] tensor")
+    for o in (out, out2):
+        if o is not None and (tuple(o.shape) != (M, N) or o.dtype != torch.float32 or not o.is_contiguous()):
+            raise RuntimeError("linear_f32: out / out2 must be contiguous fp32 [M, N] tensors")
     check(_lib.load().primx_linear_f32(_dev(x, "x", torch.float32), _dev(W, "W", torch.float32),
                                        _dev(b, "b", torch.float32) if b is not None else None, out.data_ptr(),
-                                       M, N, K, act_out, _stream()), "primx_linear_f32")
+                                       _dev(out2, "out2") if out2 is not None else None, M, N, K, act_out, _stream()), "primx_linear_f32")
     return out
 
 

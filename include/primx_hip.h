@@ -113,8 +113,9 @@ int primx_cast16(const float* in, void* out, int dtype, int64_t n, void* stream)
 /* Small fp32 linear: out[m, n] = act_out( sum_k in[m, k] * W[n, k] + bias[n] ), W in nn.Linear
  * (out, in) layout, everything fp32 (these layers run outside autocast in the reference).
  * act_out: 0 none, 1 SiLU.  Used for x_embedder (models/dit_crossattn.py:141,191) and the
- * TimestepEmbedder MLP (models/utils.py:33-37). */
-int primx_linear_f32(const float* in, const float* W, const float* bias, float* out, int M, int N, int K,
+ * TimestepEmbedder MLP (models/utils.py:33-37).  `out2` (NULL or a second [M, N] buffer, M > 8): receives the same rows -
+ * forward_with_cfg embeds cat([x, x]) (dit_crossattn.py:205), i.e. the same tokens into both halves of the residual stream. */
+int primx_linear_f32(const float* in, const float* W, const float* bias, float* out, float* out2, int M, int N, int K,
                      int act_out, void* stream);
 
 /* ----------------------------------------------------------------------------------------------

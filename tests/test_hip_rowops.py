@@ -55,6 +55,13 @@ def test_linear_f32(ops, M, N, K):
     x, W, b = synth.tensor(3, "x", (M, K)), synth.tensor(3, "W", (N, K), K ** -0.5), synth.tensor(3, "b", (N,))
     got = ops.linear_f32(x.to(DEV), W.to(DEV), b.to(DEV))
     assert rel_l2(got, F.linear(x.double(), W.double(), b.double())) < 1e-6
+    if M > 8:   # the second destination of the tiled kernel (forward_with_cfg embeds the same tokens into both halves of the stream)
+        two = torch.full((2 * M + 1, N), 7.0, device=DEV)
+        ops.linear_f32(x.to(DEV), W.to(DEV), b.to(DEV), out=two[:M], out2=two[M:2 * M])
+        assert torch.equal(two[:M], got) and torch.equal(two[M:2 * M], got) and float(two[2 * M].min()) == 7.0 == float(two[2 * M].max())
+    else:
+        with pytest.raises(Exception):
+            ops.linear_f32(x.to(DEV), W.to(DEV), b.to(DEV), out2=torch.empty(M, N, device=DEV))
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
