@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PRIMX_LIB") or os.path.join(_HERE, "csrc", "libprimx_
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
 HEADS_ROWS, HEADS_VT, HEADS_KROWS = 0, 1, 2
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -40,6 +40,12 @@ SIGNATURES = {
     "primx_linear_gate_residual": [_p, _p, _p, _p, _l, _p, _i, _i, _i, _i, _i, _p, _l, _p],
     "primx_linear_gate_residual_ln": [_p, _p, _p, _p, _l, _p, _i, _i, _i, _i, _p, _p, _l, _p, _f, _p, _l, _i, _p, _l, _p],
     "primx_ln_sync_timeouts": [],
+    "primx_linear_f32out": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "primx_row_mean": [_p, _i, _i, _p, _p],
+    "primx_linear_gate_residual_fold": [_p, _p, _p, _p, _l, _p, _i, _i, _i, _i, _p, _l, _p, _p, _p, _i, _p, _l, _p],
+    "primx_linear_heads_fold": [_p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _f, _p, _p, _p, _p, _f, _i,
+                                _p, _l, _p],
+    "primx_linear_fold": [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p, _l, _p],
     "primx_linear_heads": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _i, _i, _f, _i, _p, _l, _p],
     "primx_attention": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "primx_attention_bcast": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _i, _i, _i, _p],
@@ -69,9 +75,11 @@ SIGNATURES = {
 }
 _RESTYPES = {"primx_last_error": C.c_char_p, "primx_last_gemm_kernel": C.c_char_p}
 # an alternate build named by PRIMX_LIB (same-box A/B against another build) must speak the same ABI: version 21 changed the
-# argument lists of the GEMM / LayerNorm entry points (explicit prefetch ranges), so older libraries cannot be bound any more
-_OPTIONAL_IN_AB_BUILDS: set = set()
-_AB_ABI_VERSIONS: tuple = ()
+# argument lists of the GEMM / LayerNorm entry points (explicit prefetch ranges), so older libraries cannot be bound any more;
+# version 22 only ADDED the LayerNorm-fold entry points, so a version-21 build can stand in as long as nothing folds
+_OPTIONAL_IN_AB_BUILDS: set = {"primx_linear_f32out", "primx_row_mean", "primx_linear_gate_residual_fold", "primx_linear_heads_fold",
+                               "primx_linear_fold"}
+_AB_ABI_VERSIONS: tuple = (21,)
 
 _lib: Optional[C.CDLL] = None
 

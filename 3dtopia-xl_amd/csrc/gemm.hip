@@ -52,7 +52,11 @@ __device__ __forceinline__ V8 ldg16(const S* ptr, bool keep) {
 constexpr int BK = 64;
 
 // (EPI_GATE_RESIDUAL_LN: gemm144l_dma_kernel only - the gate-residual epilogue followed by the LayerNorm + modulate of the row block)
-enum { EPI_LINEAR = 0, EPI_GATE_RESIDUAL = 1, EPI_HEADS = 2, EPI_RES = 3, EPI_CONVT = 4, EPI_GATE_RESIDUAL_LN = 5 };
+// The *_FOLD epilogues are the LayerNorm fold (see "LayerNorm fold" below): EPI_GATE_RESIDUAL_FOLD = the PRODUCER of a folded
+// LayerNorm site (gemm144l only), EPI_HEADS_FOLD / EPI_LINEAR_FOLD = its CONSUMERS (gemm144l, gemm288q heads, gemm288p),
+// EPI_F32OUT = fp32 rows out of 16-bit operands (the per-timestep u / v vectors of the fold; generic kernel only).
+enum { EPI_LINEAR = 0, EPI_GATE_RESIDUAL = 1, EPI_HEADS = 2, EPI_RES = 3, EPI_CONVT = 4, EPI_GATE_RESIDUAL_LN = 5,
+       EPI_GATE_RESIDUAL_FOLD = 6, EPI_HEADS_FOLD = 7, EPI_LINEAR_FOLD = 8, EPI_F32OUT = 9 };
 
 template <int DT>
 struct GemmArgs {
@@ -96,6 +100,16 @@ struct GemmArgs {
     float ln_eps;
     unsigned* sync;
     int ln_light;
+    // LayerNorm fold.  Producer (EPI_GATE_RESIDUAL_FOLD): ln_scale / ln_mod_stride = the NEXT LayerNorm's scale vectors, ln_out = the
+    // 16-bit operand cast16((x - c) (1 + scale)), fold_c = per-row centre c (read), fold_part = [M][N / 144][2] partial sums of
+    // (x - c), (x - c)^2 per column tile (written).  Consumers: fold_part / fold_parts (read), fold_u / fold_v = fp32 per-column
+    // vectors, fold_c (the column tile 0 workgroups add the row's mean of (x - c) to it), fold_eps.
+    float* fold_part;
+    int fold_parts;
+    const float* fold_u;
+    const float* fold_v;
+    float* fold_c;
+    float fold_eps;
 };
 
 // Weight prefetch carried by a GEMM launch (the `prefetch` / `prefetch_bytes` arguments of primx_linear, primx_linear_heads,
@@ -307,6 +321,14 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs<DT>& p, const ColIn
             float* xp = p.x + (int64_t)m * p.N + n;
             *xp = *xp + rnd16<DT>(gt * v);
         }
+    } else if (EPI == EPI_F32OUT) {
+        // fp32 rows (p.x) of 16-bit operands; the bias joins the rows from p.rows_per_batch on (the fold's v rows, not its u rows)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mq + j;
+            if (m >= p.M) continue;
+            p.x[(int64_t)m * p.N + n] = a[j] + (m >= p.rows_per_batch ? c.bias : 0.f);
+        }
     } else {  // EPI_HEADS
         float v[4];
 #pragma unroll
@@ -389,6 +411,93 @@ __device__ __forceinline__ typename T16<DT>::V4 linear_out4(const GemmArgs<DT>& 
         for (int j = 0; j < 4; ++j) o[j] = (S)y[j];
     }
     return o;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm fold (primx_linear_gate_residual_fold -> primx_linear_heads_fold / primx_linear_fold).  Every LayerNorm + modulate of a
+// DiT block sits between a gated residual add and a Linear (dit_crossattn.py:55-57).  With the row statistics mu, rho of the fp32
+// residual stream x, m = cast16(1 + scale) and ANY per-row centre c:
+//     reference:  y = cast16( cast16( (x - mu) rho m + shift ) W^T + b )
+//     folded:     y = cast16( rho ( cast16((x - c) m) W^T  -  (mu - c) u ) + v ),     u = m W^T,  v = shift W^T + b  (fp32, per column)
+// The PRODUCER (the gate-residual GEMM, EPI_GATE_RESIDUAL_FOLD) stores a16 = cast16((x - c) m) next to x and the partial sums
+// of (x - c), (x - c)^2 of its 144 columns; the CONSUMER (to_q / qkv / fc1, EPI_HEADS_FOLD / EPI_LINEAR_FOLD) multiplies a16,
+// finishes mu' = mean(x - c) and rho from the partials and applies them with u, v in its epilogue: no LayerNorm kernel and no
+// second pass over the fp32 rows.  u, v depend on the timestep only (two GEMM rows per timestep and site, EPI_F32OUT, once per
+// planned sampling loop).  The fold rounds (x - c) m where the reference rounds the normalised value: the same relative
+// rounding per element, but - mu' u cancels, so it costs accuracy in proportion to |mu'| / sigma (tools/ln_fold_study.py: equal
+// to the reference's rounding up to a ratio of 0.5, x 1.4 at 2, x 5 at 10).  Hence the centre: c = the row mean at the PREVIOUS
+// LayerNorm site (the consumer's column tile 0 moves it: c += mu'), so |mu'| is what ONE gated branch adds to the mean.
+// Statistics: var = E[(x - c)^2] - mu'^2 in fp32 - harmless for the same reason.
+// Row statistics of a consumer tile, in two steps so that the kernel can put its own memory requests between the loads and their
+// use: thread t < rows owns row m0 + t.  Up to eight partials per row (fold_parts <= 8, host-checked), all loads independent.
+struct FoldPartials {
+    f32x2 v[8];
+};
+template <int DT>
+__device__ __forceinline__ FoldPartials fold_stats_load(const GemmArgs<DT>& p, int M, int m0, int t) {
+    const int m = min(m0 + t, M - 1);
+    const f32x2* pp = reinterpret_cast<const f32x2*>(p.fold_part) + (int64_t)m * p.fold_parts;
+    FoldPartials r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = pp[min(i, p.fold_parts - 1)];
+    return r;
+}
+template <int DT>
+__device__ __forceinline__ void fold_stats_finish(const GemmArgs<DT>& p, const FoldPartials& r, int M, int K, int m0, int t,
+                                                  bool tile0, f32x2* stats) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                        // fixed order
+        s1 += (i < p.fold_parts) ? r.v[i][0] : 0.f;
+        s2 += (i < p.fold_parts) ? r.v[i][1] : 0.f;
+    }
+    const float inv = 1.0f / (float)K;
+    const float mu = s1 * inv;
+    const float rho = 1.0f / sqrtf(fmaxf(s2 * inv - mu * mu, 0.f) + p.fold_eps);
+    stats[t] = f32x2{mu, rho};                           // (LDS)
+    if (tile0 && m0 + t < M) p.fold_c[m0 + t] += mu;     // the next producer centres with this site's mean
+}
+
+// the consumer's value of four columns: rho (acc - mu' u) + v
+__device__ __forceinline__ f32x4 fold_apply(const f32x4 a, const f32x2 st, const f32x4 u, const f32x4 v) {
+    f32x4 y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = st[1] * (a[j] - st[0] * u[j]) + v[j];
+    return y;
+}
+
+// linear_out4 behind the fold: `y` already holds what bias + accumulator are there
+template <int DT>
+__device__ __forceinline__ typename T16<DT>::V4 fold_out4(const GemmArgs<DT>& p, const f32x4 yin) {
+    using S = typename T16<DT>::S;
+    typename T16<DT>::V4 o;
+    float y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = rnd16<DT>(yin[j]);
+    if (p.act == PRIMX_ACT_GELU_TANH) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(y[j]);
+    } else if (p.act == PRIMX_ACT_GELU_ERF) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = gelu_erf_f(y[j]);
+    }
+    if (p.out_scale != 1.0f) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (S)(p.out_scale * rnd16<DT>(y[j]));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (S)y[j];
+    }
+    return o;
+}
+
+__device__ __forceinline__ float quad_sum(float v) {   // lanes 4 q .. 4 q + 3: (v0 + v1) + (v2 + v3) in every lane
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+    return v;
 }
 
 template <int DT, int EPI>
@@ -999,8 +1108,12 @@ __device__ unsigned g_ln_sync_timeouts = 0;
 template <int DT, int EPI>
 __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)) {
     PRIMX_GEMM_ARGS(DT);
-    static_assert(EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_HEADS || EPI == EPI_GATE_RESIDUAL_LN, "row-major epilogues only");
-    constexpr bool GATE_RES = EPI == EPI_GATE_RESIDUAL || EPI == EPI_GATE_RESIDUAL_LN;
+    static_assert(EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_HEADS || EPI == EPI_GATE_RESIDUAL_LN ||
+                  EPI == EPI_GATE_RESIDUAL_FOLD || EPI == EPI_HEADS_FOLD || EPI == EPI_LINEAR_FOLD, "row-major epilogues only");
+    constexpr bool GATE_RES = EPI == EPI_GATE_RESIDUAL || EPI == EPI_GATE_RESIDUAL_LN || EPI == EPI_GATE_RESIDUAL_FOLD;
+    constexpr bool HEADS = EPI == EPI_HEADS || EPI == EPI_HEADS_FOLD;
+    constexpr bool FOLD_P = EPI == EPI_GATE_RESIDUAL_FOLD;                          // producer of a folded LayerNorm site
+    constexpr bool FOLD_C = EPI == EPI_HEADS_FOLD || EPI == EPI_LINEAR_FOLD;        // consumer
     using S = typename T16<DT>::S;
     using V8 = typename T16<DT>::V8;
     using V4e = typename T16<DT>::V4;
@@ -1012,8 +1125,12 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     constexpr int RS = BN + 4;
     constexpr int ROWMAJOR_HALVES = 2 * BM * RS * 2;
     constexpr int LDS_HALVES = (NST * STAGE > ROWMAJOR_HALVES) ? NST * STAGE : ROWMAJOR_HALVES;
-    static_assert(LDS_HALVES * 2 <= 160 * 1024 && NINST % 2 == 0, "LDS budget / loader split");
-    __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES];
+    // fold consumer, behind the ring: (mu', rho) of the tile's 128 rows, then u and v of its 144 columns - fetched ONCE per workgroup
+    // at kernel start (every thread loading the vectors of its nine units from L2 was 147 KB through the L1 per workgroup: to_q
+    // 19.2 vs 17.7 us)
+    constexpr int STAT_HALVES = FOLD_C ? BM * 4 + 2 * BN * 2 : 0;
+    static_assert((LDS_HALVES + STAT_HALVES) * 2 <= 160 * 1024 && NINST % 2 == 0, "LDS budget / loader split");
+    __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES + STAT_HALVES];
     // (Round 2 left an untested option here - the LOADER waves fetching 5 of the 9 fp32 residual row-chunks of every thread by
     // LDS-DMA into the 47 KB behind the ring.  Measured in round 3, same box: gate-residual 19.3 / 19.5 vs 19.2 / 18.4 us at
     // K = 1152, 49.6 / 47.8 vs 46.6 / 49.3 us at K = 4608, the configs[1] step 9.23 - 9.27 vs 9.12 - 9.17 ms: slower.  vmcnt is ONE
@@ -1059,6 +1176,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                   // D
         asm volatile("s_barrier" ::: "memory");                                          // E
+        if constexpr (FOLD_P) asm volatile("s_barrier" ::: "memory");                    // H (every wave executes every barrier)
         if constexpr (EPI == EPI_GATE_RESIDUAL_LN) {
             if (pl_rest.ln_light & 8) asm volatile("s_barrier\n\ts_barrier" ::: "memory");   // F, G of the LayerNorm tail (every wave executes every barrier)
         }
@@ -1091,7 +1209,28 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     };
     constexpr int NROWCH = (BM * (BN / 4)) / 512;
     f32x4 xpre[NROWCH];
+    // fold consumer: the tile's row statistics from the producer's partial sums, while the loaders fetch the first tiles (requested
+    // BEFORE the prefetch lines: vmcnt is in-order, the wait for these must not include those)
+    f32x2* const fstat = reinterpret_cast<f32x2*>(smem + LDS_HALVES);
+    float* const fu = reinterpret_cast<float*>(smem + LDS_HALVES + BM * 4);              // u[144], then v[144]
+    FoldPartials fpart;
+    f32x2 fu2 = {0.f, 0.f}, fv2 = {0.f, 0.f};
+    const int tuv = tid - BM;                                                            // threads 128 .. 199: two columns each
+    if constexpr (FOLD_C) {
+        if (wave < BM / 64) fpart = fold_stats_load<DT>(p, pl_M, m0, tid);
+        else if (tuv < BN / 2) {
+            fu2 = *reinterpret_cast<const f32x2*>(p.fold_u + n0 + 2 * tuv);
+            fv2 = *reinterpret_cast<const f32x2*>(p.fold_v + n0 + 2 * tuv);
+        }
+    }
     const pf_u32x2 pf_v = gemm_prefetch_lines<DT>(p, wave, lane);                        // (the launch's prefetch range)
+    if constexpr (FOLD_C) {
+        if (wave < BM / 64) fold_stats_finish<DT>(p, fpart, pl_M, pl_K, m0, tid, n0 == 0, fstat);
+        else if (tuv < BN / 2) {
+            *reinterpret_cast<f32x2*>(fu + 2 * tuv) = fu2;
+            *reinterpret_cast<f32x2*>(fu + BN + 2 * tuv) = fv2;
+        }
+    }
     asm volatile("s_barrier" ::: "memory");                                              // P
     V8 a0[MI], b0[NI], a1[MI], b1[NI];
     read_frags(0, a0, b0);
@@ -1130,7 +1269,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     // EPI_HEADS: the tile lies inside ONE (repetition, segment): everything that needs a division is tile-uniform
     int h_hh0 = 0, h_dd0 = 0, h_bb0 = 0, h_tok0 = 0, h_rs = 0, h_seg = 0;
     S* h_dst = nullptr;
-    if (EPI == EPI_HEADS) {
+    if (HEADS) {
         const int per = p.heads * p.dh;
         const int seg_all = n0 / per, rep_i = seg_all / p.n_seg;
         h_seg = seg_all - rep_i * p.n_seg;
@@ -1144,16 +1283,22 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
                 rep_i * (h_seg == 0 ? p.rep_stride[0] : h_seg == 1 ? p.rep_stride[1] : p.rep_stride[2]);
     }
     V4e bpre[NROWCH], gpre[NROWCH];
+    V4e spre[FOLD_P ? NROWCH : 1];             // fold producer: the next LayerNorm's scale vector, the row's centre
+    float cpre[FOLD_P ? NROWCH : 1];
 #pragma unroll
     for (int i = 0; i < NROWCH; ++i) {
         const int cid = tid + 512 * i;
         const int row = cid / (BN / 4), c4 = cid - row * (BN / 4);
         const int m = min(m0 + row, pl_M - 1);
         bpre[i] = V4e{};
-        if (p.bias) bpre[i] = *reinterpret_cast<const V4e*>(p.bias + n0 + 4 * c4);
+        if (!FOLD_C && p.bias) bpre[i] = *reinterpret_cast<const V4e*>(p.bias + n0 + 4 * c4);
         if (GATE_RES) {
             gpre[i] = *reinterpret_cast<const V4e*>(p.gate + (int64_t)(m / p.rows_per_batch) * p.gate_stride + n0 + 4 * c4);
             xpre[i] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * pl_N + n0 + 4 * c4);
+            if constexpr (FOLD_P) {
+                spre[i] = *reinterpret_cast<const V4e*>(p.ln_scale + (int64_t)(m / p.rows_per_batch) * p.ln_mod_stride + n0 + 4 * c4);
+                cpre[i] = p.fold_c[m];
+            }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                     // E
@@ -1164,7 +1309,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(red + row * RS + 4 * c4);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(red + BM * RS + row * RS + 4 * c4);
         if (m0 + row >= pl_M) continue;
-        if (EPI == EPI_HEADS) {
+        if (HEADS) {
             int d = h_dd0 + 4 * c4, hh = h_hh0;          // d < dh + 144 <= 4 dh
             if (d >= p.dh) { d -= p.dh; ++hh; }
             if (d >= p.dh) { d -= p.dh; ++hh; }
@@ -1173,11 +1318,22 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
             if (tok >= p.rows_per_batch) { tok -= p.rows_per_batch; ++bb; }
             const V4e bv = bpre[i];
             V4e o;
+            if constexpr (FOLD_C) {
+                const f32x4 pre = fold_apply(v0 + v1, fstat[row], *reinterpret_cast<const f32x4*>(fu + 4 * c4),
+                                             *reinterpret_cast<const f32x4*>(fu + BN + 4 * c4));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float y = rnd16<DT>(v0[j] + v1[j] + (p.bias ? (float)bv[j] : 0.f));
-                if (h_seg == 0 && p.scale0 != 1.0f) y = rnd16<DT>(p.scale0 * y);
-                o[j] = (S)y;
+                for (int j = 0; j < 4; ++j) {
+                    float y = rnd16<DT>(pre[j]);
+                    if (h_seg == 0 && p.scale0 != 1.0f) y = rnd16<DT>(p.scale0 * y);
+                    o[j] = (S)y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float y = rnd16<DT>(v0[j] + v1[j] + (p.bias ? (float)bv[j] : 0.f));
+                    if (h_seg == 0 && p.scale0 != 1.0f) y = rnd16<DT>(p.scale0 * y);
+                    o[j] = (S)y;
+                }
             }
             out_store(reinterpret_cast<V4e*>(h_dst + (((int64_t)bb * p.heads + hh) * p.n_pad + tok) * h_rs + d), o);
         } else if (GATE_RES) {
@@ -1187,9 +1343,46 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
             for (int j = 0; j < 4; ++j)
                 xv[j] = xv[j] + rnd16<DT>((float)gv[j] * rnd16<DT>(v0[j] + v1[j] + (p.bias ? (float)bv[j] : 0.f)));
             out_store(reinterpret_cast<f32x4*>(p.x + (int64_t)(m0 + row) * pl_N + n0 + 4 * c4), xv);
+            if constexpr (FOLD_P) {
+                // the next site's operand and this unit's share of the row statistics; the partial sums go back into the unit's
+                // own (dead) slot of the parking area
+                const V4e sv = spre[i];
+                const float cr = cpre[i];
+                float s1 = 0.f, s2 = 0.f;
+                V4e o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = xv[j] - cr;
+                    s1 += d;
+                    s2 = __builtin_fmaf(d, d, s2);
+                    o[j] = (S)(d * rnd16<DT>(1.0f + (float)sv[j]));
+                }
+                out_store(reinterpret_cast<V4e*>(p.ln_out + (int64_t)(m0 + row) * pl_N + n0 + 4 * c4), o);
+                *reinterpret_cast<f32x2*>(red + row * RS + 4 * c4) = f32x2{s1, s2};
+            }
         } else if constexpr (EPI == EPI_LINEAR) {
             epilogue_row4<DT, EPI>(p, m0 + row, n0 + 4 * c4, v0 + v1, bpre[i]);
+        } else if constexpr (EPI == EPI_LINEAR_FOLD) {
+            out_store(reinterpret_cast<V4e*>(p.out + (int64_t)(m0 + row) * pl_N + n0 + 4 * c4),
+                      fold_out4<DT>(p, fold_apply(v0 + v1, fstat[row], *reinterpret_cast<const f32x4*>(fu + 4 * c4),
+                                                  *reinterpret_cast<const f32x4*>(fu + BN + 4 * c4))));
         }
+    }
+    if constexpr (FOLD_P) {
+        // row sums of the tile: 36 units per row -> thread (row, quarter) adds nine, the four quarters meet by DPP - a fixed order
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                 // H
+        const int row = tid >> 2, qu = tid & 3;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(red + row * RS + 4 * (qu * 9 + k));
+            s1 += v[0];
+            s2 += v[1];
+        }
+        s1 = quad_sum(s1);
+        s2 = quad_sum(s2);
+        if (qu == 0 && m0 + row < pl_M)
+            *reinterpret_cast<f32x2*>(p.fold_part + ((int64_t)(m0 + row) * nt + n0 / BN) * 2) = f32x2{s1, s2};
     }
     if constexpr (EPI == EPI_GATE_RESIDUAL_LN) {
         // ---------------- LayerNorm + modulate of the 128-row block, in the tail of the GEMM that completes its rows
@@ -1293,10 +1486,13 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
     // EPI_HEADS stages the rounded 16-bit tile in LDS after the main loop (row-major [256][304] for the token-major
     // layouts, transposed [288][272] for PRIMX_HEADS_VT); the strides put the 16 fragment rows of a wave 8 banks apart
     constexpr int RS_ROWS = BN + 16, RS_VT = BM + 16;
-    constexpr int STG = (EPI == EPI_HEADS) ? ((BM * RS_ROWS > BN * RS_VT) ? BM * RS_ROWS : BN * RS_VT) : 0;
+    constexpr bool HEADS = EPI == EPI_HEADS || EPI == EPI_HEADS_FOLD;
+    constexpr bool FOLD_C = EPI == EPI_HEADS_FOLD;                 // consumer of a folded LayerNorm site (see fold_stats_load)
+    constexpr int STG = HEADS ? ((BM * RS_ROWS > BN * RS_VT) ? BM * RS_ROWS : BN * RS_VT) : 0;
     constexpr int LDS_HALVES = (NST * STAGE > STG) ? NST * STAGE : STG;
-    static_assert(LDS_HALVES * 2 <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES];
+    constexpr int STAT_HALVES = FOLD_C ? BM * 4 + 2 * BN * 2 : 0;  // behind the staging area: (mu', rho) of the tile's rows, u and v of its columns
+    static_assert((LDS_HALVES + STAT_HALVES) * 2 <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES + STAT_HALVES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1343,10 +1539,30 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
     const int w_off = (BM + wn * 144 + lr) * KS + ((lg ^ sw2) << 3);      // + j * 16 rows
 
     const int nks = pl_K / KS;
+    // fold consumer: the partial sums are requested in front of the first DMAs (vmcnt is in-order) and used behind their issue
+    f32x2* const fstat = reinterpret_cast<f32x2*>(smem + LDS_HALVES);
+    float* const fu = reinterpret_cast<float*>(smem + LDS_HALVES + BM * 4);              // u[288], then v[288]
+    FoldPartials fpart;
+    f32x2 fu2 = {0.f, 0.f}, fv2 = {0.f, 0.f};
+    const int tuv = tid - BM;                                                            // threads 256 .. 399: two columns each
+    if constexpr (FOLD_C) {
+        if (wave < BM / 64) fpart = fold_stats_load<DT>(p, pl_M, m0, tid);
+        else if (tuv < BN / 2) {
+            fu2 = *reinterpret_cast<const f32x2*>(p.fold_u + n0 + 2 * tuv);
+            fv2 = *reinterpret_cast<const f32x2*>(p.fold_v + n0 + 2 * tuv);
+        }
+    }
 #pragma unroll
     for (int pre = 0; pre < NST - 1; ++pre)
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) issue_one(min(pre, nks - 1), pre, i);
+    if constexpr (FOLD_C) {
+        if (wave < BM / 64) fold_stats_finish<DT>(p, fpart, pl_M, pl_K, m0, tid, ni_t == 0, fstat);
+        else if (tuv < BN / 2) {
+            *reinterpret_cast<f32x2*>(fu + 2 * tuv) = fu2;
+            *reinterpret_cast<f32x2*>(fu + BN + 2 * tuv) = fv2;
+        }
+    }
     // Fragment prefetch: the A fragments and the first NPF W fragments of slice ks+1 are read while the MFMAs of slice ks
     // run (they need slice ks+1 to have landed one barrier earlier: "vmcnt(4)" = only slice ks+2 still in flight).
     constexpr int NPF = 3;
@@ -1364,7 +1580,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
     // lane, i.e. the plain operand order (accumulator = C); everything else swaps the operands (accumulator = C^T, 4
     // consecutive columns per lane).  The main loop exists once per order; the choice is made once per workgroup.
     bool vt_tile = false;
-    if (EPI == EPI_HEADS) {
+    if (HEADS) {
         const int seg = (n0 / (p.heads * p.dh)) % p.n_seg;
         vt_tile = (seg == 0 ? p.kind[0] : seg == 1 ? p.kind[1] : p.kind[2]) == PRIMX_HEADS_VT;
     }
@@ -1404,7 +1620,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
         st = st_next;
     }
     };
-    if (EPI == EPI_HEADS && vt_tile) main_loop(std::false_type{});
+    if (HEADS && vt_tile) main_loop(std::false_type{});
     else main_loop(std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (clamped tail DMAs)
     if (pl_prof) pc2 = __builtin_readcyclecounter();
@@ -1428,7 +1644,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
     };
 
     using V4e = typename T16<DT>::V4;
-    if (EPI == EPI_HEADS) {
+    if (HEADS) {
         // ---- heads epilogue through LDS (host guarantees: per % 288 == 0, 288 % dh == 0, dh % 8 == 0,
         // rows_per_batch % 256 == 0 - hence M % 256 == 0, no ragged tile - so the tile lies in ONE (repetition, segment,
         // batch entry) and covers whole heads).
@@ -1449,18 +1665,33 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
             // every segment a multiply, two conversions and a select)
             auto park = [&](auto scaled_t) {
             constexpr bool scaled = decltype(scaled_t)::value;
+            f32x2 st[FOLD_C ? MI : 1];                   // fold: (mu', rho) of this lane's four rows
+            if constexpr (FOLD_C) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) st[i] = fstat[wm * 64 + i * 16 + lr];
+            }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 V4e bv = V4e{};
-                if (p.bias) bv = *reinterpret_cast<const V4e*>(p.bias + n0 + wn * 144 + j * 16 + 4 * lg);
+                f32x4 u4 = {0.f, 0.f, 0.f, 0.f}, v4 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (FOLD_C) {
+                    u4 = *reinterpret_cast<const f32x4*>(fu + wn * 144 + j * 16 + 4 * lg);          // (LDS)
+                    v4 = *reinterpret_cast<const f32x4*>(fu + BN + wn * 144 + j * 16 + 4 * lg);
+                } else if (p.bias) {
+                    bv = *reinterpret_cast<const V4e*>(p.bias + n0 + wn * 144 + j * 16 + 4 * lg);
+                }
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     V4e o;
+                    f32x4 yv;
+                    if constexpr (FOLD_C) {
+                        yv = fold_apply(acc[i][j], st[i], u4, v4);
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float y = acc[i][j][r] + (float)bv[r];
-                        o[r] = scaled ? (S)(sc * rnd16<DT>(y)) : (S)y;
+                        for (int r = 0; r < 4; ++r) yv[r] = acc[i][j][r] + (float)bv[r];
                     }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = scaled ? (S)(sc * rnd16<DT>(yv[r])) : (S)yv[r];
                     *reinterpret_cast<V4e*>(smem + (wm * 64 + i * 16 + lr) * RS_ROWS + wn * 144 + j * 16 + 4 * lg) = o;
                 }
             }
@@ -1484,15 +1715,30 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
             // acc[i][j][r] = C[wm*64 + i*16 + 4*lg + r][wn*144 + j*16 + lr]  ->  staged transposed [column][token]
             auto park = [&](auto scaled_t) {
             constexpr bool scaled = decltype(scaled_t)::value;
+            f32x2 st[FOLD_C ? MI : 1][4];                // fold: (mu', rho) of this lane's sixteen rows
+            if constexpr (FOLD_C) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[i][r] = fstat[wm * 64 + i * 16 + 4 * lg + r];
+            }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                const float bj = p.bias ? (float)p.bias[n0 + wn * 144 + j * 16 + lr] : 0.f;
+                float bj = 0.f, uj = 0.f;
+                if constexpr (FOLD_C) {
+                    uj = fu[wn * 144 + j * 16 + lr];                                                 // (LDS)
+                    bj = fu[BN + wn * 144 + j * 16 + lr];
+                } else if (p.bias) {
+                    bj = (float)p.bias[n0 + wn * 144 + j * 16 + lr];
+                }
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     V4e o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float y = acc[i][j][r] + bj;
+                        float y;
+                        if constexpr (FOLD_C) y = st[i][r][1] * (acc[i][j][r] - st[i][r][0] * uj) + bj;
+                        else y = acc[i][j][r] + bj;
                         o[r] = scaled ? (S)(sc * rnd16<DT>(y)) : (S)y;
                     }
                     *reinterpret_cast<V4e*>(smem + (wn * 144 + j * 16 + lr) * RS_VT + wm * 64 + i * 16 + 4 * lg) = o;
@@ -1607,7 +1853,9 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
 // Pipeline: the unit is a 32-wide k-step (18 MFMAs per wave).  Fragments of step u + 1 are read while step u multiplies; the
 // ONE barrier per k-tile sits between its two steps: B_g = "reads of tile g are home (its stage may be refilled), tile g + 1 has
 // landed" - the same two-tiles-of-flight ring protocol as gemm144l_dma_kernel, all ten waves execute every barrier.
-template <int DT>
+// FOLD: the Linear is the consumer of a folded LayerNorm site (fc1; see fold_stats_load): row statistics from the producer's partial
+// sums at kernel start, y = rho (acc - mu' u) + v in place of acc + bias.
+template <int DT, bool FOLD = false>
 __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)) {
     PRIMX_GEMM_ARGS(DT);
     unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pc2 = 0;   // PRIMX_GEMM_PROF=1 timeline (see g_gemm_prof)
@@ -1619,8 +1867,11 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     typedef __attribute__((address_space(3))) void LV;
     constexpr int BM = 256, BN = 144, MI = 2, NI = 9, NST = 3, NPASS = 2;
     constexpr int ROWS = BM + BN, STAGE = ROWS * 64, NINST = ROWS / 8, NL = NINST / 2;   // 50 wave-instructions per tile, 25 per loader
-    static_assert(NST * STAGE * 2 <= 160 * 1024 && NINST % 2 == 0 && BM % 8 == 0, "LDS budget / loader split");
-    __shared__ __attribute__((aligned(16))) S smem[NST * STAGE];
+    // FOLD, behind the ring: (mu', rho) of the tile's 256 rows, then u and v of its 288 columns (fetched at kernel start: requested
+    // at the head of each pass's epilogue they cost every pass an L2 round trip with nothing to overlap it - fc1 57.5 vs 53.0 us)
+    constexpr int STAT_HALVES = FOLD ? BM * 4 + 2 * NPASS * BN * 2 : 0;
+    static_assert((NST * STAGE + STAT_HALVES) * 2 <= 160 * 1024 && NINST % 2 == 0 && BM % 8 == 0, "LDS budget / loader split");
+    __shared__ __attribute__((aligned(16))) S smem[NST * STAGE + STAT_HALVES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1691,7 +1942,26 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(b[j], a[i], acc[i][j]);
     };
+    f32x2* const fstat = reinterpret_cast<f32x2*>(smem + NST * STAGE);
+    float* const fu = reinterpret_cast<float*>(smem + NST * STAGE + BM * 4);             // u[288], then v[288]
+    FoldPartials fpart;
+    f32x2 fu2 = {0.f, 0.f}, fv2 = {0.f, 0.f};
+    const int tuv = tid - BM;                                                            // waves 4 - 7: two columns each
+    if constexpr (FOLD) {
+        if (wave < BM / 64) fpart = fold_stats_load<DT>(p, pl_M, m0, tid);
+        else if (tuv < NPASS * BN / 2) {
+            fu2 = *reinterpret_cast<const f32x2*>(p.fold_u + n00 + 2 * tuv);
+            fv2 = *reinterpret_cast<const f32x2*>(p.fold_v + n00 + 2 * tuv);
+        }
+    }
     const pf_u32x2 pf_v = gemm_prefetch_lines<DT>(p, wave, lane);                        // (the launch's prefetch range)
+    if constexpr (FOLD) {
+        if (wave < BM / 64) fold_stats_finish<DT>(p, fpart, pl_M, pl_K, m0, tid, ni_t == 0, fstat);
+        else if (tuv < NPASS * BN / 2) {
+            *reinterpret_cast<f32x2*>(fu + 2 * tuv) = fu2;
+            *reinterpret_cast<f32x2*>(fu + NPASS * BN + 2 * tuv) = fv2;
+        }
+    }
     asm volatile("s_barrier" ::: "memory");                                              // P
     if (pl_prof) pc1 = __builtin_readcyclecounter();
     int st = 0;
@@ -1720,13 +1990,49 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
         // halves of neighbouring 16-column tiles with v_permlane16_swap, see gemm288q_dma_kernel).  Nothing below waits for the
         // stores: the next pass's fragments and MFMAs follow immediately.
         const int n0 = n00 + pass * BN;
+        typedef unsigned int u32;
+        if constexpr (FOLD) {
+            // column pairs outermost: the u / v vectors of a pair (16 registers) serve both row groups - all nine tiles' vectors next to
+            // the 72 accumulators did not fit the 168 registers of a 10-wave workgroup
+            f32x2 fst[MI];
+            bool ok[MI];
+            S* orow[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wave * 32 + i * 16 + lr;
+                ok[i] = m < pl_M;
+                orow[i] = p.out + (int64_t)(ok[i] ? m : pl_M - 1) * pl_N + n0;
+                fst[i] = fstat[wave * 32 + i * 16 + lr];
+            }
+            const float* up = fu + pass * BN + 4 * lg;                                   // (LDS)
+            const float* vp = fu + NPASS * BN + pass * BN + 4 * lg;
+#pragma unroll
+            for (int j = 0; j + 1 < NI; j += 2) {
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(up + j * 16), v0 = *reinterpret_cast<const f32x4*>(vp + j * 16);
+                const f32x4 u1 = *reinterpret_cast<const f32x4*>(up + j * 16 + 16), v1 = *reinterpret_cast<const f32x4*>(vp + j * 16 + 16);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const u32x2 a = __builtin_bit_cast(u32x2, fold_out4<DT>(p, fold_apply(acc[i][j], fst[i], u0, v0)));
+                    const u32x2 b = __builtin_bit_cast(u32x2, fold_out4<DT>(p, fold_apply(acc[i][j + 1], fst[i], u1, v1)));
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                    const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
+                    if (ok[i]) out_store(reinterpret_cast<u32x4*>(orow[i] + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
+                }
+            }
+            const f32x4 u8 = *reinterpret_cast<const f32x4*>(up + (NI - 1) * 16), v8 = *reinterpret_cast<const f32x4*>(vp + (NI - 1) * 16);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                if (ok[i])
+                    out_store(reinterpret_cast<V4e*>(orow[i] + (NI - 1) * 16 + 4 * lg),
+                              fold_out4<DT>(p, fold_apply(acc[i][NI - 1], fst[i], u8, v8)));
+        } else {
         V4e bpre[NI];
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             bpre[j] = V4e{};
             if (p.bias) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + n0 + j * 16 + 4 * lg);
         }
-        typedef unsigned int u32;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = m0 + wave * 32 + i * 16 + lr;
@@ -1742,6 +2048,7 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
                 if (ok) out_store(reinterpret_cast<u32x4*>(orow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
             }
             if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), linear_out4<DT>(p, acc[i][NI - 1], bpre[NI - 1]));
+        }
         }
     }
     asm volatile("" ::"v"(pf_v[0]), "v"(pf_v[1]));
@@ -1883,16 +2190,31 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
         // (the heads epilogue keeps the row-major walk: the batched K / V projection measured 210 vs 217 us with sub-blocks - its rounds
         // are bound by the two-layout scatter of the tile, not by operand traffic - while the dense-output GEMMs of a large batch
         // gain: fc1 at T = 32768 440 -> 410 us, the batch-8 step 61.25 -> 60.86 ms)
-        if (a2.xcd_gm > 0) a2.xcd_gm = xcd_pack(a2.xcd_gm, mtb, ntb, EPI == EPI_HEADS);
+        if (a2.xcd_gm > 0) a2.xcd_gm = xcd_pack(a2.xcd_gm, mtb, ntb, EPI == EPI_HEADS || EPI == EPI_HEADS_FOLD);
     }
+    constexpr bool FOLD_EPI = EPI == EPI_GATE_RESIDUAL_FOLD || EPI == EPI_HEADS_FOLD || EPI == EPI_LINEAR_FOLD;
     // loader-wave kernel: the row-major epilogues (heads: token-major segments whose tiles stay inside one segment)
-    bool loader_ok = !BIG && (EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL);
-    if (!BIG && EPI == EPI_HEADS && a.heads > 0) {
+    bool loader_ok = !BIG && (EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_GATE_RESIDUAL_FOLD || EPI == EPI_LINEAR_FOLD);
+    if (!BIG && (EPI == EPI_HEADS || EPI == EPI_HEADS_FOLD) && a.heads > 0) {
         const int per = a.heads * a.dh;
         loader_ok = per % 144 == 0 && a.dh >= 48 && a.dh % 4 == 0 && a.rows_per_batch >= 128;
         for (int sgi = 0; sgi < a.n_seg; ++sgi) loader_ok = loader_ok && a.kind[sgi] != PRIMX_HEADS_VT;
     }
     auto go = [&](const GemmArgs<DT>& x) {
+        // the LayerNorm-fold epilogues exist in exactly one kernel per tile shape (launch_fold checked the shape)
+        if constexpr (FOLD_EPI) {
+            if constexpr (BIG && EPI == EPI_LINEAR_FOLD) {
+                PRIMX_NOTE_KERNEL("gemm288p_dma_kernel<%d, true>", DT);
+                hipLaunchKernelGGL((gemm288p_dma_kernel<DT, true>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
+            } else if constexpr (BIG && EPI == EPI_HEADS_FOLD) {
+                PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d>", DT, EPI);
+                hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, PRIMX_GEMM_PASS(x));
+            } else if constexpr (!BIG) {
+                PRIMX_NOTE_KERNEL("gemm144l_dma_kernel<%d, %d>", DT, EPI);
+                hipLaunchKernelGGL((gemm144l_dma_kernel<DT, EPI>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
+            }
+            return;
+        } else {
         // two passes only when the launch is ONE round of workgroups (fc1 at T = 4096: exactly 256): there the first pass's stores
         // drain under the second pass (the step 8.97 -> 8.92 ms same box); with several rounds per CU the next workgroup already
         // overlaps the previous one's drain and the one-pass tile's fewer bytes per FLOP win (T = 32768: 428 vs 451 us)
@@ -1924,6 +2246,7 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
         } else {
             PRIMX_NOTE_KERNEL("gemm144_dma_kernel<%d, %d>", DT, EPI);
             hipLaunchKernelGGL((gemm144_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, PRIMX_GEMM_PASS(x));
+        }
         }
     };
     if (!g_gemm_prof_on) {
@@ -2012,6 +2335,47 @@ int launch(const GemmArgs<DT>& a_in, hipStream_t st, const char* name) {
     } else {
         PRIMX_NOTE_KERNEL("gemm_kernel<%d, %d, 32, 2, 2, 2, 2, %d>", DT, EPI, GATHER);
         hipLaunchKernelGGL((gemm_kernel<DT, EPI, 32, 2, 2, 2, 2, GATHER>), dim3(mt * ((a.N + 127) / 128)), dim3(256), 0, st, a);
+    }
+    PRIMX_CHECK_LAUNCH(name);
+    return PRIMX_OK;
+}
+
+// The LayerNorm-fold GEMMs (see fold_stats_load): explicit kernel choice, an error where the fold kernels do not cover the shape - the
+// caller decides per model whether it folds (DiT: ops.fold_supported) and keeps the LayerNorm launches otherwise.
+template <int DT, int EPI>
+int launch_fold(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
+    PRIMX_REQUIRE(a.A && a.W, "%s: null operand", name);
+    PRIMX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % BK == 0 && a.N % 144 == 0,
+                  "%s: the fold kernels need N %% 144 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", name, a.M, a.N, a.K);
+    const int mt = (a.M + 127) / 128;
+    if constexpr (EPI == EPI_GATE_RESIDUAL_FOLD) {
+        PRIMX_REQUIRE(a.N / 144 <= 8, "%s: at most 8 column tiles (N <= 1152), the consumers read 8 partial sums per row (N=%d)", name, a.N);
+        PRIMX_REQUIRE((((uintptr_t)a.ln_scale | (uintptr_t)a.ln_out | (uintptr_t)a.fold_part) & 7) == 0 && a.ln_mod_stride % 4 == 0,
+                      "%s: the scale vectors, the operand and the partial sums must be 8-byte aligned", name);
+        launch144_dma<DT, EPI>(a, mt, st);
+    } else {
+        PRIMX_REQUIRE(a.K % 144 == 0 && a.fold_parts == a.K / 144 && a.fold_parts <= 8,
+                      "%s: K must be the producer's N: a multiple of 144, at most 1152 (K=%d)", name, a.K);
+        PRIMX_REQUIRE((((uintptr_t)a.fold_u | (uintptr_t)a.fold_v) & 15) == 0 && ((uintptr_t)a.fold_part & 7) == 0,
+                      "%s: u / v must be 16-byte aligned, the partial sums 8-byte aligned", name);
+        if constexpr (EPI == EPI_HEADS_FOLD) {
+            const int per = a.heads * a.dh;
+            const bool big = !g_no_big && g_big_heads_min > 0 && a.N % 288 == 0 && per % 288 == 0 && 288 % a.dh == 0 && a.dh % 8 == 0 &&
+                             a.dh >= 32 && a.rows_per_batch % 256 == 0 && (a.M / 256) * (a.N / 288) >= g_big_heads_min;
+            if (big) {
+                launch144_dma<DT, EPI, 1>(a, mt, st);
+            } else {
+                bool ok = per % 144 == 0 && a.dh >= 48 && a.dh % 4 == 0 && a.rows_per_batch >= 128 && g_loader;
+                for (int sgi = 0; sgi < a.n_seg; ++sgi) ok = ok && a.kind[sgi] != PRIMX_HEADS_VT;
+                PRIMX_REQUIRE(ok, "%s: head layout outside the fold kernels (heads=%d dh=%d rows_per_batch=%d)", name, a.heads, a.dh,
+                              a.rows_per_batch);
+                launch144_dma<DT, EPI>(a, mt, st);
+            }
+        } else {
+            const int wgs = ((a.M + 255) / 256) * (a.N / 288);
+            if (!g_no_big && g_two_pass && a.N % 288 == 0 && wgs >= g_big_min && wgs <= 256) launch144_dma<DT, EPI, 1>(a, mt, st);
+            else launch144_dma<DT, EPI>(a, mt, st);
+        }
     }
     PRIMX_CHECK_LAUNCH(name);
     return PRIMX_OK;
@@ -2220,6 +2584,98 @@ extern "C" int primx_linear_heads(const void* A, const void* W, const void* bias
         }
         if (int rc = set_prefetch<DT>(a, prefetch, prefetch_bytes, "primx_linear_heads")) return rc;
         return launch<DT, EPI_HEADS>(a, (hipStream_t)stream, "primx_linear_heads");
+    });
+    return PRIMX_OK;
+}
+
+// ---- LayerNorm fold (see fold_stats_load)
+extern "C" int primx_linear_f32out(const void* A, const void* W, const void* bias, float* out, int M, int N, int K,
+                                   int bias_from_row, int dtype, void* stream) {
+    PRIMX_REQUIRE(A && W && out, "primx_linear_f32out: null pointer");
+    PRIMX_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0, "primx_linear_f32out: need M,N>0 and K %% 8 == 0 (M=%d N=%d K=%d)", M, N, K);
+    PRIMX_DISPATCH_16(dtype, "primx_linear_f32out", {
+        using S = typename T16<DT>::S;
+        GemmArgs<DT> a = {};
+        a.A = (const S*)A; a.W = (const S*)W; a.bias = (const S*)bias;
+        a.M = M; a.N = N; a.K = K;
+        a.x = out; a.rows_per_batch = bias_from_row;
+        PRIMX_NOTE_KERNEL("gemm_kernel<%d, %d, 32, 2, 2, 2, 2, 0>", DT, EPI_F32OUT);
+        hipLaunchKernelGGL((gemm_kernel<DT, EPI_F32OUT, 32, 2, 2, 2, 2, 0>), dim3(((M + 127) / 128) * ((N + 127) / 128)), dim3(256), 0,
+                           (hipStream_t)stream, a);
+    });
+    PRIMX_CHECK_LAUNCH("primx_linear_f32out");
+    return PRIMX_OK;
+}
+
+extern "C" int primx_linear_gate_residual_fold(const void* A, const void* W, const void* bias, const void* gate,
+                                               int64_t gate_stride, float* x, int M, int N, int K, int rows_per_batch,
+                                               const void* next_scale, int64_t next_mod_stride, const float* center,
+                                               void* a16_out, float* part_out, int dtype, const void* prefetch,
+                                               int64_t prefetch_bytes, void* stream) {
+    const char* name = "primx_linear_gate_residual_fold";
+    PRIMX_REQUIRE(gate && x && rows_per_batch > 0 && next_scale && center && a16_out && part_out, "%s: bad argument", name);
+    PRIMX_DISPATCH_16(dtype, name, {
+        using S = typename T16<DT>::S;
+        GemmArgs<DT> a = {};
+        a.A = (const S*)A; a.W = (const S*)W; a.bias = (const S*)bias;
+        a.M = M; a.N = N; a.K = K;
+        a.gate = (const S*)gate; a.gate_stride = gate_stride; a.x = x; a.rows_per_batch = rows_per_batch;
+        a.ln_scale = (const S*)next_scale; a.ln_mod_stride = next_mod_stride; a.ln_out = (S*)a16_out;
+        a.fold_c = const_cast<float*>(center); a.fold_part = part_out;
+        if (int rc = set_prefetch<DT>(a, prefetch, prefetch_bytes, name)) return rc;
+        return launch_fold<DT, EPI_GATE_RESIDUAL_FOLD>(a, (hipStream_t)stream, name);
+    });
+    return PRIMX_OK;
+}
+
+extern "C" int primx_linear_heads_fold(const void* A, const void* W, int M, int N, int K, int rows_per_batch, int heads, int dh,
+                                       int n_seg, const int* kind, void* const* dst, int n_pad, float scale0, const float* part,
+                                       const float* u, const float* v, float* center, float eps, int dtype,
+                                       const void* prefetch, int64_t prefetch_bytes, void* stream) {
+    const char* name = "primx_linear_heads_fold";
+    PRIMX_REQUIRE(kind && dst && n_seg >= 1 && n_seg <= 3, "%s: n_seg must be 1..3", name);
+    PRIMX_REQUIRE(heads > 0 && dh > 0 && N == n_seg * heads * dh, "%s: N must equal n_seg*heads*dh", name);
+    PRIMX_REQUIRE(rows_per_batch > 0 && M % rows_per_batch == 0 && n_pad >= rows_per_batch && n_pad % 16 == 0,
+                  "%s: need M %% rows_per_batch == 0, n_pad >= rows_per_batch, n_pad %% 16 == 0", name);
+    PRIMX_REQUIRE(part && u && v && center, "%s: null fold argument", name);
+    for (int s = 0; s < n_seg; ++s) {
+        PRIMX_REQUIRE(dst[s] != nullptr, "%s: null destination", name);
+        PRIMX_REQUIRE(kind[s] == PRIMX_HEADS_ROWS || kind[s] == PRIMX_HEADS_VT || kind[s] == PRIMX_HEADS_KROWS, "%s: bad kind", name);
+    }
+    PRIMX_DISPATCH_16(dtype, name, {
+        using S = typename T16<DT>::S;
+        GemmArgs<DT> a = {};
+        a.A = (const S*)A; a.W = (const S*)W;
+        a.M = M; a.N = N; a.K = K;
+        a.rows_per_batch = rows_per_batch; a.heads = heads; a.dh = dh; a.DP = primx_padded_head_dim(dh);
+        a.n_pad = n_pad; a.n_seg = n_seg; a.scale0 = scale0;
+        for (int s = 0; s < 3; ++s) {
+            a.kind[s] = s < n_seg ? kind[s] : 0;
+            a.rep_stride[s] = 0;
+            a.dst[s] = s < n_seg ? (S*)dst[s] : nullptr;
+        }
+        a.fold_part = const_cast<float*>(part); a.fold_parts = K / 144; a.fold_u = u; a.fold_v = v; a.fold_c = center; a.fold_eps = eps;
+        if (int rc = set_prefetch<DT>(a, prefetch, prefetch_bytes, name)) return rc;
+        return launch_fold<DT, EPI_HEADS_FOLD>(a, (hipStream_t)stream, name);
+    });
+    return PRIMX_OK;
+}
+
+extern "C" int primx_linear_fold(const void* A, const void* W, void* out, int M, int N, int K, int act, const float* part,
+                                 const float* u, const float* v, float* center, float eps, int dtype, const void* prefetch,
+                                 int64_t prefetch_bytes, void* stream) {
+    const char* name = "primx_linear_fold";
+    PRIMX_REQUIRE(out && part && u && v && center, "%s: null pointer", name);
+    PRIMX_REQUIRE(act == PRIMX_ACT_NONE || act == PRIMX_ACT_GELU_TANH || act == PRIMX_ACT_GELU_ERF, "%s: bad activation code", name);
+    PRIMX_DISPATCH_16(dtype, name, {
+        using S = typename T16<DT>::S;
+        GemmArgs<DT> a = {};
+        a.A = (const S*)A; a.W = (const S*)W;
+        a.M = M; a.N = N; a.K = K;
+        a.out = (S*)out; a.act = act; a.out_scale = 1.0f;
+        a.fold_part = const_cast<float*>(part); a.fold_parts = K / 144; a.fold_u = u; a.fold_v = v; a.fold_c = center; a.fold_eps = eps;
+        if (int rc = set_prefetch<DT>(a, prefetch, prefetch_bytes, name)) return rc;
+        return launch_fold<DT, EPI_LINEAR_FOLD>(a, (hipStream_t)stream, name);
     });
     return PRIMX_OK;
 }

@@ -181,6 +181,29 @@ extern "C" int primx_layernorm_modulate(const float* x, const void* shift, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row means of the fp32 residual stream: the centre of the first folded LayerNorm site of a forward (gemm.hip, "LayerNorm fold").
+// One half-wave per row, the loads and the summation order of ln_row32.
+__global__ __launch_bounds__(256) void row_mean_kernel(const float* __restrict__ x, int rows, int D, float* __restrict__ mean) {
+    const int row = (int)blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * D;
+    float s = 0.f;
+    for (int c = l32 * 4; c < D; c += 128) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    s = half_wave_sum(s);
+    if (l32 == 0) mean[row] = s * (1.0f / (float)D);
+}
+
+extern "C" int primx_row_mean(const float* x, int rows, int D, float* mean, void* stream) {
+    PRIMX_REQUIRE(x && mean && rows > 0 && D > 0 && D % 4 == 0, "primx_row_mean: need rows > 0 and D %% 4 == 0 (D=%d)", D);
+    hipLaunchKernelGGL(row_mean_kernel, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, rows, D, mean);
+    PRIMX_CHECK_LAUNCH("primx_row_mean");
+    return PRIMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, const float* __restrict__ freqs,
                                           float* __restrict__ emb, int B, int dim) {
     const int half = dim / 2;

@@ -175,6 +175,17 @@ class DiT(nn.Module):
         self.fuse_ln = os.environ.get("PRIMX_DIT_FUSE_LN", "1") != "0"
         self.ln_in_kernel = os.environ.get("PRIMX_DIT_LN_TAIL", "0") == "1"
         self._ln_sync: Dict = {}              # device -> int32 workspace of the fused route (zero between launches)
+        # `fold_ln` (default on; PRIMX_DIT_FOLD=0 turns it off): the LayerNorm fold (include/primx_hip.h, ABI 22; csrc/gemm.hip "LayerNorm fold").  In a PLANNED
+        # sampling loop (plan_timesteps: the modulation vectors of every coming call are known) each LayerNorm + modulate between a
+        # gated residual add and a Linear is folded into the two GEMMs around it: the gate-residual GEMM also stores the centred,
+        # scaled 16-bit operand and partial row sums, the consumer (to_q / qkv / fc1) finishes the statistics and applies them in
+        # its epilogue with the per-timestep vectors u = (1 + scale) W^T, v = shift W^T + b.  83 of the 85 LayerNorm launches of a
+        # DiT-XL forward disappear (the first of block 0 and the final layer's stay).  NOT bit-identical to the unfolded path: the
+        # operand is rounded before the normalisation instead of after it - equal accuracy against the fp32 reference
+        # (tools/ln_fold_study.py; tests/test_hip_fold.py).  Applies at the shapes the fold kernels cover (_fold_ok); every other
+        # call - unplanned forwards included - takes the LayerNorm launches.
+        self.fold_ln = os.environ.get("PRIMX_DIT_FOLD", "1") != "0"
+        self._fold_ws: Dict = {}              # (device, rows) -> (center, part) workspaces of the fold
         self._side: Dict = {}
         self._t_plan: Optional[Dict] = None   # plan_timesteps(): the coming calls' timesteps and their modulation table
 
@@ -566,6 +577,43 @@ class DiT(nn.Module):
             plan["mod"] = {key: tab}
         return tab
 
+    _FOLD_MAX_ROWS = 4096   # tokens x batch entries up to which the fold is taken (beyond, the big-tile kernels serve the producers)
+
+    def _fold_ok(self, T: int, N: int) -> bool:
+        return bool(self.fold_ln) and self.depth > 0 and T <= self._FOLD_MAX_ROWS and ops.fold_shapes_ok(
+            T, N, self.hidden_size, self.num_heads)
+
+    def _fold_tables(self, plan: Dict, dt: torch.dtype, pk: Dict) -> Dict:
+        """The fold's per-timestep vectors of a planned loop: for every block and site (to_q, qkv, fc1) u = cast16(1 + scale) W^T
+        and v = shift W^T + b in fp32, all planned timesteps in ONE GEMM per (block, site) - 3 x depth launches per loop, the rows
+        [2, n_timesteps, N_site]."""
+        key = (dt, pk["w_ada"].data_ptr())
+        ft = plan.get("fold")
+        if ft is not None and ft["key"] == key:
+            return ft
+        tab = self._modulation_table(plan, dt, pk)
+        n, D, depth = tab.shape[0], self.hidden_size, self.depth
+        v = tab[:, :depth * 9 * D].view(n, depth, 3, 3, D)               # [timestep, block, site, (shift, scale, gate), D]
+        A = torch.empty(depth, 3, 2, n, D, dtype=dt, device=tab.device)
+        A[:, :, 0] = (1 + v[:, :, :, 1]).permute(1, 2, 0, 3)              # (1 + scale) is formed in the 16-bit type, as autocast does
+        A[:, :, 1] = v[:, :, :, 0].permute(1, 2, 0, 3)
+        # (3 x depth - 1 independent few-row GEMMs, 9 - 36 workgroups and ~20 us each: 0.07 ms per step of a 25-step loop.  Issued
+        # round-robin on four side streams they overlap - and every LATER launch of the loop got slower: the step 8.83 vs 8.63 ms on
+        # the same box, against 8.97 unfolded (profiles/r4_experiments.txt section 6).  They stay on the calling stream.)
+        uv = []
+        for i, w in enumerate(pk["blocks"]):
+            row = []
+            for s, name in enumerate(("q", "qkv", "fc1")):
+                if i == 0 and s == 0:                                     # (the first LayerNorm of a forward stays a launch)
+                    row.append(None)
+                    continue
+                out = torch.empty(2, n, w["w_" + name].shape[0], dtype=torch.float32, device=tab.device)
+                ops.linear_f32out(A[i, s].view(2 * n, D), w["w_" + name], w["b_" + name], out.view(2 * n, -1), bias_from_row=n)
+                row.append(out)
+            uv.append(row)
+        ft = plan["fold"] = {"key": key, "uv": uv}
+        return ft
+
     def _forward16(self, x, t, y, dt, null_half: bool):
         """The 16-bit autocast path.  `null_half`: classifier-free guidance - the effective batch is [x; x] with the
         second half conditioned on the null embedding (dit_crossattn.py:204-209), assembled here without materialising
@@ -660,6 +708,16 @@ class DiT(nn.Module):
                 sync = self._ln_sync[key] = torch.zeros(2 * sync_w, dtype=torch.int32, device=dev)
         base = self.depth * 9 * D
         fin_mod = (mod[:, base:base + D], mod[:, base + D:base + 2 * D])    # final layer's shift / scale
+        # the LayerNorm fold (`fold_ln`): planned calls only - u / v come from the loop's tables, shared by all batch entries
+        fold_uv = fcent = fpart = None
+        prow = plan["row"] if plan is not None else None
+        if (prow is not None and fuse and not collapse and not (self.cfg_streams and null_half and ops.PROFILE is None)
+                and self._fold_ok(T, N)):
+            fold_uv = self._fold_tables(plan, dt, pk)["uv"]
+            wk = (str(dev), T)
+            if wk not in self._fold_ws:
+                self._fold_ws = {wk: ops.fold_workspace(T, D, dev)}
+            fcent, fpart = self._fold_ws[wk]
 
         def warm(*wts):
             return wts if wpf == 1 else ()
@@ -679,13 +737,25 @@ class DiT(nn.Module):
                     return None
                 return (shift, scale, xh, self.LN_EPS, None if sync is None else (sync[:sync_w] if b0 == 0 else sync[sync_w:]))
             # ---- cross-attention to the image tokens (dit_crossattn.py:55, attention.py:96-114)
+            folded = fold_uv is not None
+            fc, fp = (fcent[r0:r1], fpart[r0:r1]) if folded else (None, None)
+            uvs = fold_uv[i] if folded else None
+
+            def uv(s):                                   # this call's (u, v) of site s: rows of the planned loop's tables
+                return uvs[s][0, prow], uvs[s][1, prow]
             if not fuse or i == 0:                       # (fused: the previous block's fc2 launch has normalised these rows)
                 # (the block's cross-attention K / V as the prefetch instead: -1.0 us on that kernel, +0.5 on this one)
                 ops.layernorm_modulate(hh, ch[0], ch[1], N, xh, self.LN_EPS, prefetch=warm(w["w_q"], w["w_cproj"]))
+                if folded:
+                    ops.row_mean(hh, fc)                 # the centre of the first folded site
             bc = min(b1, B) if collapse else b1          # batch entries [b0, bc) attend; [bc, b1) are unconditional rows
             if bc > b0:
-                ops.linear_heads(xh[:(bc - b0) * N], w["w_q"], w["b_q"], N, H, dh, [HEADS_ROWS], [Qc[b0:bc]], nq_pad, scale0=scale,
-                                 carry=carry(w["w_cproj"]))
+                if folded and i > 0:                     # (folded: bc == b1, every row attends)
+                    ops.linear_heads_fold(xh, w["w_q"], N, H, dh, [HEADS_ROWS], [Qc[b0:bc]], nq_pad, fp, *uv(0), fc, self.LN_EPS,
+                                          scale0=scale, carry=carry(w["w_cproj"]))
+                else:
+                    ops.linear_heads(xh[:(bc - b0) * N], w["w_q"], w["b_q"], N, H, dh, [HEADS_ROWS], [Qc[b0:bc]], nq_pad,
+                                     scale0=scale, carry=carry(w["w_cproj"]))
                 if dedup and bc > B:                     # entries [max(b0, B), bc) take the broadcast key / value entry
                     kc = Kc_blk[i][b0:B] if b0 < B else None
                     ops.attention(Qc[b0:bc], kc, Vc_blk[i][b0:B] if b0 < B else None, N, L, dh, scale, out=ah[:bc - b0],
@@ -700,24 +770,42 @@ class DiT(nn.Module):
                 ah[max(bc, b0) - b0:].copy_(vrow.expand(-1, N, -1))
             if hook is not None:
                 hook()
-            ops.linear_gate_residual(ah.view(Th, D), w["w_cproj"], w["b_cproj"], ch[2], hh, N, carry=carry(w["w_proj"]),
-                                     ln=ln_of(ch[3], ch[4]))
+            if folded:                                   # producer of the qkv site
+                ops.linear_gate_residual_fold(ah.view(Th, D), w["w_cproj"], w["b_cproj"], ch[2], hh, N, ch[4], fc, xh, fp,
+                                              carry=carry(w["w_proj"]))
+            else:
+                ops.linear_gate_residual(ah.view(Th, D), w["w_cproj"], w["b_cproj"], ch[2], hh, N, carry=carry(w["w_proj"]),
+                                         ln=ln_of(ch[3], ch[4]))
             # ---- self-attention over the primitive tokens (dit_crossattn.py:56, attention.py:48-59)
             if not fuse:
                 ops.layernorm_modulate(hh, ch[3], ch[4], N, xh, self.LN_EPS, prefetch=warm(w["w_proj"]))
-            ops.linear_heads(xh, w["w_qkv"], w["b_qkv"], N, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT],
-                             [Qs[b0:b1], Ks[b0:b1], Vs[b0:b1]], nq_pad)
+            if folded:
+                ops.linear_heads_fold(xh, w["w_qkv"], N, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT],
+                                      [Qs[b0:b1], Ks[b0:b1], Vs[b0:b1]], nq_pad, fp, *uv(1), fc, self.LN_EPS)
+            else:
+                ops.linear_heads(xh, w["w_qkv"], w["b_qkv"], N, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT],
+                                 [Qs[b0:b1], Ks[b0:b1], Vs[b0:b1]], nq_pad)
             ops.attention(Qs[b0:b1], Ks[b0:b1], Vs[b0:b1], N, N, dh, scale, out=ah)
-            ops.linear_gate_residual(ah.view(Th, D), w["w_proj"], w["b_proj"], ch[5], hh, N, ln=ln_of(ch[6], ch[7]))
+            if folded:                                   # producer of the fc1 site
+                ops.linear_gate_residual_fold(ah.view(Th, D), w["w_proj"], w["b_proj"], ch[5], hh, N, ch[7], fc, xh, fp)
+            else:
+                ops.linear_gate_residual(ah.view(Th, D), w["w_proj"], w["b_proj"], ch[5], hh, N, ln=ln_of(ch[6], ch[7]))
             # ---- MLP (dit_crossattn.py:57, models/utils.py:94-101)
             if not fuse:
                 ops.layernorm_modulate(hh, ch[6], ch[7], N, xh, self.LN_EPS, prefetch=warm(w["w_fc2"]))
-            ops.linear(xh, w["w_fc1"], w["b_fc1"], out=hid[r0:r1], act=ACT_GELU_TANH, carry=carry(w["w_fc2"]))
+            if folded:
+                ops.linear_fold(xh, w["w_fc1"], hid[r0:r1], fp, *uv(2), fc, self.LN_EPS, act=ACT_GELU_TANH, carry=carry(w["w_fc2"]))
+            else:
+                ops.linear(xh, w["w_fc1"], w["b_fc1"], out=hid[r0:r1], act=ACT_GELU_TANH, carry=carry(w["w_fc2"]))
             last = i + 1 == len(blocks)
             nxt = (fin_mod[0][b0:b1], fin_mod[1][b0:b1]) if last else \
                 (mod[b0:b1, (i + 1) * 9 * D:(i + 1) * 9 * D + D], mod[b0:b1, (i + 1) * 9 * D + D:(i + 1) * 9 * D + 2 * D])
-            ops.linear_gate_residual(hid[r0:r1], w["w_fc2"], w["b_fc2"], ch[8], hh, N,
-                                     carry=None if last else carry(blocks[i + 1]["w_q"]), ln=ln_of(*nxt))
+            if folded and not last:                      # producer of the next block's to_q site
+                ops.linear_gate_residual_fold(hid[r0:r1], w["w_fc2"], w["b_fc2"], ch[8], hh, N, nxt[1], fc, xh, fp,
+                                              carry=carry(blocks[i + 1]["w_q"]))
+            else:                                        # (the final layer's LayerNorm stays a launch: its Linear has 8 columns)
+                ops.linear_gate_residual(hid[r0:r1], w["w_fc2"], w["b_fc2"], ch[8], hh, N,
+                                         carry=None if last else carry(blocks[i + 1]["w_q"]), ln=ln_of(*nxt))
 
         if self.cfg_streams and null_half and self.depth and ops.PROFILE is None:
             # Two HIP streams, one per CFG half (the conditional and the unconditional rows are independent chains of

@@ -301,6 +301,120 @@ def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
         "primx_linear_heads"))
 
 
+# ----------------------------------------------------------------------------- the LayerNorm fold (include/primx_hip.h, ABI 22)
+FOLD_TILE = 144     # columns per partial sum of the producer; the consumers read at most FOLD_MAX_PARTS of them per row
+FOLD_MAX_PARTS = 8
+
+
+def fold_supported(D: int, heads: int) -> bool:
+    """Can a DiT of width D fold its LayerNorms into the neighbouring GEMMs?  (producer: N = D in 144-column tiles, at most 8;
+    consumers: K = D; heads layout of the 128 x 144 / 256 x 288 kernels)"""
+    dh = D // max(heads, 1)
+    return D % FOLD_TILE == 0 and D // FOLD_TILE <= FOLD_MAX_PARTS and D % 64 == 0 and dh >= 48 and dh % 4 == 0
+
+
+def fold_shapes_ok(T: int, rows_per_batch: int, D: int, heads: int) -> bool:
+    """Do ALL GEMMs of a DiT block at T = batch entries x rows_per_batch token rows have a fold kernel?  The qkv projection writes a
+    V^T segment, which only the 256 x 288 tile's heads epilogue does under the fold: the launch must qualify for it (the rule of
+    csrc/gemm.hip launch_fold, including the switches that move it)."""
+    if not fold_supported(D, heads) or rows_per_batch < 128:
+        return False
+    if os.environ.get("PRIMX_GEMM_NOBIG") == "1" or os.environ.get("PRIMX_GEMM_LOADER") == "0":
+        return False
+    big_min = int(os.environ.get("PRIMX_GEMM_BIGHEADS_MIN", "160"))
+    dh = D // heads
+    return (big_min > 0 and D % 288 == 0 and 288 % dh == 0 and dh % 8 == 0 and dh >= 32 and rows_per_batch % 256 == 0
+            and (T // 256) * (3 * D // 288) >= big_min)
+
+
+def fold_workspace(rows: int, D: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(center [rows] fp32, part [rows, D / 144, 2] fp32) of one forward."""
+    return (torch.empty(rows, dtype=torch.float32, device=device),
+            torch.empty(rows, D // FOLD_TILE, 2, dtype=torch.float32, device=device))
+
+
+def row_mean(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[r] = mean(x[r, :]) (fp32): the centre of the first folded LayerNorm site of a forward."""
+    rows, D = x.shape
+    check(_lib.load().primx_row_mean(_dev(x, "x", torch.float32), rows, D, _dev(out, "mean", torch.float32), _stream()),
+          "primx_row_mean")
+    return out
+
+
+def linear_f32out(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, bias_from_row: int) -> torch.Tensor:
+    """out[M, N] (fp32) = A W^T (+ bias for the rows >= bias_from_row): the fold's u rows (no bias) and v rows in one launch."""
+    M, K = A.shape
+    N = W.shape[0]
+    if tuple(out.shape) != (M, N) or W.shape[1] != K:
+        raise RuntimeError("linear_f32out: shape mismatch")
+    _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_f32out(
+        _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None,
+        _dev(out, "out", torch.float32), M, N, K, bias_from_row, dtype_code(A.dtype), _stream()), "primx_linear_f32out"))
+    return out
+
+
+def _fold_args(part: torch.Tensor, u: torch.Tensor, v: torch.Tensor, center: torch.Tensor, M: int, N: int, K: int):
+    if K % FOLD_TILE or tuple(part.shape) != (M, K // FOLD_TILE, 2) or center.numel() != M:
+        raise RuntimeError("fold: `part` must be [M, K / 144, 2] and `center` [M] (fp32)")
+    for t, name in ((u, "u"), (v, "v")):
+        if t.dtype != torch.float32 or t.numel() != N or not t.is_contiguous() or t.data_ptr() % 16:
+            raise RuntimeError(f"fold: {name} must be a contiguous, 16-byte aligned fp32 vector of N elements")
+    return (_dev(part, "part", torch.float32), u.data_ptr(), v.data_ptr(), _dev(center, "center", torch.float32))
+
+
+def linear_gate_residual_fold(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], gate: torch.Tensor, x: torch.Tensor,
+                              rows_per_batch: int, next_scale: torch.Tensor, center: torch.Tensor, a16: torch.Tensor,
+                              part: torch.Tensor, carry: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """linear_gate_residual as the PRODUCER of the LayerNorm site behind it: also a16[m] = cast16((x[m] - center[m]) cast16(1 +
+    next_scale[b])) and the per-tile partial sums of (x - center), (x - center)^2 into `part`."""
+    M, K = A.shape
+    N = W.shape[0]
+    if gate.stride(-1) != 1 or gate.dtype != A.dtype or not gate.is_cuda:
+        raise RuntimeError("gate must be a last-dim-contiguous 16-bit device view")
+    if next_scale.stride(-1) != 1 or next_scale.dtype != A.dtype or not next_scale.is_cuda or next_scale.shape[-1] != N:
+        raise RuntimeError("next_scale must be a last-dim-contiguous 16-bit device view of N columns")
+    if tuple(a16.shape) != (M, N) or a16.dtype != A.dtype or tuple(part.shape) != (M, N // FOLD_TILE, 2) or center.numel() != M:
+        raise RuntimeError("linear_gate_residual_fold: a16 must be [M, N] 16-bit, part [M, N / 144, 2], center [M]")
+    cp, cn = _range(carry)
+    _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_gate_residual_fold(
+        _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None,
+        gate.data_ptr(), gate.stride(0), _dev(x, "x", torch.float32), M, N, K, rows_per_batch,
+        next_scale.data_ptr(), next_scale.stride(0), _dev(center, "center", torch.float32), _dev(a16, "a16"),
+        _dev(part, "part", torch.float32), dtype_code(A.dtype), cp, cn, _stream()), "primx_linear_gate_residual_fold"))
+    return x
+
+
+def linear_heads_fold(A: torch.Tensor, W: torch.Tensor, rows_per_batch: int, heads: int, dh: int, kinds: Sequence[int],
+                      dsts: Sequence[torch.Tensor], n_pad: int, part: torch.Tensor, u: torch.Tensor, v: torch.Tensor,
+                      center: torch.Tensor, eps: float, scale0: float = 1.0, carry: Optional[torch.Tensor] = None) -> None:
+    """linear_heads as the CONSUMER of a folded LayerNorm site: A = the producer's a16; the Linear's bias is part of v."""
+    M, K = A.shape
+    N = W.shape[0]
+    n_seg = len(kinds)
+    kind_arr = (C.c_int * n_seg)(*kinds)
+    dst_arr = (C.c_void_p * n_seg)(*[_dev(d, "dst", A.dtype) for d in dsts])
+    fa = _fold_args(part, u, v, center, M, N, K)
+    cp, cn = _range(carry)
+    _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_heads_fold(
+        _dev(A, "A"), _dev(W, "W", A.dtype), M, N, K, rows_per_batch, heads, dh, n_seg, kind_arr, dst_arr, n_pad, scale0,
+        fa[0], fa[1], fa[2], fa[3], eps, dtype_code(A.dtype), cp, cn, _stream()), "primx_linear_heads_fold"))
+
+
+def linear_fold(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, part: torch.Tensor, u: torch.Tensor, v: torch.Tensor,
+                center: torch.Tensor, eps: float, act: int = ACT_NONE, carry: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """linear as the CONSUMER of a folded LayerNorm site (fc1 + GELU)."""
+    M, K = A.shape
+    N = W.shape[0]
+    if tuple(out.shape) != (M, N) or out.dtype != A.dtype:
+        raise RuntimeError("linear_fold: out must be a 16-bit [M, N] tensor of A's dtype")
+    fa = _fold_args(part, u, v, center, M, N, K)
+    cp, cn = _range(carry)
+    _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_fold(
+        _dev(A, "A"), _dev(W, "W", A.dtype), _dev(out, "out"), M, N, K, act, fa[0], fa[1], fa[2], fa[3], eps,
+        dtype_code(A.dtype), cp, cn, _stream()), "primx_linear_fold"))
+    return out
+
+
 # ----------------------------------------------------------------------------- attention
 KEY_MASK_VALUE = -30000.0  # finite in fp16 and bf16; times scale*log2(e) it underflows exp2 to exactly 0
 

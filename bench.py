@@ -393,6 +393,20 @@ def main() -> None:
                             "half are projected by to_k / to_v, stored and read like the conditional ones; bit-identical attention "
                             "results (tests/test_hip_attention.py::test_broadcast_key_value_entries)"}
 
+    # The same K steps with the LayerNorm fold off (DiT.fold_ln = False: 85 LayerNorm launches per forward instead of 2): what the
+    # fold saves, for the record (it changes rounding points, not accuracy: tests/test_hip_fold.py, tests/test_hip_fullconfig.py).
+    unfolded = None
+    if args.config == "ddim" and rank == 0 and world == 1 and getattr(model, "fold_ln", False) and model._fold_ok(2 * B * N, N):
+        model.fold_ln = False
+        run_steps(args.warmup)
+        el, _ = timed_repeats(run_steps, args.steps, max(1, args.repeats), 1, dist, dev)
+        model.fold_ln = True
+        run_steps(1)
+        e = statistics.median(el)
+        unfolded = {"ms_per_step": 1e3 * e / args.steps, "value": B * args.steps / e, "unit": "denoise-steps/s",
+                    "note": "DiT.fold_ln=False (PRIMX_DIT_FOLD=0): every LayerNorm + modulate as a launch of its own between the "
+                            "gate-residual GEMM and the Linear it feeds (the round-3 / early round-4 path)"}
+
     # Two more shapes of the same loop, reported NEXT TO the headline (outside its timed region, like `decode`): the configs[2] /
     # configs[3] per-GPU batch of 8 (T = 32768 tokens per launch: every GEMM on the 256 x 288 tile) and configs[1] in bf16 - the
     # north star's target dtype.  Same model, same kernels, K steps between synchronisations, median of R.
@@ -537,6 +551,12 @@ def main() -> None:
             res["with_reuse_cond_kv"] = reuse
         if expanded:
             res["with_expanded_null_kv"] = expanded
+        if unfolded:
+            res["with_layernorm_launches"] = unfolded
+        if args.config in ("ddim", "c4"):
+            res["ln_fold"] = {"enabled": bool(getattr(model, "fold_ln", False) and model._fold_ok(2 * B * N, N)),
+                              "what": "LayerNorm + modulate folded into the gate-residual GEMM in front of it (operand + partial row sums) "
+                                      "and the Linear behind it (statistics + per-timestep u, v in the epilogue): csrc/gemm.hip"}
         res.update(side)
         if args.config in ("ddim", "c4"):
             res["ln_in_gemm_tail"] = {"enabled": bool(getattr(model, "fuse_ln", False) and getattr(model, "ln_in_kernel", False)),

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 21
+#define PRIMX_ABI_VERSION 22
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -163,6 +163,49 @@ int primx_linear_gate_residual_ln(const void* A, const void* W, const void* bias
  * dispatch-order assumption of the fused route is violated on this machine (then PRIMX_LN_FUSE=0 selects the two-launch route).
  * Synchronises with the device.  ABI 21. */
 int primx_ln_sync_timeouts(void);
+
+/* ---- The LayerNorm fold (ABI 22).  Every LayerNorm + modulate of a DiT block sits between a gated residual add and a Linear
+ * (models/dit_crossattn.py:55-57).  With the row statistics mu, rho of the fp32 residual stream x, m = cast16(1 + scale) and any
+ * per-row centre c:
+ *     reference:  y = cast16( cast16( (x - mu) rho m + shift ) W^T + b )
+ *     folded:     y = cast16( rho ( cast16((x - c) m) W^T  -  (mu - c) u ) + v ),    u = m W^T,  v = shift W^T + b   (fp32 rows)
+ * so the gate-residual GEMM in front of the LayerNorm (the PRODUCER) can store the 16-bit operand a16 = cast16((x - c) m) and
+ * per-column-tile partial sums of (x - c), (x - c)^2, and the Linear behind it (the CONSUMER: to_q, qkv, fc1) can finish mu, rho
+ * from the partials and apply them with u, v in its epilogue - no LayerNorm launch, no second pass over the fp32 rows.  The
+ * fold rounds (x - c) m where the reference rounds the normalised value: equal accuracy while |mu - c| stays below the row's
+ * spread (tools/ln_fold_study.py), which is why c follows the row mean from site to site (the consumer moves it).  u, v depend
+ * on the timestep only (primx_linear_f32out, once per planned sampling loop).  Shapes: N of the producer = K of the consumer =
+ * a multiple of 144, at most 1152; everything else returns PRIMX_EINVAL and the caller keeps primx_layernorm_modulate. */
+
+/* out[m, n] (fp32) = sum_k A[m, k] W[n, k] + (m >= bias_from_row ? bias[n] : 0): fp32 rows out of 16-bit operands.  The fold's
+ * u rows (A = cast16(1 + scale) of each planned timestep, no bias) and v rows (A = shift, bias = the Linear's) in one launch. */
+int primx_linear_f32out(const void* A, const void* W, const void* bias, float* out, int M, int N, int K, int bias_from_row,
+                        int dtype, void* stream);
+
+/* mean[r] = mean(x[r, :]) in fp32: the centre c of the first folded site of a forward (D % 4 == 0). */
+int primx_row_mean(const float* x, int rows, int D, float* mean, void* stream);
+
+/* primx_linear_gate_residual that is also the PRODUCER of the LayerNorm site behind it:
+ *   x[m, :] += cast16(gate[b, :] * cast16(A W^T + bias)[m, :]);   a16_out[m, :] = cast16( (x[m, :] - center[m]) * cast16(1 + next_scale[b, :]) );
+ *   part_out[m, t, 0 / 1] = sum over the 144 columns of tile t of (x - center), (x - center)^2      (t < N / 144, fixed summation order).
+ * next_scale: the 16-bit scale vectors of the NEXT LayerNorm's modulate, element stride next_mod_stride between batch entries. */
+int primx_linear_gate_residual_fold(const void* A, const void* W, const void* bias, const void* gate, int64_t gate_stride,
+                                    float* x, int M, int N, int K, int rows_per_batch, const void* next_scale,
+                                    int64_t next_mod_stride, const float* center, void* a16_out, float* part_out, int dtype,
+                                    const void* prefetch, int64_t prefetch_bytes, void* stream);
+
+/* primx_linear_heads (n_rep = 1) as the CONSUMER of a folded site: A = the producer's a16, `part` its partial sums (K / 144 per
+ * row), u / v = fp32 vectors of N columns (16-byte aligned; the Linear's bias is part of v), eps = the LayerNorm's.  The
+ * workgroups of column tile 0 add each row's mean of (x - center) to center[m] (the next producer's centre). */
+int primx_linear_heads_fold(const void* A, const void* W, int M, int N, int K, int rows_per_batch, int heads, int dh, int n_seg,
+                            const int* kind, void* const* dst, int n_pad, float scale0, const float* part, const float* u,
+                            const float* v, float* center, float eps, int dtype, const void* prefetch, int64_t prefetch_bytes,
+                            void* stream);
+
+/* primx_linear (out_scale = 1) as the CONSUMER of a folded site (fc1 + GELU): out = act(cast16(rho (a16 W^T - mu' u) + v)). */
+int primx_linear_fold(const void* A, const void* W, void* out, int M, int N, int K, int act, const float* part, const float* u,
+                      const float* v, float* center, float eps, int dtype, const void* prefetch, int64_t prefetch_bytes,
+                      void* stream);
 
 /* Projection whose output columns are `n_rep` repetitions of `n_seg` groups of (heads * dh) features
  * (N = n_rep * n_seg * heads * dh), each group written straight into an attention operand layout (see

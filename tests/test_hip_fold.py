@@ -1,0 +1,340 @@
+"""GPU parity of the LayerNorm fold (include/primx_hip.h, ABI 22; csrc/gemm.hip "LayerNorm fold"): the gate-residual GEMM as the
+PRODUCER of a LayerNorm site (16-bit centred operand + partial row sums next to the residual update), the three CONSUMER GEMMs
+(to_q / qkv / fc1 forms: statistics from the partials, y = rho (acc - mu' u) + v in the epilogue), the fp32-row GEMM of u / v, and
+the DiT with `fold_ln` against the unfolded path and the fp32 oracle.
+
+What is compared with what: a float64 LayerNorm -> modulate -> Linear of the UPDATED residual rows (the reference's arithmetic,
+models/dit_crossattn.py:32-36,55-57) is the truth; the folded chain must meet it with the tolerance of one 16-bit rounding of the
+operand and one of the output - the same bar as the unfolded HIP path, whose error is measured next to it."""
+import os
+
+import pytest
+import torch
+
+from oracle import dit_ref, synth
+from tests.util import max_abs, rel_l2, unpack_rows, unpack_vt
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = {torch.float16: 1.5e-3, torch.bfloat16: 1.2e-2}   # rel-L2 of one 16-bit rounding (tests/test_hip_gemm.py)
+EPS = 1e-6
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import __graft_entry__
+    __graft_entry__.build()
+    from topia_xl_amd import ops
+    return ops
+
+
+def _default_dispatch() -> bool:
+    return not any(os.environ.get(v) for v in ("PRIMX_GEMM_LOADER", "PRIMX_GEMM_NOBIG", "PRIMX_GEMM_P2", "PRIMX_GEMM_BIG_MIN",
+                                               "PRIMX_GEMM_BIGHEADS_MIN", "PRIMX_GEMM_PROF", "PRIMX_LIB"))
+
+
+def _fold_kernels_selectable(ops) -> bool:
+    """False under the kernel-selection switches that take away a tile shape the fold kernels need (PRIMX_GEMM_NOBIG,
+    PRIMX_GEMM_LOADER=0, PRIMX_GEMM_BIGHEADS_MIN=0): the DiT then keeps its LayerNorm launches (ops.fold_shapes_ok) and the
+    operator tests of those kernels do not apply."""
+    return ops.fold_shapes_ok(4096, 2048, 1152, 16)
+
+
+def _last_kernel(ops):
+    from topia_xl_amd import _lib
+    return _lib.load().primx_last_gemm_kernel().decode()
+
+
+def test_row_mean(ops):
+    x = (synth.tensor(3, "x", (300, 1152)) * 3 + 0.7).to(DEV)
+    out = torch.empty(300, device=DEV)
+    ops.row_mean(x, out)
+    assert max_abs(out, x.double().mean(-1)) < 2e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,frm", [(50, 3456, 1152, 25), (6, 1152, 1152, 3), (130, 4608, 1152, 65), (50, 200, 72, 0)])
+def test_linear_f32out(ops, dtype, M, N, K, frm):
+    """fp32 rows out of 16-bit operands; the bias joins the rows from `frm` on (the fold's v rows, not its u rows)."""
+    A = synth.tensor(4, "A", (M, K)).to(dtype)
+    W = synth.tensor(4, "W", (N, K), K ** -0.5).to(dtype)
+    b = synth.tensor(4, "b", (N,), 0.3).to(dtype)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.linear_f32out(A.to(DEV), W.to(DEV), b.to(DEV), out, frm)
+    ref = A.double() @ W.double().t()
+    ref[frm:] += b.double()
+    assert rel_l2(out, ref) < 2e-6 and max_abs(out, ref) < 2e-5 * float(ref.abs().max())
+    out2 = torch.empty_like(out)
+    ops.linear_f32out(A.to(DEV), W.to(DEV), None, out2, 0)
+    assert rel_l2(out2, A.double() @ W.double().t()) < 2e-6
+
+
+def _site(seed, B, n, D, K, dtype, mean_ratio=0.3):
+    """Inputs of one folded LayerNorm site: the branch operand A [B n, K] and weights of the PRODUCER (N = D), the residual
+    stream x with a per-row mean of `mean_ratio` x its spread, gate / shift / scale vectors per batch entry, and the centre c
+    (the row mean one branch ago: the true mean of x plus a perturbation of a tenth of the spread)."""
+    M = B * n
+    A = synth.tensor(seed, "A", (M, K)).to(dtype)
+    W = synth.tensor(seed, "W", (D, K), K ** -0.5).to(dtype)
+    b = synth.tensor(seed, "b", (D,), 0.3).to(dtype)
+    mod = synth.tensor(seed, "mod", (B, 3 * D), 0.4).to(dtype)
+    x = synth.tensor(seed, "x", (M, D)) * 2.0
+    x = x + mean_ratio * x.std(-1, keepdim=True) * synth.tensor(seed, "mr", (M, 1))
+    c = x.mean(-1) + 0.1 * x.std(-1) * synth.tensor(seed, "cn", (M,))
+    return A, W, b, mod, x, c.float().contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,n,K", [(2, 2048, 1152), (2, 2048, 4608), (2, 487, 192), (1, 130, 64)])
+def test_fold_producer(ops, dtype, B, n, K):
+    """x: the same bits as the plain gate-residual GEMM.  a16: EXACTLY cast16((x_new - c) cast16(1 + scale)) of the stored rows.
+    Partial sums: the 144-column sums of (x_new - c) and its square (fp32, fixed order) against float64."""
+    D = 1152
+    M = B * n
+    A, W, b, mod, x, c = _site(21, B, n, D, K, dtype)
+    gate, scale = mod[:, :D], mod[:, D:2 * D]
+    modd = mod.to(DEV)
+    x_plain = x.to(DEV)
+    ops.linear_gate_residual(A.to(DEV), W.to(DEV), b.to(DEV), modd[:, :D], x_plain, n)
+    x_fold = x.to(DEV)
+    a16 = torch.full((M, D), float("nan"), dtype=dtype, device=DEV)
+    part = torch.full((M, D // 144, 2), float("nan"), device=DEV)
+    ops.linear_gate_residual_fold(A.to(DEV), W.to(DEV), b.to(DEV), modd[:, :D], x_fold, n, modd[:, D:2 * D], c.to(DEV), a16, part)
+    if _default_dispatch():
+        assert _last_kernel(ops).startswith("gemm144l_dma_kernel<") and _last_kernel(ops).endswith(", 6>"), _last_kernel(ops)
+        assert torch.equal(x_fold, x_plain)
+    else:
+        assert rel_l2(x_fold, x_plain) < 1e-5
+    d = x_fold.cpu() - c[:, None]                                                   # fp32, as the kernel forms it
+    m16 = (1 + scale).float().repeat_interleave(n, 0)                               # (1 + scale) formed in the 16-bit type
+    assert torch.equal(a16.cpu(), (d * m16).to(dtype))
+    dd = d.double().view(M, D // 144, 144)
+    want = torch.stack([dd.sum(-1), (dd * dd).sum(-1)], -1)
+    assert max_abs(part[..., 0], want[..., 0]) < 1e-5 * float(dd.abs().sum(-1).max())
+    assert rel_l2(part[..., 1], want[..., 1]) < 1e-6
+
+
+def _ln_linear_ref(x_new, shift, scale, n, W, b, dtype):
+    """float64 LayerNorm -> modulate -> Linear of the reference, with autocast's (1 + scale) in the 16-bit type."""
+    xd = x_new.double()
+    mu = xd.mean(-1, keepdim=True)
+    ln = (xd - mu) / torch.sqrt(((xd - mu) ** 2).mean(-1, keepdim=True) + EPS)
+    m = (1 + scale).double().repeat_interleave(n, 0)
+    a = ln * m + shift.double().repeat_interleave(n, 0)
+    return a @ W.double().t() + (0 if b is None else b.double())
+
+
+def _chain(ops, dtype, B, n, Wc, bc, seed, consumer, mean_ratio=0.3):
+    """Producer (N = 1152, K = 1152) -> consumer `consumer(a16, part, u, v, cdev)` against the float64 reference and the unfolded
+    HIP path.  Returns (x_new, reference [M, Nc], LayerNorm output of the unfolded path, the centre before / after)."""
+    D = 1152
+    M = B * n
+    A, W, b, mod, x, c = _site(seed, B, n, D, D, dtype, mean_ratio)
+    shift, scale = mod[:, D:2 * D], mod[:, 2 * D:]
+    modd = mod.to(DEV)
+    xd = x.to(DEV)
+    a16 = torch.empty(M, D, dtype=dtype, device=DEV)
+    part = torch.empty(M, D // 144, 2, device=DEV)
+    cdev = c.to(DEV)
+    # (the modulation of a planned loop is shared by the batch: entry 0's scale / shift vectors serve all rows, row stride 0)
+    ops.linear_gate_residual_fold(A.to(DEV), W.to(DEV), b.to(DEV), modd[:, :D], xd, n, modd[:1, 2 * D:].expand(B, -1), cdev, a16, part)
+    # u, v of the site: rows [cast16(1 + scale); shift] through the fp32-row GEMM (one "timestep")
+    rows = torch.stack([(1 + scale[0]), shift[0]]).to(dtype).to(DEV)
+    uv = torch.empty(2, Wc.shape[0], device=DEV)
+    ops.linear_f32out(rows, Wc.to(DEV), None if bc is None else bc.to(DEV), uv, 1)
+    consumer(a16, part, uv[0], uv[1], cdev)
+    x_new = xd.cpu()
+    ref = _ln_linear_ref(x_new, shift[:1].expand(B, -1), scale[:1].expand(B, -1), n, Wc, bc, dtype)
+    # the centre has moved to the row mean of the updated stream
+    assert max_abs(cdev, x_new.double().mean(-1)) < 2e-5 * float(x_new.abs().max())
+    xn = torch.empty(M, D, dtype=dtype, device=DEV)
+    m0 = modd[:1].expand(B, -1)
+    ops.layernorm_modulate(xd, m0[:, D:2 * D], m0[:, 2 * D:], n, xn, EPS)
+    return ref, xn
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,n", [(2, 2048), (2, 300)])
+def test_fold_consumer_to_q(ops, dtype, B, n):
+    """The to_q form: one ROWS segment, scale0, the loader-wave 128 x 144 kernel."""
+    from topia_xl_amd._lib import HEADS_ROWS
+    if not _fold_kernels_selectable(ops):
+        pytest.skip("a kernel-selection switch removes the loader-wave kernel")
+    D, H, dh = 1152, 16, 72
+    Wc = synth.tensor(31, "Wq", (D, D), D ** -0.5).to(dtype)
+    bq = synth.tensor(31, "bq", (D,), 0.3).to(dtype)
+    s0 = dh ** -0.5
+    Q = ops.alloc_heads(B, H, n, dh, HEADS_ROWS, dtype, DEV, 128)
+    names = []
+
+    def consumer(a16, part, u, v, c):
+        ops.linear_heads_fold(a16, Wc.to(DEV), n, H, dh, [HEADS_ROWS], [Q], Q.shape[2], part, u, v, c, EPS, scale0=s0)
+        names.append(_last_kernel(ops))
+    ref, xn = _chain(ops, dtype, B, n, Wc, bq, 31, consumer)
+    want = (s0 * ref.to(dtype).float()).to(dtype).view(B, n, H, dh)
+    err = rel_l2(unpack_rows(Q, n, dh), want)
+    Q2 = ops.alloc_heads(B, H, n, dh, HEADS_ROWS, dtype, DEV, 128)
+    ops.linear_heads(xn, Wc.to(DEV), bq.to(DEV), n, H, dh, [HEADS_ROWS], [Q2], Q2.shape[2], scale0=s0)
+    err_unfolded = rel_l2(unpack_rows(Q2, n, dh), want)
+    print(f"to_q {dtype} B={B} n={n}: folded {err:.2e}, unfolded {err_unfolded:.2e}")
+    assert err < 2 * TOL[dtype] and err < 1.5 * err_unfolded + 1e-4
+    if _default_dispatch():
+        assert names[0].startswith("gemm144l_dma_kernel<") and names[0].endswith(", 7>")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fold_consumer_qkv(ops, dtype):
+    """The qkv form at the configs[1] shape (T = 4096): ROWS / KROWS / V^T segments on the 256 x 288 tile."""
+    from topia_xl_amd._lib import HEADS_KROWS, HEADS_ROWS, HEADS_VT
+    if not _fold_kernels_selectable(ops):
+        pytest.skip("a kernel-selection switch removes the 256 x 288 heads tile")
+    B, n, D, H, dh = 2, 2048, 1152, 16, 72
+    Wc = synth.tensor(32, "Wqkv", (3 * D, D), D ** -0.5).to(dtype)
+    bc = synth.tensor(32, "bqkv", (3 * D,), 0.3).to(dtype)
+    bufs = [ops.alloc_heads(B, H, n, dh, k, dtype, DEV, 128) for k in (HEADS_ROWS, HEADS_KROWS, HEADS_VT)]
+    names = []
+
+    def consumer(a16, part, u, v, c):
+        ops.linear_heads_fold(a16, Wc.to(DEV), n, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT], bufs, bufs[0].shape[2], part, u, v, c, EPS)
+        names.append(_last_kernel(ops))
+    ref, xn = _chain(ops, dtype, B, n, Wc, bc, 32, consumer)
+    want = ref.to(dtype).view(B, n, 3, H, dh)
+    got = [unpack_rows(bufs[0], n, dh), unpack_rows(bufs[1], n, dh), unpack_vt(bufs[2], n, dh)]
+    ref_bufs = [ops.alloc_heads(B, H, n, dh, k, dtype, DEV, 128) for k in (HEADS_ROWS, HEADS_KROWS, HEADS_VT)]
+    ops.linear_heads(xn, Wc.to(DEV), bc.to(DEV), n, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT], ref_bufs, ref_bufs[0].shape[2])
+    unf = [unpack_rows(ref_bufs[0], n, dh), unpack_rows(ref_bufs[1], n, dh), unpack_vt(ref_bufs[2], n, dh)]
+    for s in range(3):
+        err, err_u = rel_l2(got[s], want[:, :, s]), rel_l2(unf[s], want[:, :, s])
+        print(f"qkv {dtype} segment {s}: folded {err:.2e}, unfolded {err_u:.2e}")
+        assert err < 2 * TOL[dtype] and err < 1.5 * err_u + 1e-4
+    # the operand-level mask / denominator markers of the layouts survive (include/primx_hip.h)
+    assert float(bufs[2][:, :, dh].float().sum()) == B * H * n
+    if _default_dispatch():
+        assert names[0].startswith("gemm288q_dma_kernel<") and names[0].endswith(", 7>")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,n,kernel", [(2, 2048, "gemm288p_dma_kernel"), (2, 1950, "gemm288p_dma_kernel"), (1, 1024, "gemm144l_dma_kernel"),
+                                        (1, 333, "gemm144l_dma_kernel")])
+def test_fold_consumer_fc1(ops, dtype, B, n, kernel):
+    """The fc1 form: GELU(tanh) behind the fold, on the two-pass 256 x 288 kernel (T = 4096: 256 workgroups) and on the loader-wave
+    128 x 144 kernel (smaller launches); ragged last tiles."""
+    from topia_xl_amd._lib import ACT_GELU_TANH
+    D, Hm = 1152, 4608
+    Wc = synth.tensor(33, "Wfc1", (Hm, D), D ** -0.5).to(dtype)
+    bc = synth.tensor(33, "bfc1", (Hm,), 0.3).to(dtype)
+    out = torch.empty(B * n, Hm, dtype=dtype, device=DEV)
+    names = []
+
+    def consumer(a16, part, u, v, c):
+        ops.linear_fold(a16, Wc.to(DEV), out, part, u, v, c, EPS, act=ACT_GELU_TANH)
+        names.append(_last_kernel(ops))
+    ref, xn = _chain(ops, dtype, B, n, Wc, bc, 33, consumer)
+    want = torch.nn.functional.gelu(ref.to(dtype).double(), approximate="tanh")
+    unf = ops.linear(xn, Wc.to(DEV), bc.to(DEV), act=ACT_GELU_TANH)
+    err, err_u = rel_l2(out, want), rel_l2(unf, want)
+    print(f"fc1 {dtype} B={B} n={n}: folded {err:.2e}, unfolded {err_u:.2e}  ({names[0]})")
+    assert err < 2 * TOL[dtype] and err < 1.5 * err_u + 1e-4
+    if _default_dispatch():
+        assert names[0].startswith(kernel), names
+
+
+def test_fold_large_row_mean_is_what_the_centre_is_for(ops):
+    """Rows whose mean is 20 x their spread: with the centre at the previous site's mean (within a tenth of the spread of the
+    true one) the folded result keeps the unfolded path's accuracy - without a centre it would lose a factor ~10
+    (tools/ln_fold_study.py)."""
+    from topia_xl_amd._lib import ACT_NONE
+    dtype, B, n, D = torch.float16, 2, 512, 1152
+    Wc = synth.tensor(34, "W", (D, D), D ** -0.5).to(dtype)
+    out = torch.empty(B * n, D, dtype=dtype, device=DEV)
+
+    def consumer(a16, part, u, v, c):
+        ops.linear_fold(a16, Wc.to(DEV), out, part, u, v, c, EPS, act=ACT_NONE)
+    ref, xn = _chain(ops, dtype, B, n, Wc, None, 34, consumer, mean_ratio=20.0)
+    unf = ops.linear(xn, Wc.to(DEV), None)
+    err, err_u = rel_l2(out, ref), rel_l2(unf, ref)
+    print(f"row mean = 20 sigma: folded {err:.2e}, unfolded {err_u:.2e}")
+    assert err < 1.5 * err_u + 1e-4
+
+
+def test_fold_shape_errors(ops):
+    """Shapes outside the fold kernels are errors, not silent fall-backs."""
+    from topia_xl_amd._lib import PrimxError
+    dtype = torch.float16
+    A = torch.zeros(256, 1152, dtype=dtype, device=DEV)
+    W = torch.zeros(1280, 1152, dtype=dtype, device=DEV)          # N % 144 != 0
+    out = torch.zeros(256, 1280, dtype=dtype, device=DEV)
+    part = torch.zeros(256, 8, 2, device=DEV)
+    c = torch.zeros(256, device=DEV)
+    u = torch.zeros(1280, device=DEV)
+    with pytest.raises(PrimxError):
+        ops.linear_fold(A, W, out, part, u, u, c, EPS)
+    assert not ops.fold_supported(384, 6) and ops.fold_supported(1152, 16)
+    assert ops.fold_shapes_ok(4096, 2048, 1152, 16) == _default_dispatch() or not _default_dispatch()
+    assert not ops.fold_shapes_ok(2048, 2048, 1152, 16)
+
+
+def _fold_model(pkg, depth, seed):
+    cfg = dict(in_channels=68, condition_channels=768, hidden_size=1152, depth=depth)
+    sd = synth.dit_state_dict(seed, **cfg)
+    m = pkg.DiT(seq_length=2048, num_heads=16, attn_proj_bias=True, cond_drop_prob=0.1, **cfg).eval()
+    m.load_state_dict(sd)
+    m.to(DEV)
+    return sd, m
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_dit_with_the_fold_against_the_unfolded_path_and_the_oracle(ops, dtype, monkeypatch):
+    """Three full-width blocks at the configs[1] shape (N_prim = 2048, CFG -> 4096 token rows), a planned 4-step DDIM loop: every
+    step's sample with `fold_ln` within 2e-3 (fp16) of the unfolded loop; one planned forward against the fp32 oracle with the
+    error of the unfolded path next to it; the launch list really changes (no LayerNorm launches between the first and the last,
+    the fold kernels in their place); unplanned calls are untouched."""
+    import topia_xl_amd as pkg
+    sd, m = _fold_model(pkg, 3, 81)
+    x, y = synth.tensor(81, "x", (1, 2048, 68)), synth.tensor(81, "y", (1, 1370, 768))
+    d = pkg.create_diffusion("ddim4", noise_schedule="squaredcos_cap_v2", parameterization="v")
+    kw = dict(y=y.to(DEV), cfg_scale=6.0, precision_dtype=dtype, enable_amp=True)
+
+    def loop():
+        return [o["sample"].clone() for o in d.ddim_sample_loop_progressive(m.forward_with_cfg, tuple(x.shape), noise=x.to(DEV),
+                                                                            clip_denoised=False, model_kwargs=kw)]
+    m.fold_ln = False
+    base = loop()
+    m.fold_ln = True
+    tags, ln_calls = [], []
+    real_ln = ops.layernorm_modulate
+    monkeypatch.setattr(ops, "layernorm_modulate", lambda *a, **k: (ln_calls.append(1), real_ln(*a, **k))[1])
+    ops.PROFILE = tags       # (with per-launch timing on, every LayerNorm launch is issued from Python: countable)
+    try:
+        folded = loop()
+    finally:
+        ops.PROFILE = None
+        monkeypatch.setattr(ops, "layernorm_modulate", real_ln)
+    tol = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
+    for i, (a, b) in enumerate(zip(folded, base)):
+        e = rel_l2(a, b)
+        print(f"{dtype} step {i}: folded vs unfolded sample {e:.2e}")
+        assert e < tol
+    names = [tg[0] for tg in tags]
+    if _default_dispatch() and os.environ.get("PRIMX_DIT_FOLD") != "0" and os.environ.get("PRIMX_DIT_FUSE_LN") != "0" and not os.environ.get("PRIMX_CFG_STREAMS") and os.environ.get("PRIMX_WPREFETCH", "2") != "1":
+        assert len(ln_calls) == 2 * 4, len(ln_calls)                       # the first LayerNorm and the final layer's, per forward
+        assert sum(1 for nm in names if ", 6> " in nm) == 4 * (3 * 3 - 1), names   # producers: every gated add but the last
+        assert sum(1 for nm in names if ", 7> " in nm) == 4 * (2 * 3 - 1)          # to_q (blocks 1, 2) + qkv
+        assert sum(1 for nm in names if nm.startswith("gemm288p_dma_kernel") and "true" in nm) == 4 * 3
+    # one planned forward against the fp32 oracle
+    t = torch.tensor([520])
+    ref32 = dit_ref.dit_forward_with_cfg(sd, x, t, y, 16, 6.0, None)
+    errs = {}
+    for fold in (False, True):
+        m.fold_ln = fold
+        m.plan_timesteps(t.to(DEV))
+        m.select_planned_timestep(0)
+        errs[fold] = rel_l2(m.forward_with_cfg(x.to(DEV), t.to(DEV), y.to(DEV), 6.0, dtype, True), ref32)
+        m.clear_timestep_plan()
+    print(f"{dtype} forward_with_cfg vs fp32 oracle: unfolded {errs[False]:.3e}, folded {errs[True]:.3e}")
+    assert errs[True] < 1.25 * errs[False] + 1e-4
+    # an unplanned call never folds: bit-identical with the flag on and off
+    m.fold_ln = True
+    a = m.forward_with_cfg(x.to(DEV), t.to(DEV), y.to(DEV), 6.0, dtype, True)
+    m.fold_ln = False
+    assert torch.equal(a, m.forward_with_cfg(x.to(DEV), t.to(DEV), y.to(DEV), 6.0, dtype, True))
