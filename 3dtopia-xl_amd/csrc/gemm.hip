@@ -1487,7 +1487,8 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
     // layouts, transposed [288][272] for PRIMX_HEADS_VT); the strides put the 16 fragment rows of a wave 8 banks apart
     constexpr int RS_ROWS = BN + 16, RS_VT = BM + 16;
     constexpr bool HEADS = EPI == EPI_HEADS || EPI == EPI_HEADS_FOLD;
-    constexpr bool FOLD_C = EPI == EPI_HEADS_FOLD;                 // consumer of a folded LayerNorm site (see fold_stats_load)
+    constexpr bool FOLD_C = EPI == EPI_HEADS_FOLD || EPI == EPI_LINEAR_FOLD;   // consumer of a folded LayerNorm site (see fold_stats_load)
+    constexpr bool FOLD_P = EPI == EPI_GATE_RESIDUAL_FOLD;         // producer
     constexpr int STG = HEADS ? ((BM * RS_ROWS > BN * RS_VT) ? BM * RS_ROWS : BN * RS_VT) : 0;
     constexpr int LDS_HALVES = (NST * STAGE > STG) ? NST * STAGE : STG;
     constexpr int STAT_HALVES = FOLD_C ? BM * 4 + 2 * BN * 2 : 0;  // behind the staging area: (mu', rho) of the tile's rows, u and v of its columns
@@ -1779,7 +1780,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         bpre[j] = V4e{};
-        if (p.bias && EPI != EPI_CONVT) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + nb + j * 16);
+        if (p.bias && EPI != EPI_CONVT && EPI != EPI_LINEAR_FOLD) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + nb + j * 16);
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -1790,7 +1791,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
         const bool ok = m < pl_M;
 #endif
         const int mc = ok ? m : pl_M - 1;
-        if (EPI == EPI_GATE_RESIDUAL) {
+        if (EPI == EPI_GATE_RESIDUAL || FOLD_P) {
             const S* grow = p.gate + (int64_t)(mc / p.rows_per_batch) * p.gate_stride + nb;
             float* xrow = p.x + (int64_t)mc * pl_N + nb;
             V4e gv[NI];
@@ -1800,6 +1801,50 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
                 gv[j] = *reinterpret_cast<const V4e*>(grow + j * 16);
                 xv[j] = *reinterpret_cast<const f32x4*>(xrow + j * 16);
             }
+            if constexpr (FOLD_P) {
+                // the producer of the LayerNorm site behind this GEMM (see fold_stats_load): a lane owns 36 of its row's columns in
+                // this wave's 144-column half; the four lanes of a row meet by shuffle, so the half IS one 144-column partial sum
+                const float cr = p.fold_c[mc];
+                const S* srow = p.ln_scale + (int64_t)(mc / p.rows_per_batch) * p.ln_mod_stride + nb;
+                S* arow = p.ln_out + (int64_t)mc * pl_N + n0 + wn * 144;
+                float s1 = 0.f, s2 = 0.f;
+                auto unit = [&](int j) -> V4e {            // residual update of four columns (stored), their operand values (returned)
+                    const V4e sv = *reinterpret_cast<const V4e*>(srow + j * 16);
+                    V4e o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        xv[j][r] += rnd16<DT>((float)gv[j][r] * rnd16<DT>(acc[i][j][r] + (p.bias ? (float)bpre[j][r] : 0.f)));
+                        const float d = xv[j][r] - cr;
+                        s1 += d;
+                        s2 = __builtin_fmaf(d, d, s2);
+                        o[r] = (S)(d * rnd16<DT>(1.0f + (float)sv[r]));
+                    }
+                    if (ok) out_store(reinterpret_cast<f32x4*>(xrow + j * 16), xv[j]);
+                    return o;
+                };
+                // 16-bit operand: 16-byte stores - the lane groups of a row trade halves of neighbouring tiles (see EPI_LINEAR below);
+                // 8-byte stores of 32-byte row pieces left the batch-8 step where it was (61.1 vs 61.3 ms unfolded)
+                typedef unsigned int u32;
+#pragma unroll
+                for (int j = 0; j + 1 < NI; j += 2) {
+                    const u32x2 a = __builtin_bit_cast(u32x2, unit(j));
+                    const u32x2 b = __builtin_bit_cast(u32x2, unit(j + 1));
+                    const auto t0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                    const auto t1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                    const u32x4 o = {(u32)t0[0], (u32)t1[0], (u32)t0[1], (u32)t1[1]};
+                    if (ok) out_store(reinterpret_cast<u32x4*>(arow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
+                }
+                {
+                    const V4e o = unit(NI - 1);
+                    if (ok) out_store(reinterpret_cast<V4e*>(arow + (NI - 1) * 16 + 4 * lg), o);
+                }
+                s1 += __shfl_xor(s1, 16);                 // lanes lr + 16 lg: (lg0 + lg1) + (lg2 + lg3), the same in all four
+                s2 += __shfl_xor(s2, 16);
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (ok && lg == 0)
+                    *reinterpret_cast<f32x2*>(p.fold_part + ((int64_t)m * (pl_N / 144) + ni_t * 2 + wn) * 2) = f32x2{s1, s2};
+            } else {
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
 #pragma unroll
@@ -1807,6 +1852,28 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
                     xv[j][r] += rnd16<DT>((float)gv[j][r] * rnd16<DT>(acc[i][j][r] + (p.bias ? (float)bpre[j][r] : 0.f)));
                 if (ok) out_store(reinterpret_cast<f32x4*>(xrow + j * 16), xv[j]);
             }
+            }
+        } else if (EPI == EPI_LINEAR_FOLD) {
+            // (the epilogue of gemm288p_dma_kernel<., true>: statistics and u / v from LDS, 16-byte stores by permlane swap)
+            typedef unsigned int u32;
+            S* orow = p.out + (int64_t)mc * pl_N + n0 + wn * 144;
+            const f32x2 fst = fstat[wm * 64 + i * 16 + lr];
+            const float* up = fu + wn * 144 + 4 * lg;
+            const float* vp = fu + BN + wn * 144 + 4 * lg;
+            auto out4 = [&](int j) -> V4e {
+                return fold_out4<DT>(p, fold_apply(acc[i][j], fst, *reinterpret_cast<const f32x4*>(up + j * 16),
+                                                   *reinterpret_cast<const f32x4*>(vp + j * 16)));
+            };
+#pragma unroll
+            for (int j = 0; j + 1 < NI; j += 2) {
+                const u32x2 a = __builtin_bit_cast(u32x2, out4(j));
+                const u32x2 b = __builtin_bit_cast(u32x2, out4(j + 1));
+                const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
+                if (ok) out_store(reinterpret_cast<u32x4*>(orow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
+            }
+            if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), out4(NI - 1));
         } else if (EPI == EPI_LINEAR) {
             // 16-bit outputs.  Stored straight from the accumulator layout a lane writes 8 bytes and an instruction touches 16 rows
             // x 32 bytes; the store path of a CU then needs ~21k cycles for the tile's 147 KB (tools/probe/write_burst.hip: "fc1
@@ -2203,13 +2270,15 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     auto go = [&](const GemmArgs<DT>& x) {
         // the LayerNorm-fold epilogues exist in exactly one kernel per tile shape (launch_fold checked the shape)
         if constexpr (FOLD_EPI) {
-            if constexpr (BIG && EPI == EPI_LINEAR_FOLD) {
-                PRIMX_NOTE_KERNEL("gemm288p_dma_kernel<%d, true>", DT);
-                hipLaunchKernelGGL((gemm288p_dma_kernel<DT, true>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
-            } else if constexpr (BIG && EPI == EPI_HEADS_FOLD) {
+            if (BIG && EPI == EPI_LINEAR_FOLD && g_two_pass && (int)grid.x <= 256) {   // (the rule of the unfolded Linear below)
+                if constexpr (BIG && EPI == EPI_LINEAR_FOLD) {
+                    PRIMX_NOTE_KERNEL("gemm288p_dma_kernel<%d, true>", DT);
+                    hipLaunchKernelGGL((gemm288p_dma_kernel<DT, true>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
+                }
+            } else if constexpr (BIG) {
                 PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d>", DT, EPI);
                 hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, PRIMX_GEMM_PASS(x));
-            } else if constexpr (!BIG) {
+            } else {
                 PRIMX_NOTE_KERNEL("gemm144l_dma_kernel<%d, %d>", DT, EPI);
                 hipLaunchKernelGGL((gemm144l_dma_kernel<DT, EPI>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
             }
@@ -2219,7 +2288,7 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
         // drain under the second pass (the step 8.97 -> 8.92 ms same box); with several rounds per CU the next workgroup already
         // overlaps the previous one's drain and the one-pass tile's fewer bytes per FLOP win (T = 32768: 428 vs 451 us)
         if (BIG && EPI == EPI_LINEAR && g_two_pass && (int)grid.x <= 256) {
-            PRIMX_NOTE_KERNEL("gemm288p_dma_kernel<%d>", DT);
+            PRIMX_NOTE_KERNEL("gemm288p_dma_kernel<%d, false>", DT);
             hipLaunchKernelGGL((gemm288p_dma_kernel<DT>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
         } else if (BIG) {
             PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d>", DT, EPI);
@@ -2352,7 +2421,9 @@ int launch_fold(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
         PRIMX_REQUIRE(a.N / 144 <= 8, "%s: at most 8 column tiles (N <= 1152), the consumers read 8 partial sums per row (N=%d)", name, a.N);
         PRIMX_REQUIRE((((uintptr_t)a.ln_scale | (uintptr_t)a.ln_out | (uintptr_t)a.fold_part) & 7) == 0 && a.ln_mod_stride % 4 == 0,
                       "%s: the scale vectors, the operand and the partial sums must be 8-byte aligned", name);
-        launch144_dma<DT, EPI>(a, mt, st);
+        // the 256 x 288 tile where the unfolded gate-residual GEMM takes it (launch<>: a large batch)
+        if (!g_no_big && a.N % 288 == 0 && ((a.M + 255) / 256) * (a.N / 288) >= g_big_min) launch144_dma<DT, EPI, 1>(a, mt, st);
+        else launch144_dma<DT, EPI>(a, mt, st);
     } else {
         PRIMX_REQUIRE(a.K % 144 == 0 && a.fold_parts == a.K / 144 && a.fold_parts <= 8,
                       "%s: K must be the producer's N: a multiple of 144, at most 1152 (K=%d)", name, a.K);
@@ -2373,7 +2444,7 @@ int launch_fold(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
             }
         } else {
             const int wgs = ((a.M + 255) / 256) * (a.N / 288);
-            if (!g_no_big && g_two_pass && a.N % 288 == 0 && wgs >= g_big_min && wgs <= 256) launch144_dma<DT, EPI, 1>(a, mt, st);
+            if (!g_no_big && a.N % 288 == 0 && wgs >= g_big_min) launch144_dma<DT, EPI, 1>(a, mt, st);   // two-pass or one-pass: go()
             else launch144_dma<DT, EPI>(a, mt, st);
         }
     }

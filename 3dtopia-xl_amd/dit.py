@@ -577,11 +577,8 @@ class DiT(nn.Module):
             plan["mod"] = {key: tab}
         return tab
 
-    _FOLD_MAX_ROWS = 4096   # tokens x batch entries up to which the fold is taken (beyond, the big-tile kernels serve the producers)
-
     def _fold_ok(self, T: int, N: int) -> bool:
-        return bool(self.fold_ln) and self.depth > 0 and T <= self._FOLD_MAX_ROWS and ops.fold_shapes_ok(
-            T, N, self.hidden_size, self.num_heads)
+        return bool(self.fold_ln) and self.depth > 0 and ops.fold_shapes_ok(T, N, self.hidden_size, self.num_heads)
 
     def _fold_tables(self, plan: Dict, dt: torch.dtype, pk: Dict) -> Dict:
         """The fold's per-timestep vectors of a planned loop: for every block and site (to_q, qkv, fc1) u = cast16(1 + scale) W^T

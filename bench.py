@@ -396,7 +396,8 @@ def main() -> None:
     # The same K steps with the LayerNorm fold off (DiT.fold_ln = False: 85 LayerNorm launches per forward instead of 2): what the
     # fold saves, for the record (it changes rounding points, not accuracy: tests/test_hip_fold.py, tests/test_hip_fullconfig.py).
     unfolded = None
-    if args.config == "ddim" and rank == 0 and world == 1 and getattr(model, "fold_ln", False) and model._fold_ok(2 * B * N, N):
+    if (args.config == "ddim" and rank == 0 and world == 1 and not args.no_side_legs and getattr(model, "fold_ln", False)
+            and model._fold_ok(2 * B * N, N)):
         model.fold_ln = False
         run_steps(args.warmup)
         el, _ = timed_repeats(run_steps, args.steps, max(1, args.repeats), 1, dist, dev)

@@ -85,10 +85,11 @@ def _site(seed, B, n, D, K, dtype, mean_ratio=0.3):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("B,n,K", [(2, 2048, 1152), (2, 2048, 4608), (2, 487, 192), (1, 130, 64)])
+@pytest.mark.parametrize("B,n,K", [(2, 2048, 1152), (2, 2048, 4608), (2, 487, 192), (1, 130, 64), (8, 2048, 192), (7, 2100, 64)])
 def test_fold_producer(ops, dtype, B, n, K):
     """x: the same bits as the plain gate-residual GEMM.  a16: EXACTLY cast16((x_new - c) cast16(1 + scale)) of the stored rows.
-    Partial sums: the 144-column sums of (x_new - c) and its square (fp32, fixed order) against float64."""
+    Partial sums: the 144-column sums of (x_new - c) and its square (fp32, fixed order) against float64.  The last two shapes are
+    a large batch (>= 14336 rows): the 256 x 288 tile, whose register epilogue forms the partial sums by lane shuffles."""
     D = 1152
     M = B * n
     A, W, b, mod, x, c = _site(21, B, n, D, K, dtype)
@@ -101,7 +102,8 @@ def test_fold_producer(ops, dtype, B, n, K):
     part = torch.full((M, D // 144, 2), float("nan"), device=DEV)
     ops.linear_gate_residual_fold(A.to(DEV), W.to(DEV), b.to(DEV), modd[:, :D], x_fold, n, modd[:, D:2 * D], c.to(DEV), a16, part)
     if _default_dispatch():
-        assert _last_kernel(ops).startswith("gemm144l_dma_kernel<") and _last_kernel(ops).endswith(", 6>"), _last_kernel(ops)
+        want_kernel = "gemm288q_dma_kernel<" if M >= 14336 else "gemm144l_dma_kernel<"
+        assert _last_kernel(ops).startswith(want_kernel) and _last_kernel(ops).endswith(", 6>"), _last_kernel(ops)
         assert torch.equal(x_fold, x_plain)
     else:
         assert rel_l2(x_fold, x_plain) < 1e-5
@@ -154,9 +156,9 @@ def _chain(ops, dtype, B, n, Wc, bc, seed, consumer, mean_ratio=0.3):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("B,n", [(2, 2048), (2, 300)])
+@pytest.mark.parametrize("B,n", [(2, 2048), (2, 300), (5, 2048)])
 def test_fold_consumer_to_q(ops, dtype, B, n):
-    """The to_q form: one ROWS segment, scale0, the loader-wave 128 x 144 kernel."""
+    """The to_q form: one ROWS segment, scale0, the loader-wave 128 x 144 kernel - the 256 x 288 tile from 10240 rows on."""
     from topia_xl_amd._lib import HEADS_ROWS
     if not _fold_kernels_selectable(ops):
         pytest.skip("a kernel-selection switch removes the loader-wave kernel")
@@ -179,7 +181,7 @@ def test_fold_consumer_to_q(ops, dtype, B, n):
     print(f"to_q {dtype} B={B} n={n}: folded {err:.2e}, unfolded {err_unfolded:.2e}")
     assert err < 2 * TOL[dtype] and err < 1.5 * err_unfolded + 1e-4
     if _default_dispatch():
-        assert names[0].startswith("gemm144l_dma_kernel<") and names[0].endswith(", 7>")
+        assert names[0].startswith("gemm288q_dma_kernel<" if B * n >= 10240 else "gemm144l_dma_kernel<") and names[0].endswith(", 7>"), names
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -215,10 +217,10 @@ def test_fold_consumer_qkv(ops, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("B,n,kernel", [(2, 2048, "gemm288p_dma_kernel"), (2, 1950, "gemm288p_dma_kernel"), (1, 1024, "gemm144l_dma_kernel"),
-                                        (1, 333, "gemm144l_dma_kernel")])
+                                        (1, 333, "gemm144l_dma_kernel"), (4, 2048, "gemm288q_dma_kernel"), (3, 1500, "gemm288q_dma_kernel")])
 def test_fold_consumer_fc1(ops, dtype, B, n, kernel):
-    """The fc1 form: GELU(tanh) behind the fold, on the two-pass 256 x 288 kernel (T = 4096: 256 workgroups) and on the loader-wave
-    128 x 144 kernel (smaller launches); ragged last tiles."""
+    """The fc1 form: GELU(tanh) behind the fold, on the two-pass 256 x 288 kernel (T = 4096: 256 workgroups), on the loader-wave
+    128 x 144 kernel (smaller launches) and on the one-pass 256 x 288 kernel (more than 256 workgroups); ragged last tiles."""
     from topia_xl_amd._lib import ACT_GELU_TANH
     D, Hm = 1152, 4608
     Wc = synth.tensor(33, "Wfc1", (Hm, D), D ** -0.5).to(dtype)

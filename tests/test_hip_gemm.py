@@ -242,7 +242,7 @@ def test_reported_kernel_names_of_the_headline_shapes(ops):
     ops.linear_gate_residual(A, W[:D].contiguous(), b[:D], gate, x, 2048)
     assert name() == "gemm144l_dma_kernel<1, 1>"                                           # fc2
     ops.linear(A[:, :D].contiguous(), W[:, :D].contiguous(), b)
-    assert name() == "gemm288p_dma_kernel<1>"                                              # fc1: 256 workgroups of 256 x 288, two passes
+    assert name() == "gemm288p_dma_kernel<1, false>"                                              # fc1: 256 workgroups of 256 x 288, two passes
     ops.linear(A[:, :D].contiguous(), W[:136, :D].contiguous(), b[:136])
     assert name().startswith("gemm_kernel<1, 0, 32, 2, 2, 2, 2, 0>")                           # final layer
     ops.linear(A[:2, :D].contiguous(), W[:, :D].contiguous(), b)
@@ -262,7 +262,7 @@ def test_reported_kernel_names_of_the_headline_shapes(ops):
         tag = ops.PROFILE[0][0]
     finally:
         ops.PROFILE = None
-    assert tag == "gemm288p_dma_kernel<1> 4096x4608x1152", tag
+    assert tag == "gemm288p_dma_kernel<1, false> 4096x4608x1152", tag
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

@@ -15,7 +15,13 @@ CYCLES = {  # kernel name prefix -> shape tags in launch order within one block 
     "gemm144l_dma_kernel<1, 1>": ["4096x1152x1152", "4096x1152x1152", "4096x1152x4608"],
     "gemm144l_dma_kernel<1, 2>": ["4096x1152x1152"],
     "gemm288q_dma_kernel<1, 0>": ["4096x4608x1152"],
-    "gemm288p_dma_kernel<1>": ["4096x4608x1152"],
+    "gemm288p_dma_kernel<1, false>": ["4096x4608x1152"],
+    # with the LayerNorm fold (DiT.fold_ln, the default in planned loops): producers <1, 6> = cproj, proj, fc2 of every block but the
+    # last one's fc2, which stays <1, 1>; consumers <1, 7> (to_q from block 1 on; qkv on the 256 x 288 tile), fc1 on <1, true>
+    "gemm144l_dma_kernel<1, 6>": ["4096x1152x1152", "4096x1152x1152", "4096x1152x4608"] * 27 + ["4096x1152x1152"] * 2,
+    "gemm144l_dma_kernel<1, 7>": ["4096x1152x1152"],
+    "gemm288q_dma_kernel<1, 7>": ["4096x3456x1152"],
+    "gemm288p_dma_kernel<1, true>": ["4096x4608x1152"],
     "attn_kernel<1, 5, 3, 0, 0>": ["32x2048x1370x72", "32x2048x2048x72"],
     # --config decode (2048 primitives): one shape per kernel
     "conv3_s4c256_kernel<1, 0>": ["256->256 @4^3 x2048"],
@@ -31,10 +37,15 @@ def short(name):
     return name.split("(")[0]
 
 
+FOLDED = False   # set by load(): the trace contains fold kernels
+
+
 def load(path, counter):
+    global FOLDED
     acc = collections.defaultdict(list)
     seen = collections.Counter()
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    FOLDED = any(short(r["Kernel_Name"]).startswith("gemm144l_dma_kernel<1, 6>") for r in rows)
     rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
     for r in rows:
         k = short(r["Kernel_Name"])
@@ -42,6 +53,8 @@ def load(path, counter):
         if k.startswith("gemm288q_dma_kernel<1, 2>"):   # qkv per block + ONE batched K/V projection per forward: split by grid
             tag = k + (" 1536x64512x768" if int(r.get("Grid_Size", 0)) > 512 * 400 else " 4096x3456x1152")
         elif cyc:
+            if k == "gemm144l_dma_kernel<1, 1>" and FOLDED:
+                cyc = ["4096x1152x4608"]                   # only the last block's fc2 is left on the plain gate-residual kernel
             tag = f"{k} {cyc[seen[k] % len(cyc)]}"
             seen[k] += 1
         else:
