@@ -589,11 +589,8 @@ class DiT(nn.Module):
         if ft is not None and ft["key"] == key:
             return ft
         tab = self._modulation_table(plan, dt, pk)
-        n, D, depth = tab.shape[0], self.hidden_size, self.depth
-        v = tab[:, :depth * 9 * D].view(n, depth, 3, 3, D)               # [timestep, block, site, (shift, scale, gate), D]
-        A = torch.empty(depth, 3, 2, n, D, dtype=dt, device=tab.device)
-        A[:, :, 0] = (1 + v[:, :, :, 1]).permute(1, 2, 0, 3)              # (1 + scale) is formed in the 16-bit type, as autocast does
-        A[:, :, 1] = v[:, :, :, 0].permute(1, 2, 0, 3)
+        n, D = tab.shape[0], self.hidden_size
+        A = self._fold_rows(tab, self.depth, D)
         # (3 x depth - 1 independent few-row GEMMs, 9 - 36 workgroups and ~20 us each: 0.07 ms per step of a 25-step loop.  Issued
         # round-robin on four side streams they overlap - and every LATER launch of the loop got slower: the step 8.83 vs 8.63 ms on
         # the same box, against 8.97 unfolded (profiles/r4_experiments.txt section 6).  They stay on the calling stream.)
@@ -610,6 +607,18 @@ class DiT(nn.Module):
             uv.append(row)
         ft = plan["fold"] = {"key": key, "uv": uv}
         return ft
+
+    @staticmethod
+    def _fold_rows(tab: torch.Tensor, depth: int, D: int) -> torch.Tensor:
+        """The A operands of the fold's u / v GEMMs from the loop's modulation table `tab` [n_timesteps, depth * 9 D (+ 2 D)] (16-bit;
+        per block: shift, scale, gate of the cross-attention, self-attention and MLP branch - dit_crossattn.py:54):
+        A[block, site, 0] = cast16(1 + scale) and A[block, site, 1] = shift of every timestep, [depth, 3, 2, n_timesteps, D]."""
+        n = tab.shape[0]
+        v = tab[:, :depth * 9 * D].view(n, depth, 3, 3, D)               # [timestep, block, site, (shift, scale, gate), D]
+        A = torch.empty(depth, 3, 2, n, D, dtype=tab.dtype, device=tab.device)
+        A[:, :, 0] = (1 + v[:, :, :, 1]).permute(1, 2, 0, 3)              # (1 + scale) is formed in the 16-bit type, as autocast does
+        A[:, :, 1] = v[:, :, :, 0].permute(1, 2, 0, 3)
+        return A
 
     def _forward16(self, x, t, y, dt, null_half: bool):
         """The 16-bit autocast path.  `null_half`: classifier-free guidance - the effective batch is [x; x] with the

@@ -240,3 +240,56 @@ def test_additive_pos_emb_variant_travels_on_the_packed_routes(pkg, tmp_path):
     assert torch.equal(c.packed(torch.float16)["_flat"].view(torch.int16), a.packed(torch.float16)["_flat"].view(torch.int16))
     with pytest.raises(RuntimeError, match="different model"):   # same hyper-parameters, other class: other parameter set
         pkg.DiT(cond_drop_prob=0.0, **cfg).load_packed(path)
+
+
+def test_layernorm_fold_host_logic(pkg, monkeypatch):
+    """The fold's host side without a device: (a) the A operands of its u / v GEMMs pick shift / scale of (block, site) out of the
+    loop's modulation table exactly as DiTBlock chunks its adaLN output (dit_crossattn.py:54: shift, scale, gate x cross-attention,
+    self-attention, MLP) and form (1 + scale) in the 16-bit type; (b) the shape rule that decides whether a forward folds follows
+    the kernel-selection switches; (c) the folded algebra itself - rho (cast16((x - c) m) W^T - (mu - c) u) + v - against the
+    reference's LayerNorm -> modulate -> Linear in float64, with the centre one gated branch away from the mean."""
+    from importlib import import_module
+    ops = import_module(pkg.__name__ + ".ops")
+    depth, D, n = 3, 16, 5
+    tab = synth.tensor(7, "fold.tab", (n, depth * 9 * D + 2 * D), 0.5).to(torch.float16)
+    A = pkg.DiT._fold_rows(tab, depth, D)
+    assert A.shape == (depth, 3, 2, n, D) and A.dtype == torch.float16
+    for i in range(depth):
+        for s in range(3):
+            shift = tab[:, (i * 9 + 3 * s) * D:(i * 9 + 3 * s + 1) * D]
+            scale = tab[:, (i * 9 + 3 * s + 1) * D:(i * 9 + 3 * s + 2) * D]
+            assert torch.equal(A[i, s, 1], shift)
+            assert torch.equal(A[i, s, 0], (1.0 + scale.float()).to(torch.float16))
+    # (b)
+    for var in ("PRIMX_GEMM_NOBIG", "PRIMX_GEMM_LOADER", "PRIMX_GEMM_BIGHEADS_MIN"):
+        monkeypatch.delenv(var, raising=False)
+    assert ops.fold_supported(1152, 16) and not ops.fold_supported(384, 6) and not ops.fold_supported(1152 * 2, 32)
+    assert ops.fold_shapes_ok(4096, 2048, 1152, 16) and ops.fold_shapes_ok(32768, 2048, 1152, 16)
+    assert not ops.fold_shapes_ok(2048, 2048, 1152, 16)          # qkv would not reach the 256 x 288 heads tile
+    assert not ops.fold_shapes_ok(4096 + 300, 2198, 1152, 16)    # token count per batch entry not a multiple of 256
+    monkeypatch.setenv("PRIMX_GEMM_NOBIG", "1")
+    assert not ops.fold_shapes_ok(4096, 2048, 1152, 16)
+    monkeypatch.delenv("PRIMX_GEMM_NOBIG")
+    monkeypatch.setenv("PRIMX_GEMM_BIGHEADS_MIN", "0")
+    assert not ops.fold_shapes_ok(4096, 2048, 1152, 16)
+    monkeypatch.delenv("PRIMX_GEMM_BIGHEADS_MIN")
+    # (c) float64 algebra with the kernel's rounding points (fp16)
+    r16 = lambda t: t.to(torch.float16).double()
+    M, Dm, O = 64, 1152, 96
+    x = (synth.tensor(8, "fold.x", (M, Dm)) * 2 + 0.8).double()
+    shift, scale = r16(synth.tensor(8, "fold.sh", (Dm,), 0.3)), r16(synth.tensor(8, "fold.sc", (Dm,), 0.3))
+    W, b = r16(synth.tensor(8, "fold.W", (O, Dm), Dm ** -0.5)), r16(synth.tensor(8, "fold.b", (O,), 0.2))
+    mu = x.mean(-1, keepdim=True)
+    rho = 1.0 / torch.sqrt(((x - mu) ** 2).mean(-1, keepdim=True) + 1e-6)
+    m = r16(1 + scale)
+    ref = ((x - mu) * rho * m + shift) @ W.t() + b
+    autocast = r16(r16((x - mu) * rho * m + shift) @ W.t() + b)
+    c = mu + 0.1 * x.std(-1, keepdim=True)                        # the centre: the mean one branch ago
+    d = x - c
+    part = torch.stack([d.view(M, 8, 144).sum(-1), (d * d).view(M, 8, 144).sum(-1)], -1).float().double()   # the producer's fp32 partials
+    mu_p = part[..., 0].sum(-1, keepdim=True) / Dm
+    rho_f = 1.0 / torch.sqrt(part[..., 1].sum(-1, keepdim=True) / Dm - mu_p ** 2 + 1e-6)
+    u, v = (m @ W.t()).float().double(), (shift @ W.t() + b).float().double()
+    folded = r16(rho_f * (r16(d * m) @ W.t() - mu_p * u) + v)
+    e_ref = lambda t: float((t - ref).norm() / ref.norm())
+    assert e_ref(folded) < 1.2 * e_ref(autocast) and e_ref(folded) < 6e-4
