@@ -1109,7 +1109,8 @@ template <int DT, int EPI>
 __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)) {
     PRIMX_GEMM_ARGS(DT);
     static_assert(EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_HEADS || EPI == EPI_GATE_RESIDUAL_LN ||
-                  EPI == EPI_GATE_RESIDUAL_FOLD || EPI == EPI_HEADS_FOLD || EPI == EPI_LINEAR_FOLD, "row-major epilogues only");
+                  EPI == EPI_GATE_RESIDUAL_FOLD || EPI == EPI_HEADS_FOLD || EPI == EPI_LINEAR_FOLD || EPI == EPI_F32OUT,
+                  "row-major epilogues only");
     constexpr bool GATE_RES = EPI == EPI_GATE_RESIDUAL || EPI == EPI_GATE_RESIDUAL_LN || EPI == EPI_GATE_RESIDUAL_FOLD;
     constexpr bool HEADS = EPI == EPI_HEADS || EPI == EPI_HEADS_FOLD;
     constexpr bool FOLD_P = EPI == EPI_GATE_RESIDUAL_FOLD;                          // producer of a folded LayerNorm site
@@ -1362,6 +1363,14 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
             }
         } else if constexpr (EPI == EPI_LINEAR) {
             epilogue_row4<DT, EPI>(p, m0 + row, n0 + 4 * c4, v0 + v1, bpre[i]);
+        } else if constexpr (EPI == EPI_F32OUT) {
+            // fp32 rows (p.x); the bias joins the rows from p.rows_per_batch on (epilogue_quad's EPI_F32OUT)
+            const V4e bv = bpre[i];
+            const bool wb = p.bias && m0 + row >= p.rows_per_batch;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = v0[j] + v1[j] + (wb ? (float)bv[j] : 0.f);
+            out_store(reinterpret_cast<f32x4*>(p.x + (int64_t)(m0 + row) * pl_N + n0 + 4 * c4), o);
         } else if constexpr (EPI == EPI_LINEAR_FOLD) {
             out_store(reinterpret_cast<V4e*>(p.out + (int64_t)(m0 + row) * pl_N + n0 + 4 * c4),
                       fold_out4<DT>(p, fold_apply(v0 + v1, fstat[row], *reinterpret_cast<const f32x4*>(fu + 4 * c4),
@@ -2670,9 +2679,19 @@ extern "C" int primx_linear_f32out(const void* A, const void* W, const void* bia
         a.A = (const S*)A; a.W = (const S*)W; a.bias = (const S*)bias;
         a.M = M; a.N = N; a.K = K;
         a.x = out; a.rows_per_batch = bias_from_row;
-        PRIMX_NOTE_KERNEL("gemm_kernel<%d, %d, 32, 2, 2, 2, 2, 0>", DT, EPI_F32OUT);
-        hipLaunchKernelGGL((gemm_kernel<DT, EPI_F32OUT, 32, 2, 2, 2, 2, 0>), dim3(((M + 127) / 128) * ((N + 127) / 128)), dim3(256), 0,
-                           (hipStream_t)stream, a);
+        // the loader-wave 128 x 144 kernel where the shape allows (N % 144 == 0, K % 64 == 0; PRIMX_F32OUT_TILE144=0: never) - the fold's
+        // u / v rows are 8 - 32 workgroups of 18 k-tiles, latency-bound on the register-staged generic kernel (~20 us each); same box,
+        // the configs[1] step: 8.453 - 8.471 -> 8.446 - 8.452 ms (tools/gpu/r4_uv144.sh)
+        static const bool tile144 = [] { const char* e = getenv("PRIMX_F32OUT_TILE144"); return !(e && e[0] == '0'); }();
+        if (tile144 && g_loader && N % 144 == 0 && K % BK == 0 && (((uintptr_t)out | (uintptr_t)bias) & 15) == 0) {
+            PRIMX_NOTE_KERNEL("gemm144l_dma_kernel<%d, %d>", DT, EPI_F32OUT);
+            hipLaunchKernelGGL((gemm144l_dma_kernel<DT, EPI_F32OUT>), dim3(((M + 127) / 128) * (N / 144)), dim3(640), 0,
+                               (hipStream_t)stream, PRIMX_GEMM_PASS(a));
+        } else {
+            PRIMX_NOTE_KERNEL("gemm_kernel<%d, %d, 32, 2, 2, 2, 2, 0>", DT, EPI_F32OUT);
+            hipLaunchKernelGGL((gemm_kernel<DT, EPI_F32OUT, 32, 2, 2, 2, 2, 0>), dim3(((M + 127) / 128) * ((N + 127) / 128)), dim3(256), 0,
+                               (hipStream_t)stream, a);
+        }
     });
     PRIMX_CHECK_LAUNCH("primx_linear_f32out");
     return PRIMX_OK;
