@@ -215,6 +215,10 @@ class GaussianDiffusion(DiffusionTables):
                                      model_kwargs=model_kwargs, eta=eta, coef=coef, tmap=tmap, planner=planner)
                 yield out
                 img = out["sample"]
+            # (a model that folded its LayerNorms in fp16 has its final sample checked for overflow once per loop: DiT.fold_overflow_check)
+            check = getattr(planner, "fold_overflow_check", None) if planner is not None else None
+            if callable(check):
+                check(img)
         finally:
             if planner is not None:
                 planner.clear_timestep_plan()

@@ -186,6 +186,13 @@ class DiT(nn.Module):
         # call - unplanned forwards included - takes the LayerNorm launches.
         self.fold_ln = os.environ.get("PRIMX_DIT_FOLD", "1") != "0"
         self._fold_ws: Dict = {}              # (device, rows) -> (center, part) workspaces of the fold
+        # Dynamic range (fp16 only): the folded operand cast16((x - c)(1 + scale)) is NOT normalised - a residual stream whose rows
+        # spread beyond the fp16 range (|x - c| (1 + scale) > 65504; the synthetic models stay below 1e2, a trained DiT is not known to
+        # come near) overflows there, where the LayerNorm output of the unfolded path cannot.  The sampling loop therefore checks its
+        # final sample once when folded fp16 forwards ran (`fold_overflow_check`: one reduction + one read-back per LOOP) and
+        # raises instead of returning NaNs; bf16 has the range of fp32 and is not checked.  (The cure, not built: scale the operand
+        # by the previous site's rho the way it is centred by the previous site's mean - DESIGN_LOG.md section 10.6.)
+        self._fold_fp16_used = False
         self._side: Dict = {}
         self._t_plan: Optional[Dict] = None   # plan_timesteps(): the coming calls' timesteps and their modulation table
 
@@ -608,6 +615,15 @@ class DiT(nn.Module):
         ft = plan["fold"] = {"key": key, "uv": uv}
         return ft
 
+    def fold_overflow_check(self, sample: torch.Tensor) -> None:
+        """Called by the sampling loop when it ends (diffusion/sampler.py): if forwards of this loop ran the LayerNorm fold in fp16,
+        a non-finite sample means the folded operand left the fp16 range (see `fold_ln` in __init__) - raise, do not return NaNs."""
+        used, self._fold_fp16_used = self._fold_fp16_used, False
+        if used and not bool(torch.isfinite(sample).all()):
+            raise FloatingPointError(
+                "non-finite sample after a sampling loop with the fp16 LayerNorm fold: the residual stream of this model leaves the "
+                "fp16 range once centred and scaled - run with PRIMX_DIT_FOLD=0 (model.fold_ln = False) or precision_dtype=bfloat16")
+
     @staticmethod
     def _fold_rows(tab: torch.Tensor, depth: int, D: int) -> torch.Tensor:
         """The A operands of the fold's u / v GEMMs from the loop's modulation table `tab` [n_timesteps, depth * 9 D (+ 2 D)] (16-bit;
@@ -720,6 +736,8 @@ class DiT(nn.Module):
         if (prow is not None and fuse and not collapse and not (self.cfg_streams and null_half and ops.PROFILE is None)
                 and self._fold_ok(T, N)):
             fold_uv = self._fold_tables(plan, dt, pk)["uv"]
+            if dt == torch.float16:
+                self._fold_fp16_used = True
             wk = (str(dev), T)
             if wk not in self._fold_ws:
                 self._fold_ws = {wk: ops.fold_workspace(T, D, dev)}

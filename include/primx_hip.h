@@ -173,7 +173,9 @@ int primx_ln_sync_timeouts(void);
  * per-column-tile partial sums of (x - c), (x - c)^2, and the Linear behind it (the CONSUMER: to_q, qkv, fc1) can finish mu, rho
  * from the partials and apply them with u, v in its epilogue - no LayerNorm launch, no second pass over the fp32 rows.  The
  * fold rounds (x - c) m where the reference rounds the normalised value: equal accuracy while |mu - c| stays below the row's
- * spread (tools/ln_fold_study.py), which is why c follows the row mean from site to site (the consumer moves it).  u, v depend
+ * spread (tools/ln_fold_study.py), which is why c follows the row mean from site to site (the consumer moves it).  Range: the folded
+ * operand carries the row's spread (the LayerNorm output does not), so with PRIMX_F16 the caller must know |x - c| (1 + scale) < 65504
+ * (the DiT driver checks the finished sample of every fp16 loop); PRIMX_BF16 has the range of fp32.  u, v depend
  * on the timestep only (primx_linear_f32out, once per planned sampling loop).  Shapes: N of the producer = K of the consumer =
  * a multiple of 144, at most 1152; everything else returns PRIMX_EINVAL and the caller keeps primx_layernorm_modulate. */
 
