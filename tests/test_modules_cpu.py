@@ -293,3 +293,19 @@ def test_layernorm_fold_host_logic(pkg, monkeypatch):
     folded = r16(rho_f * (r16(d * m) @ W.t() - mu_p * u) + v)
     e_ref = lambda t: float((t - ref).norm() / ref.norm())
     assert e_ref(folded) < 1.2 * e_ref(autocast) and e_ref(folded) < 6e-4
+
+
+def test_fold_overflow_check_raises_once_per_loop(pkg):
+    """The fp16 LayerNorm fold's operand is not normalised (DESIGN_LOG.md section 10.6): the sampling loop hands its final sample to
+    `DiT.fold_overflow_check`, which raises on a non-finite sample if - and only if - folded fp16 forwards ran since the last check."""
+    m = pkg.DiT(seq_length=64, in_channels=8, condition_channels=16, hidden_size=48, depth=1, num_heads=2).eval()
+    bad, good = torch.tensor([1.0, float("nan")]), torch.ones(4)
+    m.fold_overflow_check(bad)                       # nothing folded: nothing to answer for
+    m._fold_fp16_used = True
+    m.fold_overflow_check(good)
+    assert m._fold_fp16_used is False
+    m._fold_fp16_used = True
+    with pytest.raises(FloatingPointError, match="PRIMX_DIT_FOLD=0"):
+        m.fold_overflow_check(bad)
+    assert m._fold_fp16_used is False
+    m.fold_overflow_check(bad)
