@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PRIMX_LIB") or os.path.join(_HERE, "csrc", "libprimx_
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
 HEADS_ROWS, HEADS_VT, HEADS_KROWS = 0, 1, 2
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -41,11 +41,11 @@ SIGNATURES = {
     "primx_linear_gate_residual_ln": [_p, _p, _p, _p, _l, _p, _i, _i, _i, _i, _p, _p, _l, _p, _f, _p, _l, _i, _p, _l, _p],
     "primx_ln_sync_timeouts": [],
     "primx_linear_f32out": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
-    "primx_row_mean": [_p, _i, _i, _p, _p],
+    "primx_row_stats": [_p, _i, _i, _f, _p, _p],
     "primx_linear_gate_residual_fold": [_p, _p, _p, _p, _l, _p, _i, _i, _i, _i, _p, _l, _p, _p, _p, _i, _p, _l, _p],
-    "primx_linear_heads_fold": [_p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _f, _p, _p, _p, _p, _f, _i,
-                                _p, _l, _p],
-    "primx_linear_fold": [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p, _l, _p],
+    "primx_linear_heads_fold": [_p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _f, _p, _p, _p, _p, _p, _f,
+                                _i, _p, _l, _p],
+    "primx_linear_fold": [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _i, _p, _l, _p],
     "primx_linear_heads": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _i, _i, _f, _i, _p, _l, _p],
     "primx_attention": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "primx_attention_bcast": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _i, _i, _i, _p],
@@ -76,10 +76,12 @@ SIGNATURES = {
 _RESTYPES = {"primx_last_error": C.c_char_p, "primx_last_gemm_kernel": C.c_char_p}
 # an alternate build named by PRIMX_LIB (same-box A/B against another build) must speak the same ABI: version 21 changed the
 # argument lists of the GEMM / LayerNorm entry points (explicit prefetch ranges), so older libraries cannot be bound any more;
-# version 22 only ADDED the LayerNorm-fold entry points, so a version-21 build can stand in as long as nothing folds
-_OPTIONAL_IN_AB_BUILDS: set = {"primx_linear_f32out", "primx_row_mean", "primx_linear_gate_residual_fold", "primx_linear_heads_fold",
-                               "primx_linear_fold"}
-_AB_ABI_VERSIONS: tuple = (21,)
+# versions 22 / 23 only added / re-typed the LayerNorm-fold entry points, so a version-21 or -22 build can stand in as long as
+# nothing folds: the fold prototypes are not bound to such a build and `fold_available()` is False (ops.fold_shapes_ok asks)
+_FOLD_ENTRY_POINTS: set = {"primx_linear_f32out", "primx_row_stats", "primx_linear_gate_residual_fold", "primx_linear_heads_fold",
+                           "primx_linear_fold"}
+_AB_ABI_VERSIONS: tuple = (21, 22)
+_fold_available: dict = {}
 
 _lib: Optional[C.CDLL] = None
 
@@ -116,18 +118,26 @@ def load(path: Optional[str] = None) -> C.CDLL:
         pass
     lib = C.CDLL(path)
     ab = bool(os.environ.get("PRIMX_LIB"))
-    for name, argtypes in SIGNATURES.items():
-        if ab and name in _OPTIONAL_IN_AB_BUILDS and not hasattr(lib, name):
-            continue
-        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
-        fn.argtypes = argtypes
-        fn.restype = _RESTYPES.get(name, C.c_int)
+    lib.primx_abi_version.restype = C.c_int
     got = lib.primx_abi_version()
     if got != ABI_VERSION and not (ab and got in _AB_ABI_VERSIONS):
         raise RuntimeError(f"libprimx_hip.so ABI {got} != expected {ABI_VERSION}; rebuild it")
+    for name, argtypes in SIGNATURES.items():
+        if got != ABI_VERSION and name in _FOLD_ENTRY_POINTS:
+            continue                # an older A/B build: its fold entry points (if any) have other argument lists
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _fold_available[path] = got == ABI_VERSION
     if path == LIB_PATH:
         _lib = lib
     return lib
+
+
+def fold_available() -> bool:
+    """Does the loaded library carry the LayerNorm-fold entry points of this ABI?  (False only for an older PRIMX_LIB A/B build.)"""
+    load()
+    return _fold_available.get(LIB_PATH, False)
 
 
 def check(status: int, name: str) -> None:

@@ -101,14 +101,16 @@ struct GemmArgs {
     unsigned* sync;
     int ln_light;
     // LayerNorm fold.  Producer (EPI_GATE_RESIDUAL_FOLD): ln_scale / ln_mod_stride = the NEXT LayerNorm's scale vectors, ln_out = the
-    // 16-bit operand cast16((x - c) (1 + scale)), fold_c = per-row centre c (read), fold_part = [M][N / 144][2] partial sums of
-    // (x - c), (x - c)^2 per column tile (written).  Consumers: fold_part / fold_parts (read), fold_u / fold_v = fp32 per-column
-    // vectors, fold_c (the column tile 0 workgroups add the row's mean of (x - c) to it), fold_eps.
+    // 16-bit operand cast16((x - c) rho_p (1 + scale)), fold_c = [M][2] per-row (centre c, scale rho_p) (read), fold_part =
+    // [M][N / 144][2] partial sums of (x - c), (x - c)^2 per column tile (written).  Consumers: fold_part / fold_parts (read), fold_u /
+    // fold_v = fp32 per-column vectors, fold_c = the (c, rho_p) the producer used (read), fold_c_out = [M][2] (written by the column
+    // tile 0 workgroups: this site's (mean, rstd) = the next producer's (c, rho_p); never the array fold_c points at), fold_eps.
     float* fold_part;
     int fold_parts;
     const float* fold_u;
     const float* fold_v;
-    float* fold_c;
+    const float* fold_c;
+    float* fold_c_out;
     float fold_eps;
 };
 
@@ -416,22 +418,30 @@ __device__ __forceinline__ typename T16<DT>::V4 linear_out4(const GemmArgs<DT>& 
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm fold (primx_linear_gate_residual_fold -> primx_linear_heads_fold / primx_linear_fold).  Every LayerNorm + modulate of a
 // DiT block sits between a gated residual add and a Linear (dit_crossattn.py:55-57).  With the row statistics mu, rho of the fp32
-// residual stream x, m = cast16(1 + scale) and ANY per-row centre c:
+// residual stream x, m = cast16(1 + scale), ANY per-row centre c and ANY per-row scale rho_p > 0:
 //     reference:  y = cast16( cast16( (x - mu) rho m + shift ) W^T + b )
-//     folded:     y = cast16( rho ( cast16((x - c) m) W^T  -  (mu - c) u ) + v ),     u = m W^T,  v = shift W^T + b  (fp32, per column)
-// The PRODUCER (the gate-residual GEMM, EPI_GATE_RESIDUAL_FOLD) stores a16 = cast16((x - c) m) next to x and the partial sums
-// of (x - c), (x - c)^2 of its 144 columns; the CONSUMER (to_q / qkv / fc1, EPI_HEADS_FOLD / EPI_LINEAR_FOLD) multiplies a16,
+//     folded:     y = cast16( (rho / rho_p) cast16((x - c) rho_p m) W^T  -  rho (mu - c) u  +  v ),   u = m W^T,  v = shift W^T + b  (fp32, per column)
+// The PRODUCER (the gate-residual GEMM, EPI_GATE_RESIDUAL_FOLD) stores a16 = cast16((x - c) rho_p m) next to x and the partial
+// sums of (x - c), (x - c)^2 of its 144 columns; the CONSUMER (to_q / qkv / fc1, EPI_HEADS_FOLD / EPI_LINEAR_FOLD) multiplies a16,
 // finishes mu' = mean(x - c) and rho from the partials and applies them with u, v in its epilogue: no LayerNorm kernel and no
 // second pass over the fp32 rows.  u, v depend on the timestep only (two GEMM rows per timestep and site, EPI_F32OUT, once per
-// planned sampling loop).  The fold rounds (x - c) m where the reference rounds the normalised value: the same relative
-// rounding per element, but - mu' u cancels, so it costs accuracy in proportion to |mu'| / sigma (tools/ln_fold_study.py: equal
-// to the reference's rounding up to a ratio of 0.5, x 1.4 at 2, x 5 at 10).  Hence the centre: c = the row mean at the PREVIOUS
-// LayerNorm site (the consumer's column tile 0 moves it: c += mu'), so |mu'| is what ONE gated branch adds to the mean.
-// Statistics: var = E[(x - c)^2] - mu'^2 in fp32 - harmless for the same reason.
+// planned sampling loop).
+// (c, rho_p) = the row's (mean, rstd) at the PREVIOUS LayerNorm site (the consumer's column tile 0 writes its own (c + mu', rho)
+// for the next producer; the first site's come from primx_row_stats).  Why both:
+//  * accuracy - the fold rounds (x - c) rho_p m where the reference rounds the normalised value: the same relative rounding per
+//    element, but - mu' u cancels, so it costs accuracy in proportion to |mu'| / sigma (tools/ln_fold_study.py: equal to the
+//    reference's rounding up to a ratio of 0.5, x 1.4 at 2, x 5 at 10).  With c = the previous site's mean, |mu'| is what ONE
+//    gated branch adds to the mean.
+//  * range (fp16) - (x - c) rho_p is the LayerNorm output up to the factor rho_p / rho that one gated branch changes the row's
+//    spread by: O(1) whatever the magnitude or spread of the residual stream (1e4 or 1e-5 alike), as in the reference, which
+//    normalises before it rounds.  Without rho_p (ABI 22) the operand carried the row's spread into the 16-bit type.
+// Statistics: var = E[(x - c)^2] - mu'^2 in fp32 - harmless for the same reason.  The consumers read (c, rho_p) from one array and
+// write the next pair into ANOTHER one (fold_c_out): all column tiles of a row read rho_p while tile 0 produces its successor.
 // Row statistics of a consumer tile, in two steps so that the kernel can put its own memory requests between the loads and their
 // use: thread t < rows owns row m0 + t.  Up to eight partials per row (fold_parts <= 8, host-checked), all loads independent.
 struct FoldPartials {
     f32x2 v[8];
+    f32x2 cen;                                           // (c, rho_p) the producer used
 };
 template <int DT>
 __device__ __forceinline__ FoldPartials fold_stats_load(const GemmArgs<DT>& p, int M, int m0, int t) {
@@ -440,8 +450,10 @@ __device__ __forceinline__ FoldPartials fold_stats_load(const GemmArgs<DT>& p, i
     FoldPartials r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) r.v[i] = pp[min(i, p.fold_parts - 1)];
+    r.cen = reinterpret_cast<const f32x2*>(p.fold_c)[m];
     return r;
 }
+// stats[t] = (rho_p mu', rho / rho_p): fold_apply's y = st[1] (acc - st[0] u) + v is (rho / rho_p) acc - rho mu' u + v
 template <int DT>
 __device__ __forceinline__ void fold_stats_finish(const GemmArgs<DT>& p, const FoldPartials& r, int M, int K, int m0, int t,
                                                   bool tile0, f32x2* stats) {
@@ -454,11 +466,12 @@ __device__ __forceinline__ void fold_stats_finish(const GemmArgs<DT>& p, const F
     const float inv = 1.0f / (float)K;
     const float mu = s1 * inv;
     const float rho = 1.0f / sqrtf(fmaxf(s2 * inv - mu * mu, 0.f) + p.fold_eps);
-    stats[t] = f32x2{mu, rho};                           // (LDS)
-    if (tile0 && m0 + t < M) p.fold_c[m0 + t] += mu;     // the next producer centres with this site's mean
+    stats[t] = f32x2{r.cen[1] * mu, rho / r.cen[1]};     // (LDS)
+    // the next producer centres with this site's mean and scales with this site's rstd
+    if (tile0 && m0 + t < M) reinterpret_cast<f32x2*>(p.fold_c_out)[m0 + t] = f32x2{r.cen[0] + mu, rho};
 }
 
-// the consumer's value of four columns: rho (acc - mu' u) + v
+// the consumer's value of four columns: st = (rho_p mu', rho / rho_p) -> (rho / rho_p) acc - rho mu' u + v
 __device__ __forceinline__ f32x4 fold_apply(const f32x4 a, const f32x2 st, const f32x4 u, const f32x4 v) {
     f32x4 y;
 #pragma unroll
@@ -1284,8 +1297,8 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
                 rep_i * (h_seg == 0 ? p.rep_stride[0] : h_seg == 1 ? p.rep_stride[1] : p.rep_stride[2]);
     }
     V4e bpre[NROWCH], gpre[NROWCH];
-    V4e spre[FOLD_P ? NROWCH : 1];             // fold producer: the next LayerNorm's scale vector, the row's centre
-    float cpre[FOLD_P ? NROWCH : 1];
+    V4e spre[FOLD_P ? NROWCH : 1];             // fold producer: the next LayerNorm's scale vector, the row's (centre, scale)
+    f32x2 cpre[FOLD_P ? NROWCH : 1];
 #pragma unroll
     for (int i = 0; i < NROWCH; ++i) {
         const int cid = tid + 512 * i;
@@ -1298,7 +1311,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
             xpre[i] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * pl_N + n0 + 4 * c4);
             if constexpr (FOLD_P) {
                 spre[i] = *reinterpret_cast<const V4e*>(p.ln_scale + (int64_t)(m / p.rows_per_batch) * p.ln_mod_stride + n0 + 4 * c4);
-                cpre[i] = p.fold_c[m];
+                cpre[i] = reinterpret_cast<const f32x2*>(p.fold_c)[m];
             }
         }
     }
@@ -1348,15 +1361,15 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
                 // the next site's operand and this unit's share of the row statistics; the partial sums go back into the unit's
                 // own (dead) slot of the parking area
                 const V4e sv = spre[i];
-                const float cr = cpre[i];
+                const f32x2 cr = cpre[i];
                 float s1 = 0.f, s2 = 0.f;
                 V4e o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float d = xv[j] - cr;
+                    const float d = xv[j] - cr[0];
                     s1 += d;
                     s2 = __builtin_fmaf(d, d, s2);
-                    o[j] = (S)(d * rnd16<DT>(1.0f + (float)sv[j]));
+                    o[j] = (S)((d * cr[1]) * rnd16<DT>(1.0f + (float)sv[j]));
                 }
                 out_store(reinterpret_cast<V4e*>(p.ln_out + (int64_t)(m0 + row) * pl_N + n0 + 4 * c4), o);
                 *reinterpret_cast<f32x2*>(red + row * RS + 4 * c4) = f32x2{s1, s2};
@@ -1813,7 +1826,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
             if constexpr (FOLD_P) {
                 // the producer of the LayerNorm site behind this GEMM (see fold_stats_load): a lane owns 36 of its row's columns in
                 // this wave's 144-column half; the four lanes of a row meet by shuffle, so the half IS one 144-column partial sum
-                const float cr = p.fold_c[mc];
+                const f32x2 cr = reinterpret_cast<const f32x2*>(p.fold_c)[mc];
                 const S* srow = p.ln_scale + (int64_t)(mc / p.rows_per_batch) * p.ln_mod_stride + nb;
                 S* arow = p.ln_out + (int64_t)mc * pl_N + n0 + wn * 144;
                 float s1 = 0.f, s2 = 0.f;
@@ -1823,10 +1836,10 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         xv[j][r] += rnd16<DT>((float)gv[j][r] * rnd16<DT>(acc[i][j][r] + (p.bias ? (float)bpre[j][r] : 0.f)));
-                        const float d = xv[j][r] - cr;
+                        const float d = xv[j][r] - cr[0];
                         s1 += d;
                         s2 = __builtin_fmaf(d, d, s2);
-                        o[r] = (S)(d * rnd16<DT>(1.0f + (float)sv[r]));
+                        o[r] = (S)((d * cr[1]) * rnd16<DT>(1.0f + (float)sv[r]));
                     }
                     if (ok) out_store(reinterpret_cast<f32x4*>(xrow + j * 16), xv[j]);
                     return o;
@@ -2146,6 +2159,202 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// PERSISTENT passes (round 5): the pass of gemm288p_dma_kernel - 256 rows x 144 columns over the whole K, 8 compute waves of 32 rows
+// + 2 loader waves, 3-stage LDS-DMA ring - as a kernel that stays on its CU and walks a LIST of passes: workgroup b of G (G = the
+// CU count) takes the units b, b + G, b + 2 G, ... of the mt x (N / 144) grid of passes.  For the launches where every CU has many
+// tiles in a row (T >= 8192: fc1, fc2, proj, cproj of a large batch).  Why: at T = 32768 the 8-wave 256 x 288 kernel runs 8
+// workgroups per CU back to back and each of them pays its ring fill, its epilogue and - at s_endpgm - the drain of its stores
+// with nothing to overlap them: ~107k cycles per tile for ~59k of main loop (fc1 453 - 460 us = 756 - 768 TFLOP/s; the two-pass
+// kernel 451 us with 49k of loop per workgroup).  Here the seam between two passes costs the compute waves their epilogue's ISSUE
+// only: the loader waves have the next pass's first k-tiles in the ring when the epilogue ends (they never stop at a seam: one
+// stream of k-tiles g = 0 .. rounds x nk - 1 under the two-tiles-of-flight protocol of gemm288p), the stores drain under the next
+// pass's MFMAs (the compute waves do not wait on vmcnt in the loop and issue no loads there; loads and stores share vmcnt on this
+// part, so the waves that store must not be the waves that count DMA arrivals), and nothing is launched, filled or drained per
+// tile.  Unit order: the virtual workgroup id v = b + round x G goes through the same XCD-aware 2-D walk as a one-pass-per-
+// workgroup launch would (xcd_tile2d; G % 8 == 0 keeps v's XCD = b's), so the 32 CUs of an XCD hold an sr x sc block of passes
+// in every round and share its sr activation and sc weight panels through their L2.
+// Epilogues, from registers (acc[i][j][r] = C[m0 + 32 w + 16 i + lr][n0 + 16 j + 4 lg + r]): EPI_LINEAR (bias, activation, 16-byte
+// stores by v_permlane16_swap - gemm288p's) and EPI_GATE_RESIDUAL (fp32 read-modify-write of the residual rows, 16 bytes per lane).
+template <int DT, int EPI>
+__global__ __launch_bounds__(640) void gemm144pp_dma_kernel(PRIMX_GEMM_PARAMS(DT)) {
+    PRIMX_GEMM_ARGS(DT);
+    static_assert(EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL, "persistent passes: dense-output epilogues only");
+    using S = typename T16<DT>::S;
+    using V8 = typename T16<DT>::V8;
+    using V4e = typename T16<DT>::V4;
+    typedef __attribute__((address_space(1))) const void GV;
+    typedef __attribute__((address_space(3))) void LV;
+    constexpr int BM = 256, BN = 144, MI = 2, NI = 9, NST = 3;
+    constexpr int ROWS = BM + BN, STAGE = ROWS * 64, NINST = ROWS / 8, NL = NINST / 2;   // 50 wave-instructions per k-tile, 25 per loader
+    static_assert(NST * STAGE * 2 <= 160 * 1024 && NINST % 2 == 0 && BM % 8 == 0, "LDS budget / loader split");
+    __shared__ __attribute__((aligned(16))) S smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = pl_N / BN, mt = (pl_M + BM - 1) / BM;
+    const int units = mt * nt, G = (int)gridDim.x;
+    const int rounds = (units - (int)blockIdx.x + G - 1) / G;                            // >= 1 (host: G <= units)
+    const int nk = pl_K / BK, total = rounds * nk;
+    auto unit_tile = [&](int round, int& m0, int& n0) {
+        const int v = (int)blockIdx.x + round * G;
+        int mi_t, ni_t;
+        if (pl_xcd_gm > 0) {   // packed gm | sr << 8 | sc << 16 (xcd_pack_pp)
+            xcd_tile2d(v, mt, nt, pl_xcd_gm, mi_t, ni_t);
+        } else {
+            const int id = xcd_remap(v, units);
+            mi_t = id / nt;
+            ni_t = id - mi_t * nt;
+        }
+        m0 = mi_t * BM;
+        n0 = ni_t * BN;
+    };
+
+    if (wave >= 8) {
+        // ---------------- loader wave lw: instructions t = lw * 25 + i, rows 8 t .. 8 t + 7 of the 400-row stage image (rows < 256:
+        // activations, the rest: the pass's 144 weight rows).  One stream of k-tiles over all rounds; the row pointers are formed
+        // again at every seam (a handful of 64-bit adds per pass - kept across the loop they would be the wave's whole budget twice)
+        const int lw = wave - 8;
+        const S* gp[NL];
+        auto point = [&](int round) {
+            int m0, n0;
+            unit_tile(round, m0, n0);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int row = 8 * (lw * NL + i) + (lane >> 3);
+                const int c = (lane & 7) ^ ((row >> 1) & 7);
+                gp[i] = (row < BM) ? pl_A + (int64_t)min(m0 + row, pl_M - 1) * pl_K + c * 8 : pl_W + (int64_t)(n0 + row - BM) * pl_K + c * 8;
+            }
+        };
+        int ir = 0, ikt = 0;                                                             // the next k-tile to request: (round, kt)
+        point(0);
+        auto issue_next = [&](int stage) {
+            // (behind the last k-tile the stream repeats it: the waits below count NL instructions per step)
+#pragma unroll
+            for (int i = 0; i < NL; ++i)
+                __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + ikt * BK), (LV*)(smem + stage * STAGE + (lw * NL + i) * 512), 16, 0, 0);
+            if (ikt + 1 < nk) {
+                ++ikt;
+            } else if (ir + 1 < rounds) {
+                ++ir;
+                ikt = 0;
+                point(ir);
+            }
+        };
+        issue_next(0);
+        issue_next(1);
+        issue_next(2);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NL) : "memory");      // P: k-tile 0 landed
+        int st = 0;
+        for (int g = 0; g < total; ++g) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");     // B_g: k-tile g + 1 landed, g + 2 may fly
+            issue_next(st);                                                              // k-tile g's stage is free now
+            st = (st == NST - 1) ? 0 : st + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 // the repeated tail must not outlive the LDS
+        return;
+    }
+
+    // ---------------- compute wave w: rows 32 w .. 32 w + 31 of the pass, all 144 columns, the whole K
+    const int lr = lane & 15, lg = lane >> 4;
+    const int a_row = wave * 32 + lr;
+    auto read_frags = [&](int stage, int ks, V8 (&a)[MI], V8 (&b)[NI]) {
+        const S* As = smem + stage * STAGE;
+        const S* Ws = As + BM * 64;
+        const int chunk = ks * 4 + lg;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const V8*>(As + lds_off(a_row + i * 16, chunk));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(Ws + lds_off(lr + j * 16, chunk));
+    };
+    f32x4 acc[MI][NI];
+    // operands swapped (A = weight rows, B = activation rows): the accumulator holds C^T, a lane owns ONE row and four
+    // consecutive columns, and the epilogue needs no LDS (the ring belongs to the loaders throughout)
+    auto multiply = [&](const V8 (&a)[MI], const V8 (&b)[NI]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(b[j], a[i], acc[i][j]);
+    };
+    asm volatile("s_barrier" ::: "memory");                                              // P
+    int st = 0;
+#pragma unroll 1
+    for (int round = 0; round < rounds; ++round) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        V8 a0[MI], b0[NI], a1[MI], b1[NI];
+        read_frags(st, 0, a0, b0);                 // (the round's k-tile 0 has landed: P, or B of the previous round's last k-tile)
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            const int st_next = (st == NST - 1) ? 0 : st + 1;
+            read_frags(st, 1, a1, b1);
+            multiply(a0, b0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // B_g
+            // (unconditional: behind the round's last k-tile the stage holds the next round's first one - or the repeated last one -
+            // and the values are simply not used; a conditional read kept both fragment sets live through the loop)
+            read_frags(st_next, 0, a0, b0);
+            multiply(a1, b1);
+            st = st_next;
+        }
+        // ---- epilogue of the pass, from registers.  Nothing below waits for the stores: the next round's fragments and MFMAs
+        // follow immediately; the loads at its head (bias, gate, residual rows) are the only vector-memory waits of a compute wave
+        int m0, n0;
+        unit_tile(round, m0, n0);
+        V4e bpre[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            bpre[j] = V4e{};
+            if (p.bias) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + n0 + j * 16 + 4 * lg);
+        }
+        if constexpr (EPI == EPI_LINEAR) {
+            typedef unsigned int u32;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wave * 32 + i * 16 + lr;
+                const bool ok = m < pl_M;
+                S* orow = p.out + (int64_t)(ok ? m : pl_M - 1) * pl_N + n0;
+#pragma unroll
+                for (int j = 0; j + 1 < NI; j += 2) {
+                    const u32x2 a = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j], bpre[j]));
+                    const u32x2 b = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j + 1], bpre[j + 1]));
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                    const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
+                    if (ok) out_store(reinterpret_cast<u32x4*>(orow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
+                }
+                if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), linear_out4<DT>(p, acc[i][NI - 1], bpre[NI - 1]));
+            }
+        } else {
+            // x[m, :] += cast16(gate[b, :] * cast16(acc + bias)) (models/dit_crossattn.py:55-57): one row group at a time, all nine
+            // 16-byte pieces of the lane's row requested before the first is used
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wave * 32 + i * 16 + lr;
+                const bool ok = m < pl_M;
+                const int mc = ok ? m : pl_M - 1;
+                const S* grow = p.gate + (int64_t)(mc / p.rows_per_batch) * p.gate_stride + n0 + 4 * lg;
+                float* xrow = p.x + (int64_t)mc * pl_N + n0 + 4 * lg;
+                V4e gv[NI];
+                f32x4 xv[NI];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    gv[j] = *reinterpret_cast<const V4e*>(grow + j * 16);
+                    xv[j] = *reinterpret_cast<const f32x4*>(xrow + j * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        xv[j][r] += rnd16<DT>((float)gv[j][r] * rnd16<DT>(acc[i][j][r] + (p.bias ? (float)bpre[j][r] : 0.f)));
+                    if (ok) out_store(reinterpret_cast<f32x4*>(xrow + j * 16), xv[j]);
+                }
+            }
+        }
+    }
+}
+
 // (Round 4 built a PERSISTENT form of the big tile here - four waves of 128 x 144 with the whole register file, one per SIMD, walking
 // many tiles as one operand stream, first fed by LDS-DMA, then through registers - to overlap ring fill and store drain at T >= 8192,
 // where every CU runs eight tiles back to back.  Both forms were correct and both lost to the 8-wave kernel above (fc1 at T = 32768:
@@ -2428,16 +2637,18 @@ int launch_fold(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
     const int mt = (a.M + 127) / 128;
     if constexpr (EPI == EPI_GATE_RESIDUAL_FOLD) {
         PRIMX_REQUIRE(a.N / 144 <= 8, "%s: at most 8 column tiles (N <= 1152), the consumers read 8 partial sums per row (N=%d)", name, a.N);
-        PRIMX_REQUIRE((((uintptr_t)a.ln_scale | (uintptr_t)a.ln_out | (uintptr_t)a.fold_part) & 7) == 0 && a.ln_mod_stride % 4 == 0,
-                      "%s: the scale vectors, the operand and the partial sums must be 8-byte aligned", name);
+        PRIMX_REQUIRE((((uintptr_t)a.ln_scale | (uintptr_t)a.ln_out | (uintptr_t)a.fold_part | (uintptr_t)a.fold_c) & 7) == 0 &&
+                          a.ln_mod_stride % 4 == 0,
+                      "%s: the scale vectors, the operand, the partial sums and the (centre, scale) pairs must be 8-byte aligned", name);
         // the 256 x 288 tile where the unfolded gate-residual GEMM takes it (launch<>: a large batch)
         if (!g_no_big && a.N % 288 == 0 && ((a.M + 255) / 256) * (a.N / 288) >= g_big_min) launch144_dma<DT, EPI, 1>(a, mt, st);
         else launch144_dma<DT, EPI>(a, mt, st);
     } else {
         PRIMX_REQUIRE(a.K % 144 == 0 && a.fold_parts == a.K / 144 && a.fold_parts <= 8,
                       "%s: K must be the producer's N: a multiple of 144, at most 1152 (K=%d)", name, a.K);
-        PRIMX_REQUIRE((((uintptr_t)a.fold_u | (uintptr_t)a.fold_v) & 15) == 0 && ((uintptr_t)a.fold_part & 7) == 0,
-                      "%s: u / v must be 16-byte aligned, the partial sums 8-byte aligned", name);
+        PRIMX_REQUIRE((((uintptr_t)a.fold_u | (uintptr_t)a.fold_v) & 15) == 0 &&
+                          (((uintptr_t)a.fold_part | (uintptr_t)a.fold_c | (uintptr_t)a.fold_c_out) & 7) == 0,
+                      "%s: u / v must be 16-byte aligned, the partial sums and the (centre, scale) pairs 8-byte aligned", name);
         if constexpr (EPI == EPI_HEADS_FOLD) {
             const int per = a.heads * a.dh;
             const bool big = !g_no_big && g_big_heads_min > 0 && a.N % 288 == 0 && per % 288 == 0 && 288 % a.dh == 0 && a.dh % 8 == 0 &&
@@ -2711,7 +2922,7 @@ extern "C" int primx_linear_gate_residual_fold(const void* A, const void* W, con
         a.M = M; a.N = N; a.K = K;
         a.gate = (const S*)gate; a.gate_stride = gate_stride; a.x = x; a.rows_per_batch = rows_per_batch;
         a.ln_scale = (const S*)next_scale; a.ln_mod_stride = next_mod_stride; a.ln_out = (S*)a16_out;
-        a.fold_c = const_cast<float*>(center); a.fold_part = part_out;
+        a.fold_c = center; a.fold_part = part_out;
         if (int rc = set_prefetch<DT>(a, prefetch, prefetch_bytes, name)) return rc;
         return launch_fold<DT, EPI_GATE_RESIDUAL_FOLD>(a, (hipStream_t)stream, name);
     });
@@ -2720,14 +2931,14 @@ extern "C" int primx_linear_gate_residual_fold(const void* A, const void* W, con
 
 extern "C" int primx_linear_heads_fold(const void* A, const void* W, int M, int N, int K, int rows_per_batch, int heads, int dh,
                                        int n_seg, const int* kind, void* const* dst, int n_pad, float scale0, const float* part,
-                                       const float* u, const float* v, float* center, float eps, int dtype,
-                                       const void* prefetch, int64_t prefetch_bytes, void* stream) {
+                                       const float* u, const float* v, const float* center, float* center_out, float eps,
+                                       int dtype, const void* prefetch, int64_t prefetch_bytes, void* stream) {
     const char* name = "primx_linear_heads_fold";
     PRIMX_REQUIRE(kind && dst && n_seg >= 1 && n_seg <= 3, "%s: n_seg must be 1..3", name);
     PRIMX_REQUIRE(heads > 0 && dh > 0 && N == n_seg * heads * dh, "%s: N must equal n_seg*heads*dh", name);
     PRIMX_REQUIRE(rows_per_batch > 0 && M % rows_per_batch == 0 && n_pad >= rows_per_batch && n_pad % 16 == 0,
                   "%s: need M %% rows_per_batch == 0, n_pad >= rows_per_batch, n_pad %% 16 == 0", name);
-    PRIMX_REQUIRE(part && u && v && center, "%s: null fold argument", name);
+    PRIMX_REQUIRE(part && u && v && center && center_out && center != center_out, "%s: null fold argument, or center_out == center", name);
     for (int s = 0; s < n_seg; ++s) {
         PRIMX_REQUIRE(dst[s] != nullptr, "%s: null destination", name);
         PRIMX_REQUIRE(kind[s] == PRIMX_HEADS_ROWS || kind[s] == PRIMX_HEADS_VT || kind[s] == PRIMX_HEADS_KROWS, "%s: bad kind", name);
@@ -2744,7 +2955,7 @@ extern "C" int primx_linear_heads_fold(const void* A, const void* W, int M, int 
             a.rep_stride[s] = 0;
             a.dst[s] = s < n_seg ? (S*)dst[s] : nullptr;
         }
-        a.fold_part = const_cast<float*>(part); a.fold_parts = K / 144; a.fold_u = u; a.fold_v = v; a.fold_c = center; a.fold_eps = eps;
+        a.fold_part = const_cast<float*>(part); a.fold_parts = K / 144; a.fold_u = u; a.fold_v = v; a.fold_c = center; a.fold_c_out = center_out; a.fold_eps = eps;
         if (int rc = set_prefetch<DT>(a, prefetch, prefetch_bytes, name)) return rc;
         return launch_fold<DT, EPI_HEADS_FOLD>(a, (hipStream_t)stream, name);
     });
@@ -2752,10 +2963,10 @@ extern "C" int primx_linear_heads_fold(const void* A, const void* W, int M, int 
 }
 
 extern "C" int primx_linear_fold(const void* A, const void* W, void* out, int M, int N, int K, int act, const float* part,
-                                 const float* u, const float* v, float* center, float eps, int dtype, const void* prefetch,
-                                 int64_t prefetch_bytes, void* stream) {
+                                 const float* u, const float* v, const float* center, float* center_out, float eps, int dtype,
+                                 const void* prefetch, int64_t prefetch_bytes, void* stream) {
     const char* name = "primx_linear_fold";
-    PRIMX_REQUIRE(out && part && u && v && center, "%s: null pointer", name);
+    PRIMX_REQUIRE(out && part && u && v && center && center_out && center != center_out, "%s: null pointer, or center_out == center", name);
     PRIMX_REQUIRE(act == PRIMX_ACT_NONE || act == PRIMX_ACT_GELU_TANH || act == PRIMX_ACT_GELU_ERF, "%s: bad activation code", name);
     PRIMX_DISPATCH_16(dtype, name, {
         using S = typename T16<DT>::S;
@@ -2763,7 +2974,7 @@ extern "C" int primx_linear_fold(const void* A, const void* W, void* out, int M,
         a.A = (const S*)A; a.W = (const S*)W;
         a.M = M; a.N = N; a.K = K;
         a.out = (S*)out; a.act = act; a.out_scale = 1.0f;
-        a.fold_part = const_cast<float*>(part); a.fold_parts = K / 144; a.fold_u = u; a.fold_v = v; a.fold_c = center; a.fold_eps = eps;
+        a.fold_part = const_cast<float*>(part); a.fold_parts = K / 144; a.fold_u = u; a.fold_v = v; a.fold_c = center; a.fold_c_out = center_out; a.fold_eps = eps;
         if (int rc = set_prefetch<DT>(a, prefetch, prefetch_bytes, name)) return rc;
         return launch_fold<DT, EPI_LINEAR_FOLD>(a, (hipStream_t)stream, name);
     });

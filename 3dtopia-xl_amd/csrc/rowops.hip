@@ -181,9 +181,10 @@ extern "C" int primx_layernorm_modulate(const float* x, const void* shift, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row means of the fp32 residual stream: the centre of the first folded LayerNorm site of a forward (gemm.hip, "LayerNorm fold").
-// One half-wave per row, the loads and the summation order of ln_row32.
-__global__ __launch_bounds__(256) void row_mean_kernel(const float* __restrict__ x, int rows, int D, float* __restrict__ mean) {
+// Row statistics of the fp32 residual stream: (mean, rstd) = the (centre, scale) of the first folded LayerNorm site of a forward
+// (gemm.hip, "LayerNorm fold").  One half-wave per row, the loads and the two-pass summation order of ln_row32 (ln_row.h), so
+// the pair is what primx_layernorm_modulate uses for the same row.
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, int rows, int D, float eps, f32x2* __restrict__ out) {
     const int row = (int)blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;
     if (row >= rows) return;
     const float* xr = x + (int64_t)row * D;
@@ -193,13 +194,26 @@ __global__ __launch_bounds__(256) void row_mean_kernel(const float* __restrict__
         s += (v[0] + v[1]) + (v[2] + v[3]);
     }
     s = half_wave_sum(s);
-    if (l32 == 0) mean[row] = s * (1.0f / (float)D);
+    const float mean = s * (1.0f / (float)D);
+    float q = 0.f;
+    for (int c = l32 * 4; c < D; c += 128) {             // (second pass from L1 / L2: the row is 4.6 KB)
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = v[j] - mean;
+            q += a * a;
+        }
+    }
+    q = half_wave_sum(q);
+    if (l32 == 0) out[row] = f32x2{mean, 1.0f / sqrtf(q * (1.0f / (float)D) + eps)};
 }
 
-extern "C" int primx_row_mean(const float* x, int rows, int D, float* mean, void* stream) {
-    PRIMX_REQUIRE(x && mean && rows > 0 && D > 0 && D % 4 == 0, "primx_row_mean: need rows > 0 and D %% 4 == 0 (D=%d)", D);
-    hipLaunchKernelGGL(row_mean_kernel, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, rows, D, mean);
-    PRIMX_CHECK_LAUNCH("primx_row_mean");
+extern "C" int primx_row_stats(const float* x, int rows, int D, float eps, float* stats, void* stream) {
+    PRIMX_REQUIRE(x && stats && rows > 0 && D > 0 && D % 4 == 0 && ((uintptr_t)stats & 7) == 0,
+                  "primx_row_stats: need rows > 0, D %% 4 == 0 (D=%d) and 8-byte aligned pairs", D);
+    hipLaunchKernelGGL(row_stats_kernel, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, rows, D, eps,
+                       reinterpret_cast<f32x2*>(stats));
+    PRIMX_CHECK_LAUNCH("primx_row_stats");
     return PRIMX_OK;
 }
 
@@ -554,7 +568,8 @@ __global__ void diffusion_step_kernel(const float* __restrict__ x, const void* _
         } else {
             x0 = mo;
         }
-        if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        // x.clamp(-1, 1) (gaussian_diffusion.py:287-291): torch.clamp PROPAGATES NaN, fminf / fmaxf would turn it into -1
+        if (clip) x0 = (x0 != x0) ? x0 : fminf(fmaxf(x0, -1.0f), 1.0f);
         float out;
         if (!ancestral) {
             const float a = sra * xt;

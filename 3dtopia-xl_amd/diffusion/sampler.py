@@ -208,20 +208,45 @@ class GaussianDiffusion(DiffusionTables):
         if progress:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
+        img0 = img
+
+        def step(x, i):
+            with torch.no_grad():   # scoped to the step: a generator must not hold the grad-mode context across yields
+                return self._step(kind, model, x, i, clip_denoised=clip_denoised, model_kwargs=model_kwargs, eta=eta, coef=coef,
+                                  tmap=tmap, planner=planner)
         try:
             for i in indices:
-                with torch.no_grad():   # scoped to the step: a generator must not hold the grad-mode context across yields
-                    out = self._step(kind, model, img, i, clip_denoised=clip_denoised,
-                                     model_kwargs=model_kwargs, eta=eta, coef=coef, tmap=tmap, planner=planner)
+                out = step(img, i)
+                if i == 0:
+                    out = self._fold_guard(planner, out, img0, step)     # BEFORE the final yield: consumers stop at the last item
                 yield out
                 img = out["sample"]
-            # (a model that folded its LayerNorms in fp16 has its final sample checked for overflow once per loop: DiT.fold_overflow_check)
-            check = getattr(planner, "fold_overflow_check", None) if planner is not None else None
-            if callable(check):
-                check(img)
         finally:
             if planner is not None:
                 planner.clear_timestep_plan()
+
+    def _fold_guard(self, planner, out: dict, img0: torch.Tensor, step: Callable) -> dict:
+        """A model that folded its LayerNorms in fp16 (DiT.fold_ln) has the FINAL sample of the loop checked once (one reduction +
+        one read-back per loop; NaN / inf propagate through the diffusion update, clipped or not).  The folded operand is
+        normalised with the previous site's statistics, so it leaves the fp16 range only if ONE gated branch multiplies a row's
+        spread by > 1e3 - no model of the suite comes near.  If it ever happens the loop is run again with the LayerNorm launches
+        (whose operand cannot overflow, as in the reference) and THAT result is returned: same contract as the reference, which
+        returns whatever its fp16 arithmetic gives."""
+        over = getattr(planner, "fold_overflowed", None) if planner is not None else None
+        if not callable(over) or not over(out["sample"]):
+            return out
+        import warnings
+        warnings.warn("non-finite sample after a sampling loop with the fp16 LayerNorm fold: running the loop again with "
+                      "LayerNorm launches (PRIMX_DIT_FOLD=0 / model.fold_ln = False avoids the first attempt)", RuntimeWarning)
+        keep, planner.fold_ln = planner.fold_ln, False
+        try:
+            img = img0
+            for i in range(self.num_timesteps - 1, -1, -1):
+                out = step(img, i)
+                img = out["sample"]
+        finally:
+            planner.fold_ln = keep
+        return out
 
     # ------------------------------------------------------------------ public API (reference names)
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,

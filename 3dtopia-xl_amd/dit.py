@@ -175,7 +175,7 @@ class DiT(nn.Module):
         self.fuse_ln = os.environ.get("PRIMX_DIT_FUSE_LN", "1") != "0"
         self.ln_in_kernel = os.environ.get("PRIMX_DIT_LN_TAIL", "0") == "1"
         self._ln_sync: Dict = {}              # device -> int32 workspace of the fused route (zero between launches)
-        # `fold_ln` (default on; PRIMX_DIT_FOLD=0 turns it off): the LayerNorm fold (include/primx_hip.h, ABI 22; csrc/gemm.hip "LayerNorm fold").  In a PLANNED
+        # `fold_ln` (default on; PRIMX_DIT_FOLD=0 turns it off): the LayerNorm fold (include/primx_hip.h, ABI 23; csrc/gemm.hip "LayerNorm fold").  In a PLANNED
         # sampling loop (plan_timesteps: the modulation vectors of every coming call are known) each LayerNorm + modulate between a
         # gated residual add and a Linear is folded into the two GEMMs around it: the gate-residual GEMM also stores the centred,
         # scaled 16-bit operand and partial row sums, the consumer (to_q / qkv / fc1) finishes the statistics and applies them in
@@ -186,12 +186,12 @@ class DiT(nn.Module):
         # call - unplanned forwards included - takes the LayerNorm launches.
         self.fold_ln = os.environ.get("PRIMX_DIT_FOLD", "1") != "0"
         self._fold_ws: Dict = {}              # (device, rows) -> (center, part) workspaces of the fold
-        # Dynamic range (fp16 only): the folded operand cast16((x - c)(1 + scale)) is NOT normalised - a residual stream whose rows
-        # spread beyond the fp16 range (|x - c| (1 + scale) > 65504; the synthetic models stay below 1e2, a trained DiT is not known to
-        # come near) overflows there, where the LayerNorm output of the unfolded path cannot.  The sampling loop therefore checks its
-        # final sample once when folded fp16 forwards ran (`fold_overflow_check`: one reduction + one read-back per LOOP) and
-        # raises instead of returning NaNs; bf16 has the range of fp32 and is not checked.  (The cure, not built: scale the operand
-        # by the previous site's rho the way it is centred by the previous site's mean - DESIGN_LOG.md section 10.6.)
+        # Dynamic range (fp16): the folded operand cast16((x - c) rho_p (1 + scale)) is normalised with the PREVIOUS site's (mean, rstd)
+        # of the row (ABI 23) - the LayerNorm output up to the factor rho_p / rho by which one gated branch changes the row's spread.
+        # Magnitude and spread of the residual stream do not enter (tests/test_hip_fold.py: spreads 3e4 and 1e-5, magnitude 1e4); the
+        # reference's own operand cast16(LN (1 + scale) + shift) overflows at |1 + scale| ~ 1900, this one at (rho_p / rho) |1 + scale| ~
+        # 1900.  The sampling loop still looks at its final sample once when folded fp16 forwards ran (`fold_overflowed`) and repeats
+        # the loop with LayerNorm launches if it is non-finite; bf16 has the range of fp32 and is not checked.
         self._fold_fp16_used = False
         self._side: Dict = {}
         self._t_plan: Optional[Dict] = None   # plan_timesteps(): the coming calls' timesteps and their modulation table
@@ -569,7 +569,8 @@ class DiT(nn.Module):
             self._t_plan["row"] = row
 
     def clear_timestep_plan(self) -> None:
-        self._t_plan = None
+        self._t_plan = None                   # (drops the loop's tables: modulation rows and the fold's u / v rows)
+        self._fold_fp16_used = False
 
     def _modulation_table(self, plan: Dict, dt: torch.dtype, pk: Dict) -> torch.Tensor:
         key = (dt, pk["w_ada"].data_ptr())
@@ -615,14 +616,13 @@ class DiT(nn.Module):
         ft = plan["fold"] = {"key": key, "uv": uv}
         return ft
 
-    def fold_overflow_check(self, sample: torch.Tensor) -> None:
-        """Called by the sampling loop when it ends (diffusion/sampler.py): if forwards of this loop ran the LayerNorm fold in fp16,
-        a non-finite sample means the folded operand left the fp16 range (see `fold_ln` in __init__) - raise, do not return NaNs."""
+    def fold_overflowed(self, sample: torch.Tensor) -> bool:
+        """Asked by the sampling loop about its FINAL sample (diffusion/sampler.py `_fold_guard`): did forwards of this loop run the
+        LayerNorm fold in fp16 AND is the sample non-finite?  (One reduction + one read-back per loop, only when the fold ran in
+        fp16.)  The sampler then repeats the loop with LayerNorm launches - see `fold_ln` in __init__ for why this is not expected
+        to happen."""
         used, self._fold_fp16_used = self._fold_fp16_used, False
-        if used and not bool(torch.isfinite(sample).all()):
-            raise FloatingPointError(
-                "non-finite sample after a sampling loop with the fp16 LayerNorm fold: the residual stream of this model leaves the "
-                "fp16 range once centred and scaled - run with PRIMX_DIT_FOLD=0 (model.fold_ln = False) or precision_dtype=bfloat16")
+        return bool(used) and not bool(torch.isfinite(sample).all())
 
     @staticmethod
     def _fold_rows(tab: torch.Tensor, depth: int, D: int) -> torch.Tensor:
@@ -743,6 +743,8 @@ class DiT(nn.Module):
                 self._fold_ws = {wk: ops.fold_workspace(T, D, dev)}
             fcent, fpart = self._fold_ws[wk]
 
+        fside: Dict[int, int] = {}                       # per row range (its b0): which of the fold's two (centre, scale) arrays the current site reads
+
         def warm(*wts):
             return wts if wpf == 1 else ()
 
@@ -762,8 +764,15 @@ class DiT(nn.Module):
                 return (shift, scale, xh, self.LN_EPS, None if sync is None else (sync[:sync_w] if b0 == 0 else sync[sync_w:]))
             # ---- cross-attention to the image tokens (dit_crossattn.py:55, attention.py:96-114)
             folded = fold_uv is not None
-            fc, fp = (fcent[r0:r1], fpart[r0:r1]) if folded else (None, None)
+            fp = fpart[r0:r1] if folded else None
             uvs = fold_uv[i] if folded else None
+
+            def fc_in():                                 # the (centre, scale) pairs the current site's producer used ...
+                return fcent[fside[b0]][r0:r1]
+
+            def fc_flip():                               # ... and where its consumer leaves the next site's: the other array
+                fside[b0] ^= 1
+                return fcent[fside[b0]][r0:r1]
 
             def uv(s):                                   # this call's (u, v) of site s: rows of the planned loop's tables
                 return uvs[s][0, prow], uvs[s][1, prow]
@@ -771,12 +780,13 @@ class DiT(nn.Module):
                 # (the block's cross-attention K / V as the prefetch instead: -1.0 us on that kernel, +0.5 on this one)
                 ops.layernorm_modulate(hh, ch[0], ch[1], N, xh, self.LN_EPS, prefetch=warm(w["w_q"], w["w_cproj"]))
                 if folded:
-                    ops.row_mean(hh, fc)                 # the centre of the first folded site
+                    fside[b0] = 0
+                    ops.row_stats(hh, self.LN_EPS, fc_in())   # (centre, scale) of the first folded site: this LayerNorm's (mean, rstd)
             bc = min(b1, B) if collapse else b1          # batch entries [b0, bc) attend; [bc, b1) are unconditional rows
             if bc > b0:
                 if folded and i > 0:                     # (folded: bc == b1, every row attends)
-                    ops.linear_heads_fold(xh, w["w_q"], N, H, dh, [HEADS_ROWS], [Qc[b0:bc]], nq_pad, fp, *uv(0), fc, self.LN_EPS,
-                                          scale0=scale, carry=carry(w["w_cproj"]))
+                    ops.linear_heads_fold(xh, w["w_q"], N, H, dh, [HEADS_ROWS], [Qc[b0:bc]], nq_pad, fp, *uv(0), fc_in(), fc_flip(),
+                                          self.LN_EPS, scale0=scale, carry=carry(w["w_cproj"]))
                 else:
                     ops.linear_heads(xh[:(bc - b0) * N], w["w_q"], w["b_q"], N, H, dh, [HEADS_ROWS], [Qc[b0:bc]], nq_pad,
                                      scale0=scale, carry=carry(w["w_cproj"]))
@@ -795,7 +805,7 @@ class DiT(nn.Module):
             if hook is not None:
                 hook()
             if folded:                                   # producer of the qkv site
-                ops.linear_gate_residual_fold(ah.view(Th, D), w["w_cproj"], w["b_cproj"], ch[2], hh, N, ch[4], fc, xh, fp,
+                ops.linear_gate_residual_fold(ah.view(Th, D), w["w_cproj"], w["b_cproj"], ch[2], hh, N, ch[4], fc_in(), xh, fp,
                                               carry=carry(w["w_proj"]))
             else:
                 ops.linear_gate_residual(ah.view(Th, D), w["w_cproj"], w["b_cproj"], ch[2], hh, N, carry=carry(w["w_proj"]),
@@ -805,27 +815,28 @@ class DiT(nn.Module):
                 ops.layernorm_modulate(hh, ch[3], ch[4], N, xh, self.LN_EPS, prefetch=warm(w["w_proj"]))
             if folded:
                 ops.linear_heads_fold(xh, w["w_qkv"], N, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT],
-                                      [Qs[b0:b1], Ks[b0:b1], Vs[b0:b1]], nq_pad, fp, *uv(1), fc, self.LN_EPS)
+                                      [Qs[b0:b1], Ks[b0:b1], Vs[b0:b1]], nq_pad, fp, *uv(1), fc_in(), fc_flip(), self.LN_EPS)
             else:
                 ops.linear_heads(xh, w["w_qkv"], w["b_qkv"], N, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT],
                                  [Qs[b0:b1], Ks[b0:b1], Vs[b0:b1]], nq_pad)
             ops.attention(Qs[b0:b1], Ks[b0:b1], Vs[b0:b1], N, N, dh, scale, out=ah)
             if folded:                                   # producer of the fc1 site
-                ops.linear_gate_residual_fold(ah.view(Th, D), w["w_proj"], w["b_proj"], ch[5], hh, N, ch[7], fc, xh, fp)
+                ops.linear_gate_residual_fold(ah.view(Th, D), w["w_proj"], w["b_proj"], ch[5], hh, N, ch[7], fc_in(), xh, fp)
             else:
                 ops.linear_gate_residual(ah.view(Th, D), w["w_proj"], w["b_proj"], ch[5], hh, N, ln=ln_of(ch[6], ch[7]))
             # ---- MLP (dit_crossattn.py:57, models/utils.py:94-101)
             if not fuse:
                 ops.layernorm_modulate(hh, ch[6], ch[7], N, xh, self.LN_EPS, prefetch=warm(w["w_fc2"]))
             if folded:
-                ops.linear_fold(xh, w["w_fc1"], hid[r0:r1], fp, *uv(2), fc, self.LN_EPS, act=ACT_GELU_TANH, carry=carry(w["w_fc2"]))
+                ops.linear_fold(xh, w["w_fc1"], hid[r0:r1], fp, *uv(2), fc_in(), fc_flip(), self.LN_EPS, act=ACT_GELU_TANH,
+                                carry=carry(w["w_fc2"]))
             else:
                 ops.linear(xh, w["w_fc1"], w["b_fc1"], out=hid[r0:r1], act=ACT_GELU_TANH, carry=carry(w["w_fc2"]))
             last = i + 1 == len(blocks)
             nxt = (fin_mod[0][b0:b1], fin_mod[1][b0:b1]) if last else \
                 (mod[b0:b1, (i + 1) * 9 * D:(i + 1) * 9 * D + D], mod[b0:b1, (i + 1) * 9 * D + D:(i + 1) * 9 * D + 2 * D])
             if folded and not last:                      # producer of the next block's to_q site
-                ops.linear_gate_residual_fold(hid[r0:r1], w["w_fc2"], w["b_fc2"], ch[8], hh, N, nxt[1], fc, xh, fp,
+                ops.linear_gate_residual_fold(hid[r0:r1], w["w_fc2"], w["b_fc2"], ch[8], hh, N, nxt[1], fc_in(), xh, fp,
                                               carry=carry(blocks[i + 1]["w_q"]))
             else:                                        # (the final layer's LayerNorm stays a launch: its Linear has 8 columns)
                 ops.linear_gate_residual(hid[r0:r1], w["w_fc2"], w["b_fc2"], ch[8], hh, N,

@@ -301,7 +301,7 @@ def linear_heads(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
         "primx_linear_heads"))
 
 
-# ----------------------------------------------------------------------------- the LayerNorm fold (include/primx_hip.h, ABI 22)
+# ----------------------------------------------------------------------------- the LayerNorm fold (include/primx_hip.h, ABI 23)
 FOLD_TILE = 144     # columns per partial sum of the producer; the consumers read at most FOLD_MAX_PARTS of them per row
 FOLD_MAX_PARTS = 8
 
@@ -317,7 +317,7 @@ def fold_shapes_ok(T: int, rows_per_batch: int, D: int, heads: int) -> bool:
     """Do ALL GEMMs of a DiT block at T = batch entries x rows_per_batch token rows have a fold kernel?  The qkv projection writes a
     V^T segment, which only the 256 x 288 tile's heads epilogue does under the fold: the launch must qualify for it (the rule of
     csrc/gemm.hip launch_fold, including the switches that move it)."""
-    if not fold_supported(D, heads) or rows_per_batch < 128:
+    if not fold_supported(D, heads) or rows_per_batch < 128 or not _lib.fold_available():
         return False
     if os.environ.get("PRIMX_GEMM_NOBIG") == "1" or os.environ.get("PRIMX_GEMM_LOADER") == "0":
         return False
@@ -328,16 +328,20 @@ def fold_shapes_ok(T: int, rows_per_batch: int, D: int, heads: int) -> bool:
 
 
 def fold_workspace(rows: int, D: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(center [rows] fp32, part [rows, D / 144, 2] fp32) of one forward."""
-    return (torch.empty(rows, dtype=torch.float32, device=device),
+    """(center [2, rows, 2] fp32, part [rows, D / 144, 2] fp32) of one forward.  center[k] are the (centre, scale) = (mean, rstd)
+    pairs of the rows at one LayerNorm site; the sites alternate between the two arrays (a consumer reads one, writes the other)."""
+    return (torch.empty(2, rows, 2, dtype=torch.float32, device=device),
             torch.empty(rows, D // FOLD_TILE, 2, dtype=torch.float32, device=device))
 
 
-def row_mean(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """out[r] = mean(x[r, :]) (fp32): the centre of the first folded LayerNorm site of a forward."""
+def row_stats(x: torch.Tensor, eps: float, out: torch.Tensor) -> torch.Tensor:
+    """out[r] = (mean(x[r, :]), 1 / sqrt(var(x[r, :]) + eps)) (fp32, [rows, 2]): the (centre, scale) pair of the first folded
+    LayerNorm site of a forward."""
     rows, D = x.shape
-    check(_lib.load().primx_row_mean(_dev(x, "x", torch.float32), rows, D, _dev(out, "mean", torch.float32), _stream()),
-          "primx_row_mean")
+    if tuple(out.shape) != (rows, 2):
+        raise RuntimeError("row_stats: out must be [rows, 2] fp32")
+    check(_lib.load().primx_row_stats(_dev(x, "x", torch.float32), rows, D, eps, _dev(out, "stats", torch.float32), _stream()),
+          "primx_row_stats")
     return out
 
 
@@ -353,28 +357,33 @@ def linear_f32out(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
     return out
 
 
-def _fold_args(part: torch.Tensor, u: torch.Tensor, v: torch.Tensor, center: torch.Tensor, M: int, N: int, K: int):
-    if K % FOLD_TILE or tuple(part.shape) != (M, K // FOLD_TILE, 2) or center.numel() != M:
-        raise RuntimeError("fold: `part` must be [M, K / 144, 2] and `center` [M] (fp32)")
+def _fold_args(part: torch.Tensor, u: torch.Tensor, v: torch.Tensor, center: torch.Tensor, center_out: torch.Tensor, M: int, N: int,
+               K: int):
+    if K % FOLD_TILE or tuple(part.shape) != (M, K // FOLD_TILE, 2) or tuple(center.shape) != (M, 2) or tuple(center_out.shape) != (M, 2):
+        raise RuntimeError("fold: `part` must be [M, K / 144, 2], `center` and `center_out` [M, 2] (fp32)")
+    if center.data_ptr() == center_out.data_ptr():
+        raise RuntimeError("fold: a consumer writes the next (centre, scale) pairs to ANOTHER array than the one it reads")
     for t, name in ((u, "u"), (v, "v")):
         if t.dtype != torch.float32 or t.numel() != N or not t.is_contiguous() or t.data_ptr() % 16:
             raise RuntimeError(f"fold: {name} must be a contiguous, 16-byte aligned fp32 vector of N elements")
-    return (_dev(part, "part", torch.float32), u.data_ptr(), v.data_ptr(), _dev(center, "center", torch.float32))
+    return (_dev(part, "part", torch.float32), u.data_ptr(), v.data_ptr(), _dev(center, "center", torch.float32),
+            _dev(center_out, "center_out", torch.float32))
 
 
 def linear_gate_residual_fold(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], gate: torch.Tensor, x: torch.Tensor,
                               rows_per_batch: int, next_scale: torch.Tensor, center: torch.Tensor, a16: torch.Tensor,
                               part: torch.Tensor, carry: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """linear_gate_residual as the PRODUCER of the LayerNorm site behind it: also a16[m] = cast16((x[m] - center[m]) cast16(1 +
-    next_scale[b])) and the per-tile partial sums of (x - center), (x - center)^2 into `part`."""
+    """linear_gate_residual as the PRODUCER of the LayerNorm site behind it: with (c, rho_p) = center[m] also
+    a16[m] = cast16((x[m] - c) rho_p cast16(1 + next_scale[b])) and the per-tile partial sums of (x - c), (x - c)^2 into `part`."""
     M, K = A.shape
     N = W.shape[0]
     if gate.stride(-1) != 1 or gate.dtype != A.dtype or not gate.is_cuda:
         raise RuntimeError("gate must be a last-dim-contiguous 16-bit device view")
     if next_scale.stride(-1) != 1 or next_scale.dtype != A.dtype or not next_scale.is_cuda or next_scale.shape[-1] != N:
         raise RuntimeError("next_scale must be a last-dim-contiguous 16-bit device view of N columns")
-    if tuple(a16.shape) != (M, N) or a16.dtype != A.dtype or tuple(part.shape) != (M, N // FOLD_TILE, 2) or center.numel() != M:
-        raise RuntimeError("linear_gate_residual_fold: a16 must be [M, N] 16-bit, part [M, N / 144, 2], center [M]")
+    if tuple(a16.shape) != (M, N) or a16.dtype != A.dtype or tuple(part.shape) != (M, N // FOLD_TILE, 2) or \
+            tuple(center.shape) != (M, 2):
+        raise RuntimeError("linear_gate_residual_fold: a16 must be [M, N] 16-bit, part [M, N / 144, 2], center [M, 2]")
     cp, cn = _range(carry)
     _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_gate_residual_fold(
         _dev(A, "A"), _dev(W, "W", A.dtype), _dev(bias, "bias", A.dtype) if bias is not None else None,
@@ -386,31 +395,34 @@ def linear_gate_residual_fold(A: torch.Tensor, W: torch.Tensor, bias: Optional[t
 
 def linear_heads_fold(A: torch.Tensor, W: torch.Tensor, rows_per_batch: int, heads: int, dh: int, kinds: Sequence[int],
                       dsts: Sequence[torch.Tensor], n_pad: int, part: torch.Tensor, u: torch.Tensor, v: torch.Tensor,
-                      center: torch.Tensor, eps: float, scale0: float = 1.0, carry: Optional[torch.Tensor] = None) -> None:
-    """linear_heads as the CONSUMER of a folded LayerNorm site: A = the producer's a16; the Linear's bias is part of v."""
+                      center: torch.Tensor, center_out: torch.Tensor, eps: float, scale0: float = 1.0,
+                      carry: Optional[torch.Tensor] = None) -> None:
+    """linear_heads as the CONSUMER of a folded LayerNorm site: A = the producer's a16, `center` the pairs the producer used; the
+    Linear's bias is part of v; `center_out` receives this site's (mean, rstd) - the next producer's pairs."""
     M, K = A.shape
     N = W.shape[0]
     n_seg = len(kinds)
     kind_arr = (C.c_int * n_seg)(*kinds)
     dst_arr = (C.c_void_p * n_seg)(*[_dev(d, "dst", A.dtype) for d in dsts])
-    fa = _fold_args(part, u, v, center, M, N, K)
+    fa = _fold_args(part, u, v, center, center_out, M, N, K)
     cp, cn = _range(carry)
     _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_heads_fold(
         _dev(A, "A"), _dev(W, "W", A.dtype), M, N, K, rows_per_batch, heads, dh, n_seg, kind_arr, dst_arr, n_pad, scale0,
-        fa[0], fa[1], fa[2], fa[3], eps, dtype_code(A.dtype), cp, cn, _stream()), "primx_linear_heads_fold"))
+        fa[0], fa[1], fa[2], fa[3], fa[4], eps, dtype_code(A.dtype), cp, cn, _stream()), "primx_linear_heads_fold"))
 
 
 def linear_fold(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, part: torch.Tensor, u: torch.Tensor, v: torch.Tensor,
-                center: torch.Tensor, eps: float, act: int = ACT_NONE, carry: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """linear as the CONSUMER of a folded LayerNorm site (fc1 + GELU)."""
+                center: torch.Tensor, center_out: torch.Tensor, eps: float, act: int = ACT_NONE,
+                carry: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """linear as the CONSUMER of a folded LayerNorm site (fc1 + GELU); center / center_out as in linear_heads_fold."""
     M, K = A.shape
     N = W.shape[0]
     if tuple(out.shape) != (M, N) or out.dtype != A.dtype:
         raise RuntimeError("linear_fold: out must be a 16-bit [M, N] tensor of A's dtype")
-    fa = _fold_args(part, u, v, center, M, N, K)
+    fa = _fold_args(part, u, v, center, center_out, M, N, K)
     cp, cn = _range(carry)
     _timed(f"None {M}x{N}x{K}", 2.0 * M * N * K, lambda: check(_lib.load().primx_linear_fold(
-        _dev(A, "A"), _dev(W, "W", A.dtype), _dev(out, "out"), M, N, K, act, fa[0], fa[1], fa[2], fa[3], eps,
+        _dev(A, "A"), _dev(W, "W", A.dtype), _dev(out, "out"), M, N, K, act, fa[0], fa[1], fa[2], fa[3], fa[4], eps,
         dtype_code(A.dtype), cp, cn, _stream()), "primx_linear_fold"))
     return out
 

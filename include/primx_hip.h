@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 22
+#define PRIMX_ABI_VERSION 23
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -164,32 +164,36 @@ int primx_linear_gate_residual_ln(const void* A, const void* W, const void* bias
  * Synchronises with the device.  ABI 21. */
 int primx_ln_sync_timeouts(void);
 
-/* ---- The LayerNorm fold (ABI 22).  Every LayerNorm + modulate of a DiT block sits between a gated residual add and a Linear
- * (models/dit_crossattn.py:55-57).  With the row statistics mu, rho of the fp32 residual stream x, m = cast16(1 + scale) and any
- * per-row centre c:
+/* ---- The LayerNorm fold (ABI 22; range-safe operand since ABI 23).  Every LayerNorm + modulate of a DiT block sits between a
+ * gated residual add and a Linear (models/dit_crossattn.py:55-57).  With the row statistics mu, rho of the fp32 residual stream x,
+ * m = cast16(1 + scale), any per-row centre c and any per-row scale rho_p > 0:
  *     reference:  y = cast16( cast16( (x - mu) rho m + shift ) W^T + b )
- *     folded:     y = cast16( rho ( cast16((x - c) m) W^T  -  (mu - c) u ) + v ),    u = m W^T,  v = shift W^T + b   (fp32 rows)
- * so the gate-residual GEMM in front of the LayerNorm (the PRODUCER) can store the 16-bit operand a16 = cast16((x - c) m) and
+ *     folded:     y = cast16( (rho / rho_p) cast16((x - c) rho_p m) W^T - rho (mu - c) u + v ),   u = m W^T,  v = shift W^T + b   (fp32 rows)
+ * so the gate-residual GEMM in front of the LayerNorm (the PRODUCER) can store the 16-bit operand a16 = cast16((x - c) rho_p m) and
  * per-column-tile partial sums of (x - c), (x - c)^2, and the Linear behind it (the CONSUMER: to_q, qkv, fc1) can finish mu, rho
- * from the partials and apply them with u, v in its epilogue - no LayerNorm launch, no second pass over the fp32 rows.  The
- * fold rounds (x - c) m where the reference rounds the normalised value: equal accuracy while |mu - c| stays below the row's
- * spread (tools/ln_fold_study.py), which is why c follows the row mean from site to site (the consumer moves it).  Range: the folded
- * operand carries the row's spread (the LayerNorm output does not), so with PRIMX_F16 the caller must know |x - c| (1 + scale) < 65504
- * (the DiT driver checks the finished sample of every fp16 loop); PRIMX_BF16 has the range of fp32.  u, v depend
- * on the timestep only (primx_linear_f32out, once per planned sampling loop).  Shapes: N of the producer = K of the consumer =
- * a multiple of 144, at most 1152; everything else returns PRIMX_EINVAL and the caller keeps primx_layernorm_modulate. */
+ * from the partials and apply them with u, v in its epilogue - no LayerNorm launch, no second pass over the fp32 rows.
+ * `center` is an array of (c, rho_p) PAIRS, [rows][2] fp32: the row's (mean, rstd) at the previous LayerNorm site - primx_row_stats
+ * in front of the first site, afterwards what the previous consumer wrote to its `center_out`.  With them the operand is the
+ * LayerNorm output up to what ONE gated branch changes mean and spread by: the accuracy of the reference's rounding (which rounds
+ * the normalised value; tools/ln_fold_study.py) and - ABI 23 - its RANGE: |a16| = O(|1 + scale|) whatever the magnitude or spread
+ * of the residual stream, in PRIMX_F16 as in PRIMX_BF16 (ABI 22 stored cast16((x - c) m), which carried the row's spread).
+ * A consumer reads `center` (all its column tiles need rho_p) and writes the next pair to `center_out`, which must be a different
+ * array: callers alternate two.  u, v depend on the timestep only (primx_linear_f32out, once per planned sampling loop).
+ * Shapes: N of the producer = K of the consumer = a multiple of 144, at most 1152; everything else returns PRIMX_EINVAL and the
+ * caller keeps primx_layernorm_modulate. */
 
 /* out[m, n] (fp32) = sum_k A[m, k] W[n, k] + (m >= bias_from_row ? bias[n] : 0): fp32 rows out of 16-bit operands.  The fold's
  * u rows (A = cast16(1 + scale) of each planned timestep, no bias) and v rows (A = shift, bias = the Linear's) in one launch. */
 int primx_linear_f32out(const void* A, const void* W, const void* bias, float* out, int M, int N, int K, int bias_from_row,
                         int dtype, void* stream);
 
-/* mean[r] = mean(x[r, :]) in fp32: the centre c of the first folded site of a forward (D % 4 == 0). */
-int primx_row_mean(const float* x, int rows, int D, float* mean, void* stream);
+/* stats[r] = (mean(x[r, :]), 1 / sqrt(var(x[r, :]) + eps)) in fp32, [rows][2]: the (c, rho_p) pair of the first folded site of a
+ * forward - the statistics primx_layernorm_modulate uses for the same rows (D % 4 == 0).  ABI 23 (replaces primx_row_mean). */
+int primx_row_stats(const float* x, int rows, int D, float eps, float* stats, void* stream);
 
-/* primx_linear_gate_residual that is also the PRODUCER of the LayerNorm site behind it:
- *   x[m, :] += cast16(gate[b, :] * cast16(A W^T + bias)[m, :]);   a16_out[m, :] = cast16( (x[m, :] - center[m]) * cast16(1 + next_scale[b, :]) );
- *   part_out[m, t, 0 / 1] = sum over the 144 columns of tile t of (x - center), (x - center)^2      (t < N / 144, fixed summation order).
+/* primx_linear_gate_residual that is also the PRODUCER of the LayerNorm site behind it ((c, rho_p) = center[m][0 / 1]):
+ *   x[m, :] += cast16(gate[b, :] * cast16(A W^T + bias)[m, :]);   a16_out[m, :] = cast16( (x[m, :] - c) * rho_p * cast16(1 + next_scale[b, :]) );
+ *   part_out[m, t, 0 / 1] = sum over the 144 columns of tile t of (x - c), (x - c)^2      (t < N / 144, fixed summation order).
  * next_scale: the 16-bit scale vectors of the NEXT LayerNorm's modulate, element stride next_mod_stride between batch entries. */
 int primx_linear_gate_residual_fold(const void* A, const void* W, const void* bias, const void* gate, int64_t gate_stride,
                                     float* x, int M, int N, int K, int rows_per_batch, const void* next_scale,
@@ -197,17 +201,19 @@ int primx_linear_gate_residual_fold(const void* A, const void* W, const void* bi
                                     const void* prefetch, int64_t prefetch_bytes, void* stream);
 
 /* primx_linear_heads (n_rep = 1) as the CONSUMER of a folded site: A = the producer's a16, `part` its partial sums (K / 144 per
- * row), u / v = fp32 vectors of N columns (16-byte aligned; the Linear's bias is part of v), eps = the LayerNorm's.  The
- * workgroups of column tile 0 add each row's mean of (x - center) to center[m] (the next producer's centre). */
+ * row), `center` the (c, rho_p) pairs the producer used, u / v = fp32 vectors of N columns (16-byte aligned; the Linear's bias is
+ * part of v), eps = the LayerNorm's.  The workgroups of column tile 0 write center_out[m] = (c + mean(x - c), rho): the next
+ * producer's pair (center_out != center). */
 int primx_linear_heads_fold(const void* A, const void* W, int M, int N, int K, int rows_per_batch, int heads, int dh, int n_seg,
                             const int* kind, void* const* dst, int n_pad, float scale0, const float* part, const float* u,
-                            const float* v, float* center, float eps, int dtype, const void* prefetch, int64_t prefetch_bytes,
-                            void* stream);
+                            const float* v, const float* center, float* center_out, float eps, int dtype, const void* prefetch,
+                            int64_t prefetch_bytes, void* stream);
 
-/* primx_linear (out_scale = 1) as the CONSUMER of a folded site (fc1 + GELU): out = act(cast16(rho (a16 W^T - mu' u) + v)). */
+/* primx_linear (out_scale = 1) as the CONSUMER of a folded site (fc1 + GELU):
+ * out = act(cast16((rho / rho_p) a16 W^T - rho mu' u + v)); center / center_out as above. */
 int primx_linear_fold(const void* A, const void* W, void* out, int M, int N, int K, int act, const float* part, const float* u,
-                      const float* v, float* center, float eps, int dtype, const void* prefetch, int64_t prefetch_bytes,
-                      void* stream);
+                      const float* v, const float* center, float* center_out, float eps, int dtype, const void* prefetch,
+                      int64_t prefetch_bytes, void* stream);
 
 /* Projection whose output columns are `n_rep` repetitions of `n_seg` groups of (heads * dh) features
  * (N = n_rep * n_seg * heads * dh), each group written straight into an attention operand layout (see

@@ -1,7 +1,9 @@
-"""GPU parity of the LayerNorm fold (include/primx_hip.h, ABI 22; csrc/gemm.hip "LayerNorm fold"): the gate-residual GEMM as the
-PRODUCER of a LayerNorm site (16-bit centred operand + partial row sums next to the residual update), the three CONSUMER GEMMs
-(to_q / qkv / fc1 forms: statistics from the partials, y = rho (acc - mu' u) + v in the epilogue), the fp32-row GEMM of u / v, and
-the DiT with `fold_ln` against the unfolded path and the fp32 oracle.
+"""GPU parity of the LayerNorm fold (include/primx_hip.h, ABI 23; csrc/gemm.hip "LayerNorm fold"): the gate-residual GEMM as the
+PRODUCER of a LayerNorm site (16-bit operand centred and scaled with the previous site's (mean, rstd) + partial row sums next to
+the residual update), the three CONSUMER GEMMs (to_q / qkv / fc1 forms: statistics from the partials,
+y = (rho / rho_p) acc - rho mu' u + v in the epilogue), the fp32-row GEMM of u / v, the dynamic range of the operand in fp16
+(row spreads 3e4 and 1e-5, magnitudes 1e4: `test_fold_is_range_safe`), and the DiT with `fold_ln` against the unfolded path
+and the fp32 oracle.
 
 What is compared with what: a float64 LayerNorm -> modulate -> Linear of the UPDATED residual rows (the reference's arithmetic,
 models/dit_crossattn.py:32-36,55-57) is the truth; the folded chain must meet it with the tolerance of one 16-bit rounding of the
@@ -45,11 +47,17 @@ def _last_kernel(ops):
     return _lib.load().primx_last_gemm_kernel().decode()
 
 
-def test_row_mean(ops):
-    x = (synth.tensor(3, "x", (300, 1152)) * 3 + 0.7).to(DEV)
-    out = torch.empty(300, device=DEV)
-    ops.row_mean(x, out)
-    assert max_abs(out, x.double().mean(-1)) < 2e-6
+@pytest.mark.parametrize("spread,offset", [(3.0, 0.7), (3e4, -1e4), (1e-5, 1e4), (1e-5, 0.0)])
+def test_row_stats(ops, spread, offset):
+    """(mean, rstd) pairs of fp32 rows - the statistics of primx_layernorm_modulate - against float64."""
+    x = (synth.tensor(3, "x", (300, 1152)) * spread + offset).to(DEV)
+    out = torch.full((300, 2), float("nan"), device=DEV)
+    ops.row_stats(x, EPS, out)
+    xd = x.double().cpu()
+    mean = xd.mean(-1)
+    rstd = 1 / torch.sqrt(((xd - mean[:, None]) ** 2).mean(-1) + EPS)
+    assert max_abs(out[:, 0], mean) < 2e-6 * max(1.0, abs(offset), spread)
+    assert float(((out[:, 1].cpu().double() - rstd) / rstd).abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -69,25 +77,31 @@ def test_linear_f32out(ops, dtype, M, N, K, frm):
     assert rel_l2(out2, A.double() @ W.double().t()) < 2e-6
 
 
-def _site(seed, B, n, D, K, dtype, mean_ratio=0.3):
+def _site(seed, B, n, D, K, dtype, mean_ratio=0.3, spread=2.0, offset=0.0, branch=1.0):
     """Inputs of one folded LayerNorm site: the branch operand A [B n, K] and weights of the PRODUCER (N = D), the residual
-    stream x with a per-row mean of `mean_ratio` x its spread, gate / shift / scale vectors per batch entry, and the centre c
-    (the row mean one branch ago: the true mean of x plus a perturbation of a tenth of the spread)."""
+    stream x - row spread `spread`, a per-row mean of `mean_ratio` x the spread (+ `offset` with a per-row sign), gate (scaled
+    by `branch`) / shift / scale vectors per batch entry - and the (centre, scale) pairs of the rows one branch ago: the true
+    (mean, rstd) of x, the mean perturbed by a tenth of the spread and the rstd by 10 %."""
     M = B * n
     A = synth.tensor(seed, "A", (M, K)).to(dtype)
     W = synth.tensor(seed, "W", (D, K), K ** -0.5).to(dtype)
     b = synth.tensor(seed, "b", (D,), 0.3).to(dtype)
-    mod = synth.tensor(seed, "mod", (B, 3 * D), 0.4).to(dtype)
-    x = synth.tensor(seed, "x", (M, D)) * 2.0
+    mod = synth.tensor(seed, "mod", (B, 3 * D), 0.4)
+    mod[:, :D] *= branch
+    mod = mod.to(dtype)
+    x = synth.tensor(seed, "x", (M, D)) * spread
     x = x + mean_ratio * x.std(-1, keepdim=True) * synth.tensor(seed, "mr", (M, 1))
-    c = x.mean(-1) + 0.1 * x.std(-1) * synth.tensor(seed, "cn", (M,))
-    return A, W, b, mod, x, c.float().contiguous()
+    x = (x + offset * torch.sign(synth.tensor(seed, "sg", (M, 1)))).float()
+    xd = x.double()
+    c = xd.mean(-1) + 0.1 * xd.std(-1) * synth.tensor(seed, "cn", (M,)).double()
+    rp = (1 + 0.1 * synth.tensor(seed, "rn", (M,)).clamp(-2, 2).double()) / torch.sqrt(xd.var(-1, unbiased=False) + EPS)
+    return A, W, b, mod, x, torch.stack([c, rp], -1).float().contiguous()
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("B,n,K", [(2, 2048, 1152), (2, 2048, 4608), (2, 487, 192), (1, 130, 64), (8, 2048, 192), (7, 2100, 64)])
 def test_fold_producer(ops, dtype, B, n, K):
-    """x: the same bits as the plain gate-residual GEMM.  a16: EXACTLY cast16((x_new - c) cast16(1 + scale)) of the stored rows.
+    """x: the same bits as the plain gate-residual GEMM.  a16: EXACTLY cast16(((x_new - c) rho_p) cast16(1 + scale)) of the stored rows.
     Partial sums: the 144-column sums of (x_new - c) and its square (fp32, fixed order) against float64.  The last two shapes are
     a large batch (>= 14336 rows): the 256 x 288 tile, whose register epilogue forms the partial sums by lane shuffles."""
     D = 1152
@@ -107,9 +121,9 @@ def test_fold_producer(ops, dtype, B, n, K):
         assert torch.equal(x_fold, x_plain)
     else:
         assert rel_l2(x_fold, x_plain) < 1e-5
-    d = x_fold.cpu() - c[:, None]                                                   # fp32, as the kernel forms it
+    d = x_fold.cpu() - c[:, :1]                                                     # fp32, as the kernel forms it
     m16 = (1 + scale).float().repeat_interleave(n, 0)                               # (1 + scale) formed in the 16-bit type
-    assert torch.equal(a16.cpu(), (d * m16).to(dtype))
+    assert torch.equal(a16.cpu(), ((d * c[:, 1:]) * m16).to(dtype))
     dd = d.double().view(M, D // 144, 144)
     want = torch.stack([dd.sum(-1), (dd * dd).sum(-1)], -1)
     assert max_abs(part[..., 0], want[..., 0]) < 1e-5 * float(dd.abs().sum(-1).max())
@@ -126,12 +140,12 @@ def _ln_linear_ref(x_new, shift, scale, n, W, b, dtype):
     return a @ W.double().t() + (0 if b is None else b.double())
 
 
-def _chain(ops, dtype, B, n, Wc, bc, seed, consumer, mean_ratio=0.3):
-    """Producer (N = 1152, K = 1152) -> consumer `consumer(a16, part, u, v, cdev)` against the float64 reference and the unfolded
-    HIP path.  Returns (x_new, reference [M, Nc], LayerNorm output of the unfolded path, the centre before / after)."""
+def _chain(ops, dtype, B, n, Wc, bc, seed, consumer, **site):
+    """Producer (N = 1152, K = 1152) -> consumer `consumer(a16, part, u, v, center, center_out)` against the float64 reference and
+    the unfolded HIP path.  Returns (reference [M, Nc], LayerNorm output of the unfolded path)."""
     D = 1152
     M = B * n
-    A, W, b, mod, x, c = _site(seed, B, n, D, D, dtype, mean_ratio)
+    A, W, b, mod, x, c = _site(seed, B, n, D, D, dtype, **site)
     shift, scale = mod[:, D:2 * D], mod[:, 2 * D:]
     modd = mod.to(DEV)
     xd = x.to(DEV)
@@ -144,11 +158,18 @@ def _chain(ops, dtype, B, n, Wc, bc, seed, consumer, mean_ratio=0.3):
     rows = torch.stack([(1 + scale[0]), shift[0]]).to(dtype).to(DEV)
     uv = torch.empty(2, Wc.shape[0], device=DEV)
     ops.linear_f32out(rows, Wc.to(DEV), None if bc is None else bc.to(DEV), uv, 1)
-    consumer(a16, part, uv[0], uv[1], cdev)
+    assert bool(torch.isfinite(a16.float()).all())
+    cnext = torch.full((M, 2), float("nan"), device=DEV)
+    consumer(a16, part, uv[0], uv[1], cdev, cnext)
+    assert torch.equal(cdev.cpu(), c)                                           # a consumer never touches the pairs it reads
     x_new = xd.cpu()
     ref = _ln_linear_ref(x_new, shift[:1].expand(B, -1), scale[:1].expand(B, -1), n, Wc, bc, dtype)
-    # the centre has moved to the row mean of the updated stream
-    assert max_abs(cdev, x_new.double().mean(-1)) < 2e-5 * float(x_new.abs().max())
+    # the next site's pairs: (mean, rstd) of the updated stream
+    xn64 = x_new.double()
+    mu = xn64.mean(-1)
+    rstd = 1 / torch.sqrt(xn64.var(-1, unbiased=False) + EPS)
+    assert max_abs(cnext[:, 0], mu) < 2e-5 * float(x_new.abs().max())
+    assert float(((cnext[:, 1].cpu().double() - rstd) / rstd).abs().max()) < 2e-3
     xn = torch.empty(M, D, dtype=dtype, device=DEV)
     m0 = modd[:1].expand(B, -1)
     ops.layernorm_modulate(xd, m0[:, D:2 * D], m0[:, 2 * D:], n, xn, EPS)
@@ -169,8 +190,8 @@ def test_fold_consumer_to_q(ops, dtype, B, n):
     Q = ops.alloc_heads(B, H, n, dh, HEADS_ROWS, dtype, DEV, 128)
     names = []
 
-    def consumer(a16, part, u, v, c):
-        ops.linear_heads_fold(a16, Wc.to(DEV), n, H, dh, [HEADS_ROWS], [Q], Q.shape[2], part, u, v, c, EPS, scale0=s0)
+    def consumer(a16, part, u, v, c, cn):
+        ops.linear_heads_fold(a16, Wc.to(DEV), n, H, dh, [HEADS_ROWS], [Q], Q.shape[2], part, u, v, c, cn, EPS, scale0=s0)
         names.append(_last_kernel(ops))
     ref, xn = _chain(ops, dtype, B, n, Wc, bq, 31, consumer)
     want = (s0 * ref.to(dtype).float()).to(dtype).view(B, n, H, dh)
@@ -196,8 +217,8 @@ def test_fold_consumer_qkv(ops, dtype):
     bufs = [ops.alloc_heads(B, H, n, dh, k, dtype, DEV, 128) for k in (HEADS_ROWS, HEADS_KROWS, HEADS_VT)]
     names = []
 
-    def consumer(a16, part, u, v, c):
-        ops.linear_heads_fold(a16, Wc.to(DEV), n, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT], bufs, bufs[0].shape[2], part, u, v, c, EPS)
+    def consumer(a16, part, u, v, c, cn):
+        ops.linear_heads_fold(a16, Wc.to(DEV), n, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT], bufs, bufs[0].shape[2], part, u, v, c, cn, EPS)
         names.append(_last_kernel(ops))
     ref, xn = _chain(ops, dtype, B, n, Wc, bc, 32, consumer)
     want = ref.to(dtype).view(B, n, 3, H, dh)
@@ -228,8 +249,8 @@ def test_fold_consumer_fc1(ops, dtype, B, n, kernel):
     out = torch.empty(B * n, Hm, dtype=dtype, device=DEV)
     names = []
 
-    def consumer(a16, part, u, v, c):
-        ops.linear_fold(a16, Wc.to(DEV), out, part, u, v, c, EPS, act=ACT_GELU_TANH)
+    def consumer(a16, part, u, v, c, cn):
+        ops.linear_fold(a16, Wc.to(DEV), out, part, u, v, c, cn, EPS, act=ACT_GELU_TANH)
         names.append(_last_kernel(ops))
     ref, xn = _chain(ops, dtype, B, n, Wc, bc, 33, consumer)
     want = torch.nn.functional.gelu(ref.to(dtype).double(), approximate="tanh")
@@ -250,13 +271,42 @@ def test_fold_large_row_mean_is_what_the_centre_is_for(ops):
     Wc = synth.tensor(34, "W", (D, D), D ** -0.5).to(dtype)
     out = torch.empty(B * n, D, dtype=dtype, device=DEV)
 
-    def consumer(a16, part, u, v, c):
-        ops.linear_fold(a16, Wc.to(DEV), out, part, u, v, c, EPS, act=ACT_NONE)
+    def consumer(a16, part, u, v, c, cn):
+        ops.linear_fold(a16, Wc.to(DEV), out, part, u, v, c, cn, EPS, act=ACT_NONE)
     ref, xn = _chain(ops, dtype, B, n, Wc, None, 34, consumer, mean_ratio=20.0)
     unf = ops.linear(xn, Wc.to(DEV), None)
     err, err_u = rel_l2(out, ref), rel_l2(unf, ref)
     print(f"row mean = 20 sigma: folded {err:.2e}, unfolded {err_u:.2e}")
     assert err < 1.5 * err_u + 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("spread,offset,branch", [(3e4, 0.0, 1.0), (3e4, 1e4, 1.0), (2.0, 1e4, 1.0), (1e-5, 0.0, 1e-5), (1e-5, 0.0, 1.0),
+                                                  (1e-5, 1e4, 1e-5)])
+def test_fold_is_range_safe(ops, dtype, spread, offset, branch):
+    """The dynamic range of the folded operand (the reason for ABI 23): the reference normalises BEFORE it rounds to 16 bits
+    (models/dit_crossattn.py:32-36,55-57; models/utils.py:19-20), so neither the magnitude nor the spread of the residual stream
+    can overflow or flush a Linear input.  The fold's operand is scaled by the previous site's rstd, so the same holds: row
+    spreads of 3e4 (cast16((x - c) m) of ABI 22 overflows fp16 there) and 1e-5 (fp16 subnormals there), residual magnitudes of
+    1e4, a branch that multiplies the spread by 4e4 in one step ((1e-5, 0, 1): rho_p / rho = 400) - the folded result keeps the
+    unfolded path's accuracy against the float64 LayerNorm -> modulate -> Linear, and the operand is finite.  Through the
+    128 x 144 producer / consumer (B n = 1024) and, for one case, the configs[1] kernels."""
+    from topia_xl_amd._lib import ACT_GELU_TANH
+    D, Hm = 1152, 4608
+    Wc = synth.tensor(35, "Wfc1", (Hm, D), D ** -0.5).to(dtype)
+    bc = synth.tensor(35, "bfc1", (Hm,), 0.3).to(dtype)
+    for B, n in ([(1, 1024), (2, 2048)] if (spread, offset) == (3e4, 1e4) else [(1, 1024)]):
+        out = torch.full((B * n, Hm), float("nan"), dtype=dtype, device=DEV)
+
+        def consumer(a16, part, u, v, c, cn):
+            ops.linear_fold(a16, Wc.to(DEV), out, part, u, v, c, cn, EPS, act=ACT_GELU_TANH)
+        ref, xn = _chain(ops, dtype, B, n, Wc, bc, 35, consumer, spread=spread, offset=offset, branch=branch)
+        want = torch.nn.functional.gelu(ref.to(dtype).double(), approximate="tanh")
+        unf = ops.linear(xn, Wc.to(DEV), bc.to(DEV), act=ACT_GELU_TANH)
+        err, err_u = rel_l2(out, want), rel_l2(unf, want)
+        print(f"range {dtype} spread {spread:g} offset {offset:g} branch {branch:g} rows {B * n}: folded {err:.2e}, unfolded {err_u:.2e}")
+        assert bool(torch.isfinite(out.float()).all())
+        assert err < 2 * TOL[dtype] and err < 1.5 * err_u + 1e-4
 
 
 def test_fold_shape_errors(ops):
@@ -267,10 +317,14 @@ def test_fold_shape_errors(ops):
     W = torch.zeros(1280, 1152, dtype=dtype, device=DEV)          # N % 144 != 0
     out = torch.zeros(256, 1280, dtype=dtype, device=DEV)
     part = torch.zeros(256, 8, 2, device=DEV)
-    c = torch.zeros(256, device=DEV)
+    c = torch.ones(256, 2, device=DEV)
     u = torch.zeros(1280, device=DEV)
     with pytest.raises(PrimxError):
-        ops.linear_fold(A, W, out, part, u, u, c, EPS)
+        ops.linear_fold(A, W, out, part, u, u, c, torch.ones_like(c), EPS)
+    W2 = torch.zeros(1152, 1152, dtype=dtype, device=DEV)
+    u2 = torch.zeros(1152, device=DEV)
+    with pytest.raises(RuntimeError):                              # a consumer must not write the pairs it reads
+        ops.linear_fold(A, W2, torch.zeros(256, 1152, dtype=dtype, device=DEV), part, u2, u2, c, c, EPS)
     assert not ops.fold_supported(384, 6) and ops.fold_supported(1152, 16)
     assert ops.fold_shapes_ok(4096, 2048, 1152, 16) == _default_dispatch() or not _default_dispatch()
     assert not ops.fold_shapes_ok(2048, 2048, 1152, 16)
