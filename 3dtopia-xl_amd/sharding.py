@@ -8,8 +8,9 @@ unit of sharding is the user sample and the DDIM loop itself needs NO collective
              large broadcast is link-efficient on point-to-point xGMI, 515 small ones are latency-bound)
              scatter(noise), scatter(conditioning)   (rank 0 draws the whole batch's INITIAL noise from one seeded CPU
              generator, so a seed gives the same starting latents for any world size - the role of the seeded
-             `torch.randn` of inference.py:251,316.  It is not a replay of the reference process's global RNG stream:
-             the reference also draws an unused noise tensor per DDIM step at eta = 0, see diffusion/sampler.py)
+             `torch.randn` of inference.py:251,316.  `reference_rng=True` replays the reference CLI's own draws instead
+             (global `manual_seed`, the unused `randn(1, N, 1, 4, 4, 4)`, then the noise: `initial_noise`) - seed 42 then
+             gives the CLI's seed-42 latents)
     loop   : per-rank ``ddim_sample_loop`` on its slice            (zero collectives)
     end    : gather(samples) to rank 0
 
@@ -140,6 +141,28 @@ def gather_batch(local: torch.Tensor, n_items: int, dst: int = 0) -> Optional[to
     return torch.cat([b[:h - l] for b, (l, h) in zip(bufs, bounds)], dim=0)
 
 
+def initial_noise(batch: int, n_tokens: int, channels: int, seed: Optional[int], reference_rng: bool = False) -> torch.Tensor:
+    """The [batch, n_tokens, channels] starting latents, drawn on the CPU by rank 0.
+
+    Default: a private generator seeded with `seed` (no global state touched) - reproducible for any world size.
+
+    `reference_rng=True`: the draws of the reference CLI, in its order and from the process-GLOBAL CPU generator
+    (inference.py:251,313,316): `torch.manual_seed(seed)` (skipped when `seed` is None: the caller seeded, as inference.py does
+    once per process, and every call continues the stream like the CLI's per-image loop), then the unused
+    `torch.randn(1, n_tokens, 1, 4, 4, 4)`, then `torch.randn(batch, n_tokens, channels)`.  With batch = 1 (`inf_bs` of the CLI) the
+    latents are the CLI's for the same seed and the same draws before them (the CLI constructs its modules between the seeding and
+    the first image: a caller that wants its numbers seeds, builds the models in that order, and passes seed=None here); for a
+    larger batch entry 0 is still the CLI's sample whenever n_tokens * channels is a multiple of 16 (torch fills normal draws
+    in blocks of 16)."""
+    if not reference_rng:
+        gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        return torch.randn(batch, n_tokens, channels, generator=gen)              # CPU draw, as inference.py:316
+    if seed is not None:
+        torch.manual_seed(seed)
+    torch.randn(1, n_tokens, 1, 4, 4, 4)                                           # inference.py:313 (`latent`: only its shape is used)
+    return torch.randn(batch, n_tokens, channels)
+
+
 class ShardedSampler:
     """Batch-sharded DDIM sampling over the ranks of the default process group."""
 
@@ -157,13 +180,13 @@ class ShardedSampler:
                                  else broadcast_module_(model, 0))
 
     def sample(self, batch: int, n_tokens: int, channels: int, cond: Optional[torch.Tensor], seed: Optional[int],
-               loop: Optional[Callable] = None, **model_kwargs) -> Optional[torch.Tensor]:
+               loop: Optional[Callable] = None, reference_rng: bool = False, **model_kwargs) -> Optional[torch.Tensor]:
         """cond: [batch, L, Dc] on rank 0 (None elsewhere).  Returns the [batch, n_tokens, channels] samples on
-        rank 0.  ``loop(noise_slice, cond_slice) -> samples`` overrides the DDIM call (used by the CPU tests)."""
+        rank 0.  ``loop(noise_slice, cond_slice) -> samples`` overrides the DDIM call (used by the CPU tests).
+        ``reference_rng``: draw the starting latents exactly as the reference CLI does (`initial_noise`)."""
         noise = None
         if self.rank == 0:
-            gen = torch.Generator().manual_seed(seed) if seed is not None else None
-            noise = torch.randn(batch, n_tokens, channels, generator=gen)        # CPU draw, as inference.py:316
+            noise = initial_noise(batch, n_tokens, channels, seed, reference_rng)
         cond_tail = None
         if not _single(self.world):
             meta = [tuple(cond.shape[1:])] if self.rank == 0 else [None]
@@ -185,15 +208,14 @@ class ShardedSampler:
 
     def sample_and_decode(self, batch: int, n_tokens: int, channels: int, cond: Optional[torch.Tensor],
                           seed: Optional[int], decode: Callable[[torch.Tensor], torch.Tensor],
-                          loop: Optional[Callable] = None, **model_kwargs) -> Optional[torch.Tensor]:
+                          loop: Optional[Callable] = None, reference_rng: bool = False, **model_kwargs) -> Optional[torch.Tensor]:
         """`sample`, then every rank decodes ITS OWN samples (`decode(samples [b, N, C]) -> [b, N, F]`, e.g.
         `lambda s: pipeline.latents_to_primitives(s, vae, mean, std)`: primitives are independent, SURVEY.md section
         8e) and only the decoded primitives are gathered on rank 0 - the 25 MB/sample payload crosses xGMI once, the
         decoder work is spread over all GPUs."""
         noise = None
         if self.rank == 0:
-            gen = torch.Generator().manual_seed(seed) if seed is not None else None
-            noise = torch.randn(batch, n_tokens, channels, generator=gen)
+            noise = initial_noise(batch, n_tokens, channels, seed, reference_rng)
         if not _single(self.world):
             meta = [tuple(cond.shape[1:])] if self.rank == 0 else [None]
             dist.broadcast_object_list(meta, src=0)

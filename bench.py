@@ -82,11 +82,11 @@ def step_stream(diffusion, model, x, kw):
             yield out
 
 
-def cpu_baseline_ddim(n_prim: int, budget_blocks: int = 14, threads: int = 32):
-    """The CPU oracle (oracle/dit_ref.py, fp32 - the port of the reference algorithm) on a bounded sample: one CFG step
-    (effective batch 2) at the full width with `budget_blocks` of the 28 blocks, extrapolated linearly in depth (blocks
-    are identical in cost; embedders / final layer are < 0.1 %).  Returns (record, oracle output, inputs) - the output
-    is what the `parity` leg compares the GPU's forward of the SAME truncated model with."""
+def cpu_baseline_ddim(n_prim: int, budget_blocks: int = 28, threads: int = 32):
+    """The CPU oracle (oracle/dit_ref.py, fp32 - the port of the reference algorithm, NOT the reference's own modules: /root/reference
+    does not exist on the GPU box) on a bounded sample: ONE whole CFG step (effective batch 2) of the full model - all 28 blocks, ~20 s
+    on 32 host threads (`budget_blocks` < 28: that many blocks, scaled linearly in depth).  Returns (record, oracle output, inputs) -
+    the output is what the `parity` leg compares the GPU's forward of the SAME model with."""
     from oracle import dit_ref, synth
     dit_ref.ATTN_DTYPE = torch.float32
     sd = synth.dit_state_dict(WEIGHT_SEED, in_channels=68, condition_channels=768, hidden_size=1152, depth=budget_blocks)
@@ -101,7 +101,8 @@ def cpu_baseline_ddim(n_prim: int, budget_blocks: int = 14, threads: int = 32):
     per_step = dt * 28.0 / budget_blocks
     rec = {"value": 1.0 / per_step, "unit": "denoise-steps/s", "cores": torch.get_num_threads(), "kind": "port",
            "sample": f"1 CFG step (eff. batch 2), N_prim={n_prim}, L=1370, d=1152, {budget_blocks}/28 blocks timed "
-                     f"({dt:.1f} s) and scaled x{28 // budget_blocks}; fp32 torch-CPU oracle"}
+                     f"({dt:.1f} s)" + ("" if budget_blocks == 28 else f" and scaled x{28.0 / budget_blocks:g}") +
+                     "; fp32 torch-CPU port of the reference algorithm (oracle/dit_ref.py), not the reference's own modules"}
     return rec, out, (sd, x, y, t, budget_blocks)
 
 
@@ -118,6 +119,55 @@ def cpu_baseline_decode(vae_sd, n_prims: int = 96, threads: int = 32):
     rec = {"value": n_prims / dt / 2048.0, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
            "sample": f"VAE.decode of {n_prims} primitives ({dt:.1f} s), scaled to 2048 primitives per sample; fp32 torch-CPU oracle"}
     return rec, out, z
+
+
+def torch_rocm_reference(model, x, y, dt, dev, batches=(1, 8), iters: int = 4):
+    """The reference's forward_with_cfg written with STOCK PyTorch-ROCm ops on this GPU, outside every timed region of the
+    product: oracle/dit_ref.py (the op-by-op port of models/dit_crossattn.py) run on the device under torch.autocast - F.linear
+    -> hipBLASLt, F.layer_norm, F.gelu, and F.scaled_dot_product_attention where the reference calls xformers'
+    memory_efficient_attention (not installable here).  Same weights as the benchmarked model, pre-cast to the 16-bit type once (the
+    best case for autocast, which would re-cast them every forward).  One forward_with_cfg per "step" (the sampler update is
+    < 0.2 % of a step).  A baseline on the same chip, next to `cpu_baseline`: not the product and not the target."""
+    import torch.nn.functional as F
+    from oracle import dit_ref
+
+    def sdpa(q, k, v, scale):                                      # [B, M, H, K] as xformers takes them
+        o = F.scaled_dot_product_attention(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), scale=scale)
+        return o.permute(0, 2, 1, 3)
+
+    rec = {"what": "oracle/dit_ref.py on the device under torch.autocast: stock F.linear (hipBLASLt) / F.scaled_dot_product_attention / "
+                   "F.layer_norm, weights pre-cast to the 16-bit type; one forward_with_cfg per step, HIP events, median",
+           "torch": torch.__version__}
+    keep = dit_ref.attention_core
+    try:
+        sd = {k: (v.detach().to(dt) if v.is_floating_point() else v.detach()) for k, v in model.state_dict().items()}
+        dit_ref.attention_core = sdpa
+        g = torch.Generator().manual_seed(78)
+        for bs in batches:
+            xs = x if bs == x.shape[0] else torch.randn(bs, x.shape[1], x.shape[2], generator=g).to(dev)
+            ys = y if bs == y.shape[0] else torch.randn(bs, y.shape[1], y.shape[2], generator=g).to(dev)
+            tt = torch.full((bs,), 800, dtype=torch.int64, device=dev)
+            ms = []
+            with torch.no_grad(), torch.device(dev), torch.autocast("cuda", dtype=dt):
+                for i in range(iters + 2):
+                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
+                    out = dit_ref.dit_forward_with_cfg(sd, xs, tt, ys, 16, 6.0)
+                    e.record()
+                    torch.cuda.synchronize()
+                    if i >= 2:
+                        ms.append(s.elapsed_time(e))
+            assert torch.isfinite(out.float()).all()
+            m = statistics.median(ms)
+            rec[f"batch{bs}"] = {"ms_per_step": m, "value": bs * 1e3 / m, "unit": "denoise-steps/s"}
+            del out
+        del sd
+    except Exception as ex:  # a stock op this torch build lacks on gfx950 must not take the bench line down
+        rec["error"] = f"{type(ex).__name__}: {ex}"[:300]
+    finally:
+        dit_ref.attention_core = keep
+        torch.cuda.empty_cache()
+    return rec
 
 
 def timed_repeats(run_steps, steps: int, repeats: int, world: int, dist, dev):
@@ -152,16 +202,33 @@ def traffic_file() -> str:
     return fs[-1] if fs else os.path.join(ROOT, "profiles", "none")
 
 
-def kernel_report(prof, steps: int, traffic_file: str):
+def event_pair_overhead_ms(n: int = 200) -> float:
+    """What a (start, end) pair of HIP events reads with NOTHING between them on the launch stream: the part of every per-launch
+    reading that is not the kernel.  Measured in the same process right after the per-launch pass (median of n pairs)."""
+    vals = []
+    for _ in range(n):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        e.record()
+        vals.append((s, e))
+    torch.cuda.synchronize()
+    return statistics.median(s.elapsed_time(e) for s, e in vals)
+
+
+def kernel_report(prof, steps: int, traffic_file: str, overhead_ms: float = 0.0):
+    """Per-kernel times of the per-launch pass.  Every reading has the measured empty event-pair reading subtracted (never more
+    than half of it): the raw readings of a step's launches summed to MORE than the event-free step (round-4 review)."""
     agg = {}
     for tag, fl, s, e in prof:
-        a = agg.setdefault(tag, [0.0, 0.0, 0])
-        a[0] += s.elapsed_time(e)
+        a = agg.setdefault(tag, [0.0, 0.0, 0, 0.0])
+        raw = s.elapsed_time(e)
+        a[0] += raw - min(overhead_ms, 0.5 * raw)
         a[1] += fl
         a[2] += 1
+        a[3] += raw
     mfma = {k: v for k, v in agg.items() if v[1] > 0}
     dom = max(mfma, key=lambda k: mfma[k][0])
-    ms, fl, n = agg[dom]
+    ms, fl, n, _raw = agg[dom]
     ach = fl / (ms * 1e-3) / 1e12
     traffic, src = None, None
     if os.path.exists(traffic_file):
@@ -171,13 +238,17 @@ def kernel_report(prof, steps: int, traffic_file: str):
             src = f"static profile {os.path.relpath(traffic_file, ROOT)} (separate rocprofv3 --pmc passes of this command; not re-measured in this run)"
     roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS,
             "traffic": traffic, "traffic_source": src, "launches": n, "avg_launch_ms": ms / n,
-            "algorithmic_gflop_per_launch": fl / n / 1e9,
-            "note": "kernel name as rocprofv3 prints it + the launch shape (GEMM MxNxK / attention problems x Nq x Nkv x dh); "
+            "algorithmic_gflop_per_launch": fl / n / 1e9, "avg_launch_ms_raw_event_reading": _raw / n,
+            "event_pair_overhead_ms": overhead_ms,
+            "note": "avg_launch_ms = HIP-event reading minus the reading of an empty event pair measured in the same process "
+                    "(event_pair_overhead_ms; the raw reading stands next to it); kernel name as rocprofv3 prints it + the launch shape (GEMM MxNxK / attention problems x Nq x Nkv x dh); "
                     "HIP events bracket every launch on the launch stream over a separate pass right after the timed "
                     "one (inside the timed region they cost 12.6 % and would deflate `value`); traffic = (2*FETCH_SIZE "
                     "+ WRITE_SIZE) KiB per launch (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md HBM section)"}
     kernels = {k: {"ms_per_step": v[0] / steps, "launches_per_step": v[2] / steps,
                    "tflops": (v[1] / (v[0] * 1e-3) / 1e12) if v[1] else None} for k, v in sorted(agg.items())}
+    roof["kernels_sum_ms_per_step"] = sum(v[0] for v in agg.values()) / steps
+    roof["kernels_sum_ms_per_step_raw"] = sum(v[3] for v in agg.values()) / steps
     return roof, kernels
 
 
@@ -289,14 +360,18 @@ def main() -> None:
 
     # ------------------------------------------------------------------ models
     model = vae = None
-    wbytes = 0
+    wbytes, wb_ms = 0, 0.0
     if args.config in ("ddim", "c4"):
         with torch.device(dev):                                    # construct on the GPU: no 3.6 GB host init + H2D
             model = pkg.DiT(**XL).eval()
         if rank == 0:
             load_synth_weights(model, 28)
         model.reuse_cond_kv = bool(args.reuse_cond_kv)
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
         wbytes = broadcast_packed_(model, dt, 0)                  # RCCL: the packed 16-bit blob (N > 1)
+        torch.cuda.synchronize()
+        wb_ms = 1e3 * (time.perf_counter() - tb0) if wbytes else 0.0   # (includes rank 0's fp32 -> 16-bit pack when it has not run yet)
     decode_leg = args.config == "ddim" and not args.no_decode_leg
     if args.config in ("decode", "c4") or decode_leg:
         from oracle import synth
@@ -345,13 +420,21 @@ def main() -> None:
         assert torch.isfinite(last["out"]["sample"]).all(), "non-finite sample"
     else:
         assert torch.isfinite(last_dec["out"]).all(), "non-finite decode"
-    per_rank = None
+    # what a SCALE record can be audited with: the ranks that really took part (all_gather over the process group, not the
+    # launcher's word), every rank's own median ms per step, the weight broadcast's wall time
+    ranks_seen = [[rank, local, torch.cuda.get_device_name(dev)]]
+    ms = [1e3 * statistics.median(mine) / args.steps]
     if world > 1:
         t = torch.tensor([statistics.median(mine)], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allr, t)
         ms = [1e3 * float(a.item()) / args.steps for a in allr]
-        per_rank = {"min": min(ms), "max": max(ms), "all": ms}
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, [rank, local, torch.cuda.get_device_name(dev)])
+        wbt = torch.tensor([wb_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(wbt, op=dist.ReduceOp.MAX)
+        wb_ms = float(wbt.item())
+    per_rank = {"min": min(ms), "max": max(ms), "all": ms}
 
     # Roofline leg: HIP events around every MFMA-kernel launch (ops._timed, on the launch stream) over a SEPARATE pass of the
     # same K steps, right after the timed ones (same process, buffers and clocks).
@@ -361,6 +444,7 @@ def main() -> None:
         run_steps(args.steps)
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
+        ev_over = event_pair_overhead_ms()
 
     # Opt-in exact algebra, reported NEXT TO the headline, never as it: the same K steps with the
     # step-invariant cross-attention K / V projections computed once per conditioning tensor (DiT.reuse_cond_kv).
@@ -437,6 +521,12 @@ def main() -> None:
         side["batch8"] = side_leg(8, dt, 5)
         side["bf16" if dt == torch.float16 else "fp16"] = side_leg(1, torch.bfloat16 if dt == torch.float16 else torch.float16, args.steps)
         torch.cuda.empty_cache()
+        side["torch_rocm_reference"] = torch_rocm_reference(model, x, y, dt, dev)
+        for bk, key in (("batch1", None), ("batch8", "batch8")):
+            mine_ms = (1e3 * elapsed / args.steps) if key is None else side[key]["ms_per_step"]
+            if bk in side["torch_rocm_reference"]:
+                side["torch_rocm_reference"][bk]["this_framework_ms_per_step"] = mine_ms
+                side["torch_rocm_reference"][bk]["speedup"] = side["torch_rocm_reference"][bk]["ms_per_step"] / mine_ms
 
     # ddim: the rest of the metric (SURVEY.md section 8d metric (2)), outside the headline's timed region: the VAE leg on
     # this GPU, and ONE whole sampling job - the 25-step DDIM loop (plan + 25 x forward_with_cfg + update) followed by the
@@ -475,7 +565,7 @@ def main() -> None:
             run_decode(3)
             torch.cuda.synchronize()
             dprof, ops.PROFILE = ops.PROFILE, None
-            dleg["decode"]["roofline"], dleg["decode"]["kernels"] = kernel_report(dprof, 3, traffic_file())
+            dleg["decode"]["roofline"], dleg["decode"]["kernels"] = kernel_report(dprof, 3, traffic_file(), event_pair_overhead_ms())
 
     # c4: the decode leg, timed separately (median of R)
     decode_s = None
@@ -497,8 +587,10 @@ def main() -> None:
                     "repeats_ms_per_step": [1e3 * e / args.steps for e in elapsed_all],
                     "data": "synthetic (seeded normal latents + conditioning tokens, deterministic synthetic weights "
                             "oracle/synth.py seed 4321, all layers non-zero)"})
-        if per_rank:
-            res["per_rank_ms_per_step"] = per_rank
+        res["per_rank_ms_per_step"] = per_rank
+        res["world_size_seen"] = len(ranks_seen)
+        res["ranks_seen"] = ranks_seen
+        res["weight_broadcast_ms"] = wb_ms
         par = f"batch-sharded replicas x{world}, no collective in the loop"
         if args.config == "ddim":
             steps_per_s = world * B * args.steps / elapsed
@@ -563,7 +655,7 @@ def main() -> None:
             res["ln_in_gemm_tail"] = {"enabled": bool(getattr(model, "fuse_ln", False) and getattr(model, "ln_in_kernel", False)),
                                       "sync_timeouts": ops.ln_sync_timeouts()}
         if prof:
-            res["roofline"], res["kernels"] = kernel_report(prof, args.steps, traffic_file())
+            res["roofline"], res["kernels"] = kernel_report(prof, args.steps, traffic_file(), ev_over)
         if dleg:
             res["decode"] = dleg["decode"]
             res["samples_per_s_measured"] = dleg["samples_per_s_measured"]
@@ -589,14 +681,17 @@ def main() -> None:
                 rec, ref, (sd14, xc, yc, tc, nb) = cpu_baseline_ddim(N)
                 res["cpu_baseline"] = rec
                 if not args.no_parity and N == 2048:
-                    with torch.device(dev):
-                        m14 = pkg.DiT(**{**XL, "depth": nb}).eval()
-                    m14.load_state_dict(sd14, strict=True)
-                    got = m14.forward_with_cfg(xc.to(dev), tc.to(dev), yc.to(dev), 6.0, dt, True).float().cpu()
+                    if nb == XL["depth"]:
+                        mp = model                                 # (the benchmarked model itself: load_synth_weights uses the same seed)
+                    else:
+                        with torch.device(dev):
+                            mp = pkg.DiT(**{**XL, "depth": nb}).eval()
+                        mp.load_state_dict(sd14, strict=True)
+                    got = mp.forward_with_cfg(xc.to(dev), tc.to(dev), yc.to(dev), 6.0, dt, True).float().cpu()
                     res.setdefault("parity", {}).update({
                         "rel_l2_vs_fp32_oracle": float((got - ref).norm() / ref.norm()), "blocks": nb,
-                        "oracle": "the cpu_baseline leg's own fp32 forward (oracle/dit_ref.py) of the first 14 blocks + final layer"})
-                    del m14
+                        "oracle": f"the cpu_baseline leg's own fp32 forward (oracle/dit_ref.py) of {nb} blocks + final layer"})
+                    del mp
                 if dleg:
                     rec, ref, z = cpu_baseline_decode(vae_sd, n_prims=512)
                     got = vae.decode(z.to(dev)).float().cpu()

@@ -108,6 +108,87 @@ def test_diffusion_step_bit_exact(ops, n, eta, out_dtype):
     assert float(x0.abs().max()) <= 1.0
 
 
+@pytest.mark.parametrize("ancestral", [False, True])
+def test_clip_denoised_propagates_nan_like_torch_clamp(ops, ancestral):
+    """`x.clamp(-1, 1)` of the reference (gaussian_diffusion.py:287-291) PROPAGATES NaN and maps +-inf to +-1: a non-finite
+    model output must not come out of a clipped step as a finite -1 (fminf / fmaxf would do that) - the sampling loop's
+    overflow guard (diffusion/sampler.py `_fold_guard`) reads the final sample, clipped or not."""
+    import topia_xl_amd as pkg
+    d = pkg.create_diffusion("ddim5", noise_schedule="squaredcos_cap_v2", parameterization="v")
+    tab, _ = dref.make("squaredcos_cap_v2", 1000, "ddim5")
+    coef = torch.from_numpy(d.step_coefficients(0.0)).to(DEV)
+    x = synth.tensor(9, "x", (1, 32, 68))
+    mo = synth.tensor(9, "mo", (1, 32, 136)).to(torch.float16)
+    mo[0, 3, 5] = float("nan")
+    mo[0, 4, 6] = float("inf")
+    mo[0, 5, 7] = float("-inf")
+    noise = synth.tensor(9, "n", (1, 32, 68))
+    for i in (4, 0):
+        if ancestral:
+            ref = dref.ancestral_step(tab, i, x, mo, noise, "v", True)
+        else:
+            ref = dref.ddim_step(tab, i, x, mo, "v", 0.0, True, None)
+        s, x0 = ops.diffusion_step(x.to(DEV), mo.to(DEV), coef, i, mean_type=2, var_type=3, ancestral=ancestral, clip_denoised=True,
+                                   noise=noise.to(DEV) if ancestral else None)
+        x0 = x0.cpu()
+        assert torch.isnan(x0[0, 3, 5]) and torch.isnan(s.cpu()[0, 3, 5])
+        assert float(x0[0, 4, 6]) == -1.0 and float(x0[0, 5, 7]) == 1.0          # v-prediction: x0 = a x - b v
+        fin = torch.ones_like(x0, dtype=torch.bool)
+        fin[0, 3, 5] = False
+        assert bool(torch.isfinite(x0[fin]).all()) and float(x0[fin].abs().max()) <= 1.0
+        assert torch.equal(torch.isnan(x0), torch.isnan(ref["pred_xstart"]))
+        assert torch.equal(x0[fin], ref["pred_xstart"].float()[fin])
+
+
+def test_sampling_loop_repeats_an_overflowed_folded_fp16_loop(ops):
+    """diffusion/sampler.py `_fold_guard`: a planner that reports folded fp16 forwards and a non-finite FINAL sample gets its loop
+    repeated with `fold_ln = False`, before the final item is yielded (consumers stop at the last item) and with the default
+    `clip_denoised=True` (the clip propagates NaN).  The stand-in model overflows exactly when it "folds"."""
+    import warnings
+
+    import topia_xl_amd as pkg
+
+    class Model:
+        def __init__(self):
+            self.fold_ln, self.calls, self._used, self.plans = True, [], False, 0
+
+        def plan_timesteps(self, ts):
+            self.plans += 1
+
+        def select_planned_timestep(self, row):
+            pass
+
+        def clear_timestep_plan(self):
+            self._used = False
+
+        def fold_overflowed(self, sample):
+            used, self._used = self._used, False
+            return used and not bool(torch.isfinite(sample).all())
+
+        def __call__(self, x, t, **kw):
+            self.calls.append(bool(self.fold_ln))
+            out = torch.cat([0.1 * x, torch.zeros_like(x)], -1).half()
+            if self.fold_ln:
+                self._used = True
+                if int(t[0]) < 300:
+                    out[0, 0, 0] = float("nan")
+            return out
+
+    d = pkg.create_diffusion("ddim5", noise_schedule="squaredcos_cap_v2", parameterization="v")
+    x = synth.tensor(10, "x", (1, 16, 68)).to(DEV)
+    m = Model()
+    with pytest.warns(RuntimeWarning, match="LayerNorm fold"):
+        items = list(d.ddim_sample_loop_progressive(m, tuple(x.shape), noise=x))       # default clip_denoised=True
+    assert len(items) == 5 and m.calls == [True] * 5 + [False] * 5 and m.fold_ln is True
+    assert bool(torch.isfinite(items[-1]["sample"]).all())
+    m2 = Model()
+    m2.fold_ln = False
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        want = d.ddim_sample_loop(m2, tuple(x.shape), noise=x)
+    assert torch.equal(items[-1]["sample"], want) and m2.calls == [False] * 5
+
+
 def test_ancestral_step(ops):
     import topia_xl_amd as pkg
     d = pkg.create_diffusion("ddim25", noise_schedule="squaredcos_cap_v2", parameterization="v")

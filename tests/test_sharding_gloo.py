@@ -42,9 +42,16 @@ def _worker(rank, world, port, batch, ret):
             noise = torch.randn(batch, 8, 4, generator=torch.Generator().manual_seed(42))
             want = noise * 2 + cond[:, :1, :4].sum(-1, keepdim=True)
             assert out.shape == (batch, 8, 4) and torch.equal(out, want)
-            ret.put("ok")
         else:
             assert out is None
+        # reference_rng: rank 0 replays the reference CLI's draws (inference.py:251,313,316) - global seed, the unused
+        # randn(1, N, 1, 4, 4, 4), then the noise - and the shards reassemble to exactly those latents
+        out = sampler.sample(batch, 8, 4, cond, seed=42, loop=lambda x, y: x, reference_rng=True)
+        if rank == 0:
+            torch.manual_seed(42)
+            torch.randn(1, 8, 1, 4, 4, 4)
+            assert torch.equal(out, torch.randn(batch, 8, 4))
+            ret.put("ok")
     finally:
         dist.destroy_process_group()
 
@@ -136,6 +143,30 @@ def test_two_rank_sharded_sampling(batch):
         p.join(120)
         assert p.exitcode == 0
     assert ret.get(timeout=5) == "ok"
+
+
+def test_reference_rng_gives_the_cli_latents():
+    """`initial_noise(reference_rng=True)` = the reference CLI's draws in its order (inference.py:251: torch.manual_seed(seed);
+    :313 latent = torch.randn(1, num_prims, 1, 4, 4, 4); :316 inf_x = torch.randn(inf_bs, num_prims, 68)): seed 42 gives the
+    CLI's seed-42 latents at the shipped shape; a second call continues the stream like the CLI's per-image loop; a larger
+    batch keeps entry 0; the default (private generator) leaves the global stream alone and gives other numbers."""
+    sys.path.insert(0, ROOT)
+    from topia_xl_amd.sharding import initial_noise
+    N = 2048
+    torch.manual_seed(42)
+    torch.randn(1, N, 1, 4, 4, 4)
+    cli_first = torch.randn(1, N, 68)
+    torch.randn(1, N, 1, 4, 4, 4)
+    cli_second = torch.randn(1, N, 68)
+    assert torch.equal(initial_noise(1, N, 68, 42, reference_rng=True), cli_first)
+    assert torch.equal(initial_noise(1, N, 68, None, reference_rng=True), cli_second)      # the next image of the same process
+    b4 = initial_noise(4, N, 68, 42, reference_rng=True)
+    assert torch.equal(b4[:1], cli_first)
+    torch.manual_seed(7)
+    probe = torch.rand(1)
+    torch.manual_seed(7)
+    private = initial_noise(1, N, 68, 42)
+    assert torch.equal(torch.rand(1), probe) and not torch.equal(private, cli_first)
 
 
 def test_shard_bounds():

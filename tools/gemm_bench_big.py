@@ -17,7 +17,10 @@ reps = int(os.environ.get("REPS", "16"))
 NB = 4
 shapes = [("fc1+gelu", "lin", 32768, 4608, 1152), ("proj", "gr", 32768, 1152, 1152), ("fc2", "gr", 32768, 1152, 4608),
           ("fc1+gelu", "lin", 8192, 4608, 1152), ("fc1+gelu", "lin", 4096, 4608, 1152), ("proj", "gr", 8192, 1152, 1152), ("fc2", "gr", 8192, 1152, 4608)]
+only = os.environ.get("ONLY")          # e.g. ONLY=32768: the shapes with that M
 for name, kind, M, N, K in shapes:
+    if only and str(M) not in only.split(","):
+        continue
     As = [torch.randn(M, K, device=dev).to(dt) for _ in range(NB)]
     W = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
     b = torch.randn(N, device=dev).to(dt)
