@@ -2179,8 +2179,13 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
 // tile, which needs 1.47 x fewer operand bytes per FLOP: fabric reads 321 vs 237 MB per launch) and the epilogue by its own loads'
 // round trips and by issuing 74 - 147 KB of stores into a write path that the OTHER 255 CUs keep full.  Non-temporal and write-through
 // stores (builds of both): 3 - 10 % slower on either kernel; other XCD walk shapes (gm 2 / 4 / 8 x sr 1 .. 16): within +-3 %, the
-// default below is among the best.  The lever at this size is bytes per FLOP (a larger tile than 8 waves x 256 registers hold), not
-// the seams.  Kept opt-in with its tests: the structure (loader waves streaming across tiles, stores never waited for) is what a
+// default below is among the best.  An L2 touch-ahead was built too - the compute waves, whose vector-memory queue is idle in the
+// loop, requesting one dword per 64-byte sector of the k-tile the loaders would ask for 2 - 16 steps later (4-byte LDS-DMA into a
+// strip nobody reads, each sector once per XCD by splitting a panel's rows between the tiles that share it): 2 - 5 % SLOWER at every
+// distance, the k-tile unchanged at ~2000 cycles - the loop is not waiting for first-touch misses either.  What moves with the
+// problem size is the shader clock (1.54 - 1.71 GHz under these launches, 1.9 - 2.0 under the T = 4096 ones): at T = 32768 the chip
+// is power-limited, and the lever is energy per FLOP - fewer LDS and L2 bytes per MFMA, i.e. a larger tile than 8 waves x 256
+// registers hold - not the seams and not the latency.  Kept opt-in with its tests: the structure (loader waves streaming across tiles, stores never waited for) is what a
 // larger-tile successor would start from.
 // Unit order: the virtual workgroup id v = b + round x G goes through the same XCD-aware 2-D walk as a one-pass-per-workgroup
 // launch would (xcd_tile2d; G % 8 == 0 keeps v's XCD = b's), so the 32 CUs of an XCD hold an sr x sc block of passes in every round
@@ -2542,7 +2547,8 @@ bool launch_pp(const GemmArgs<DT>& a, hipStream_t st) {
     if constexpr (EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL) {
         const int mtb = (a.M + 255) / 256, ntb = a.N / 144;
         const int min_rounds = pp_rounds();
-        if (min_rounds <= 0 || !g_loader || a.N % 144 || a.K % BK) return false;
+        if (min_rounds <= 0 || !g_loader || a.N % 144 || a.K % BK)
+            return false;
         const int G = cu_count();
         if (G <= 0 || (int64_t)mtb * ntb < (int64_t)min_rounds * G) return false;
         GemmArgs<DT> a2 = a;

@@ -49,7 +49,10 @@ C_DDIM_X0, C_DDIM_EPS, C_DDIM_SIGMA, C_NONZERO, C_FIXED_VAR = 9, 10, 11, 12, 13
 
 # PRIMX_PLAN_TIMESTEPS=0: the sampling loops do not announce their timesteps to the model (A/B of DiT.plan_timesteps)
 PLAN_TIMESTEPS = __import__("os").environ.get("PRIMX_PLAN_TIMESTEPS", "1") != "0"
-PLAN_MAX_STEPS = 256   # 16-bit table of n x (depth * 9 + 2) * D entries: 0.6 MB per step for DiT-XL
+# Longest loop that is planned.  Device memory per planned step for DiT-XL: 0.6 MB of 16-bit modulation rows (n x (depth * 9 + 2) * D)
+# + 2.1 MB of fp32 u / v rows when the LayerNorm fold applies (2 x 9216 columns x depth; DiT._fold_tables) + their 16-bit A operands
+# (0.4 MB): ~0.8 GB at 256 steps, freed when the loop ends (clear_timestep_plan drops the plan).
+PLAN_MAX_STEPS = 256
 _MEAN_CODE = {ModelMeanType.EPSILON: 0, ModelMeanType.START_X: 1, ModelMeanType.VELOCITY: 2}
 _VAR_CODE = {
     ModelVarType.FIXED_SMALL: 0,

@@ -193,6 +193,10 @@ class DiT(nn.Module):
         # 1900.  The sampling loop still looks at its final sample once when folded fp16 forwards ran (`fold_overflowed`) and repeats
         # the loop with LayerNorm launches if it is non-finite; bf16 has the range of fp32 and is not checked.
         self._fold_fp16_used = False
+        # `block_probe` (diagnostics, tools/validate_checkpoint.py): set to a list and every 16-bit forward appends one record per
+        # DiT block - the dynamic range of the fp32 residual stream behind the block and of the 16-bit operand handed to the next
+        # Linear (the LayerNorm output, or the fold's operand).  Synchronises after every block: never set on a timed path.
+        self.block_probe: Optional[list] = None
         self._side: Dict = {}
         self._t_plan: Optional[Dict] = None   # plan_timesteps(): the coming calls' timesteps and their modulation table
 
@@ -861,6 +865,13 @@ class DiT(nn.Module):
         else:
             for i, w in enumerate(pk["blocks"]):
                 block(i, w, 0, Be)
+                if self.block_probe is not None:
+                    rs = h.std(-1)
+                    self.block_probe.append({
+                        "block": i, "folded": fold_uv is not None, "dtype": str(dt).replace("torch.", ""),
+                        "residual_abs_max": float(h.abs().max()), "row_std_min": float(rs.min()), "row_std_median": float(rs.median()),
+                        "row_std_max": float(rs.max()), "row_mean_abs_max": float(h.mean(-1).abs().max()),
+                        "next_operand_abs_max": float(xn.float().abs().max()), "next_operand_finite": bool(torch.isfinite(xn.float()).all())})
 
         # ---- final layer (dit_crossattn.py:74-78)
         if not (fuse and self.depth):                    # (fused: the last block's fc2 launch has normalised the rows)

@@ -30,3 +30,8 @@ def test_validate_checkpoint_script():
     rep = json.loads(r.stdout[r.stdout.index("{"):])
     assert rep["pass"] and rep["forward_with_cfg"]["packed_route_bit_identical"] and rep["vae_decode"]["pass"]
     assert len(rep["ddim_trajectory"]["rel_l2_per_step"]) == 3
+    # the dynamic-range report (round 5): per block and dtype, finite operands, folded == unfolded up to rounding
+    for name in ("fp16", "bf16"):
+        dr = rep["dynamic_range"][name]
+        assert dr["operands_finite"] and len(dr["per_block"]) == rep["config"]["depth"] and dr["residual_abs_max"] > 0
+        assert dr["row_std_range"][0] > 0 and dr["operand_abs_max_unfolded"] > 0

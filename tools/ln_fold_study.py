@@ -52,8 +52,9 @@ def rel(a, b):
 def fold_linear(x, shift, scale, w, b, emulate, eps=1e-6, centre=None):
     """The folded LN -> modulate -> Linear of one site.  x: [B, N, D] fp32; shift / scale: [B, D] (16-bit values); w: [O, D]; b: [O].
     `centre` = None: the uncentred form of the first study (c = 0, exact statistics).  `centre` = a one-element list holding the
-    per-row centre [B, N, 1] (fp32) or None: the as-built form - statistics from fp32 partial sums of d = x - c over 144-column tiles,
-    and the list is updated to this site's mean for the next one (None: this is the first site - the row-mean kernel supplies c)."""
+    per-row (centre, scale) pair ([B, N, 1] fp32 each) or None: the as-built form (ABI 23) - operand cast16((x - c) rho_p m),
+    statistics from fp32 partial sums of d = x - c over 144-column tiles, and the list is updated to this site's (mean, rstd) for
+    the next one (None: this is the first site - primx_row_stats supplies the pair)."""
     m = r16(1 + scale, emulate).double().unsqueeze(1)                          # (1 + scale) formed in the 16-bit type, as autocast does
     wd = r16(w, emulate).double()
     u = (m @ wd.t()).float().double()                                          # [B, 1, O] fp32
@@ -65,16 +66,21 @@ def fold_linear(x, shift, scale, w, b, emulate, eps=1e-6, centre=None):
         mu, rho = mu.float().double(), rho.float().double()                  # fp32 statistics
         a16 = r16((x * m.float()), emulate).double()                           # what the producer's epilogue would store
     else:
-        c = centre[0] if centre[0] is not None else x.mean(-1, keepdim=True)   # (primx_row_mean in front of the first site)
+        if centre[0] is None:                                                  # (primx_row_stats in front of the first site)
+            c = x.mean(-1, keepdim=True)
+            rp = (1.0 / torch.sqrt(x.double().var(-1, unbiased=False, keepdim=True) + eps)).float()
+        else:
+            c, rp = centre[0]
         d = (x - c).float()                                                    # fp32, as the producer's epilogue forms it
-        a16 = r16(d * m.float(), emulate).double()
+        a16 = r16((d * rp) * m.float(), emulate).double()
         D = x.shape[-1]
         dt = d.double().view(*d.shape[:-1], D // 144, 144)
         s1 = dt.sum(-1).float().double().sum(-1, keepdim=True)                 # fp32 partials per 144-column tile, then their sum
         s2 = (dt * dt).sum(-1).float().double().sum(-1, keepdim=True)
         mu = (s1 / D).float().double()                                         # mu' = mean(x - c)
         rho = (1.0 / torch.sqrt(torch.clamp(s2 / D - mu * mu, min=0.0) + eps)).float().double()
-        centre[0] = (c.double() + mu).float()                                  # the consumer's column tile 0 moves the centre
+        centre[0] = ((c.double() + mu).float(), rho.float())                   # the consumer's column tile 0 writes the next pair
+        mu, rho = (rp.double() * mu).float().double(), (rho / rp.double()).float().double()   # the epilogue's (rho_p mu', rho / rho_p)
     acc = a16 @ wd.t()                                                         # fp32-accumulated MFMA (float64 here)
     y = (rho * (acc - mu * u) + v).float()                                     # epilogue arithmetic in fp32
     return r16(y, emulate)
@@ -127,7 +133,7 @@ def folded_block(sd, i, x, y, t_emb, H, emulate, centre=None):
     s = dh ** -0.5
     if centre is not None and i == 0:
         q0 = std_linear(x, sh_c, sc_c, sd[pc + "to_q.weight"], sd.get(pc + "to_q.bias"), emulate)
-        centre[0] = x.mean(-1, keepdim=True)
+        centre[0] = (x.mean(-1, keepdim=True), (1.0 / torch.sqrt(x.double().var(-1, unbiased=False, keepdim=True) + 1e-6)).float())
     else:
         q0 = fold_linear(x, sh_c, sc_c, sd[pc + "to_q.weight"], sd.get(pc + "to_q.bias"), emulate, centre=centre)
     q = r16(s * q0, emulate).reshape(B, N, H, dh)

@@ -18,8 +18,19 @@ the comparison to run where the files exist:
   3. HIP side: the same through `topia_xl_amd` (strict `load_state_dict` AND the packed-from-checkpoint route, which must agree
      bit for bit), in the requested 16-bit dtype and on the exact-fp32 route;
   4. the VAE: `VAE.decode` of seeded latents de-normalised with the shipped statistics, reference / oracle fp32 vs HIP;
-  5. one JSON report: rel-L2 per stage, the largest attention logit and |activation| the reference saw (the quantities the
+  5. dynamic range on TRAINED weights (round 5): one PLANNED forward per 16-bit dtype with `DiT.block_probe` - per block the
+     fp32 residual stream's largest magnitude, its rows' spread (std min / median / max) and largest |row mean|, and the
+     largest magnitude of the 16-bit operand handed to the next Linear - the LayerNorm output, or with the LayerNorm fold
+     (planned loops at the shapes that fold: DiT-XL at N_prim 2048 does) the fold's operand cast16((x - c) rho_p (1 + scale)),
+     which ABI 23 keeps normalised; a non-finite operand or a folded-vs-unfolded sample difference beyond the 16-bit rounding
+     level FAILS the report;
+  6. one JSON report: rel-L2 per stage, the largest attention logit and |activation| the reference saw (the quantities the
      fp16 operand tricks depend on), and PASS / FAIL against the tolerances of tests/test_hip_fullconfig.py.
+
+The one command where the released files exist (reference README.md:80-86 puts them under pretrained/):
+
+    python tools/validate_checkpoint.py --dit pretrained/model_sview_dit_fp16.pt --vae pretrained/model_vae_fp16.pt \
+        --reference /path/to/3DTopia-XL --steps 2 --out validate_report.json
 
 Without the files it prints {"skipped": ...} and exits 0.  `--selftest` runs the whole procedure on a SYNTHETIC small
 checkpoint written to a temporary directory (what tests/test_hip_e2e.py::test_validate_checkpoint_script does on the GPU box).
@@ -131,6 +142,36 @@ def hip_side(sd, cfg, heads, x, y, t, n_steps, dtype, blocks):
         for s in d.ddim_sample_loop_progressive(m.forward_with_cfg, x.shape, noise=xd, clip_denoised=False, model_kwargs=kw, device=dev):
             traj.append(s["sample"].float().cpu())
     out["traj"] = traj
+    # dynamic range, per block, of one PLANNED forward (the path a sampling loop runs: with the LayerNorm fold where it applies)
+    # in fp16 and bf16, and the folded forward against the unfolded one
+    rng = {}
+    for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        rec = {}
+        for fold in (True, False):
+            keep, m.fold_ln = m.fold_ln, fold
+            m.plan_timesteps(td)
+            m.select_planned_timestep(0)
+            m.block_probe = []
+            o = m.forward_with_cfg(xd, td, yd, 6.0, dt, True).float().cpu()
+            probe, m.block_probe = m.block_probe, None
+            m.clear_timestep_plan()
+            m.fold_ln = keep
+            rec["folded" if fold else "unfolded"] = {"out": o, "blocks": probe}
+        fo, un = rec["folded"], rec["unfolded"]
+        active = any(b["folded"] for b in fo["blocks"])
+        rng[name] = {
+            "fold_active": active,
+            "residual_abs_max": max(b["residual_abs_max"] for b in un["blocks"]),
+            "row_std_range": [min(b["row_std_min"] for b in un["blocks"]), max(b["row_std_max"] for b in un["blocks"])],
+            "row_mean_abs_max": max(b["row_mean_abs_max"] for b in un["blocks"]),
+            "operand_abs_max_unfolded": max(b["next_operand_abs_max"] for b in un["blocks"]),
+            "operand_abs_max_folded": max(b["next_operand_abs_max"] for b in fo["blocks"]),
+            "operands_finite": all(b["next_operand_finite"] for b in fo["blocks"] + un["blocks"]),
+            "folded_vs_unfolded_rel_l2": rel_l2(fo["out"], un["out"]),
+            "per_block": [{k: b[k] for k in ("block", "residual_abs_max", "row_std_min", "row_std_median", "row_std_max",
+                                               "row_mean_abs_max", "next_operand_abs_max")} | {"next_operand_abs_max_folded": f["next_operand_abs_max"]}
+                          for b, f in zip(un["blocks"], fo["blocks"])]}
+    out["dynamic_range"] = rng
     from topia_xl_amd import ops
     out["ln_sync_timeouts"] = ops.ln_sync_timeouts()
     return out
@@ -234,6 +275,10 @@ def main() -> int:
                                "packed_route_bit_identical": hip["packed_route_bit_identical"],
                                "finite": bool(torch.isfinite(hip["fwd"]).all()), "ln_sync_timeouts": hip["ln_sync_timeouts"]}
     ok = e16 < TOL[args.dtype] and e32 < TOL["fp32"] and hip["packed_route_bit_identical"] and hip["ln_sync_timeouts"] == 0
+    rep["dynamic_range"] = hip["dynamic_range"]
+    for name, lim in (("fp16", 4e-3), ("bf16", 3e-2)):       # folded vs unfolded: two roundings of the same model (tests/test_hip_fold.py: 1.2e-3 / 1e-2)
+        dr = hip["dynamic_range"][name]
+        ok = ok and dr["operands_finite"] and dr["folded_vs_unfolded_rel_l2"] < lim
     if n_steps:
         errs = [rel_l2(a, b) for a, b in zip(hip["traj"], ref_traj)]
         rep["ddim_trajectory"] = {"steps": n_steps, "rel_l2_per_step": errs, "tolerance": TOL["traj_" + args.dtype]}
