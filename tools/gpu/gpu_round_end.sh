@@ -1,8 +1,8 @@
 #!/bin/bash
-# round-end artefacts (round 3): GPU tests + smoke + benches (default ddim incl. the decode leg and the timed job, decode, c4, the other
+# round-end artefacts (rounds 3 - 5; ROUND=rN names the output directory): GPU tests + smoke + benches (default ddim incl. the decode leg and the timed job, decode, c4, the other
 # BASELINE shapes), kernel traces of the bench commands, PMC passes (traffic: FETCH_SIZE / WRITE_SIZE; MFMA utilisation) - each PMC
 # pass on its own, with --kernel-trace only
-R=${ROUND:-r3}
+R=${ROUND:-r5}
 OUT=gpurun_out/final_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
