@@ -6,6 +6,7 @@ R=${ROUND:-r5}
 OUT=gpurun_out/final_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+if [ -z "$ONLY_PROFILES" ]; then
 timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -s > $OUT/gpu_tests.log 2>&1; echo "pytest exit $?" >> $OUT/gpu_tests.log; tail -2 $OUT/gpu_tests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu | tail -2 | tee $OUT/smoke.txt
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench exit $?"; cut -c1-300 $OUT/bench_default.json
@@ -16,9 +17,11 @@ timeout 600 python bench.py --batch 8 --steps 6 --warmup 2 --no-cpu-baseline --n
 timeout 600 python bench.py --batch 8 --dtype bf16 --steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-decode-leg >> $OUT/bench_other.jsonl 2>/dev/null
 timeout 600 python bench.py --batch 4 --n-prim 4096 --dtype bf16 --steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-decode-leg >> $OUT/bench_other.jsonl 2>/dev/null
 timeout 600 python bench.py --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-decode-leg >> $OUT/bench_other.jsonl 2>/dev/null
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python bench.py --no-cpu-baseline --no-parity --no-decode-leg --steps 25 > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+fi   # (ONLY_PROFILES=1: the traces and counter passes alone)
+# the profiled commands carry --no-side-legs: the batch-8 / bf16 / torch-reference legs launch the same kernel names at other shapes
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python bench.py --no-cpu-baseline --no-parity --no-decode-leg --no-side-legs --steps 25 > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o trace_decode -- python bench.py --config decode --no-cpu-baseline --no-parity > $OUT/bench_trace_decode.json 2> $OUT/bench_trace_decode.err
-B="python bench.py --no-cpu-baseline --no-parity --no-decode-leg --steps 3 --warmup 1 --repeats 1 --no-kernel-events"
+B="python bench.py --no-cpu-baseline --no-parity --no-decode-leg --no-side-legs --steps 3 --warmup 1 --repeats 1 --no-kernel-events"
 D="python bench.py --config decode --no-cpu-baseline --no-parity --steps 2 --warmup 1 --repeats 1 --no-kernel-events"
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- $B > /dev/null 2> $OUT/fetch.err
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- $B > /dev/null 2> $OUT/write.err
