@@ -292,6 +292,12 @@ def rendezvous(args):
     have_gpu = torch.cuda.is_available()
     if not have_gpu and not args.dry_run:
         raise SystemExit("bench.py: no HIP device visible (only --dry-run works without one)")
+    # PRIMX_BENCH_SHARE_GPU=1 (tests/test_hip_rccl.py only): every rank runs on cuda:0 and the process group is gloo - the N > 1 code
+    # path of this file (weight broadcast into a packed-only model, all_gather of ranks and times, MAX over ranks) on a ONE-GPU box.
+    # RCCL refuses two ranks on one device; the line it prints says `"test_mode"` and measures nothing.
+    share = os.environ.get("PRIMX_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     if have_gpu and torch.cuda.device_count() <= local:
         raise SystemExit(f"bench.py: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} are visible")
     dev = torch.device("cuda", local) if have_gpu else torch.device("cpu")
@@ -301,7 +307,7 @@ def rendezvous(args):
     # really issued on it (sharding.FORCE_COLLECTIVES) - proves the collective path on a single-GPU box, measures nothing
     if world > 1 or (os.environ.get("PRIMX_FORCE_COLLECTIVES") == "1" and "MASTER_PORT" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if have_gpu:
+        if have_gpu and not share:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -591,6 +597,8 @@ def main() -> None:
                     "data": "synthetic (seeded normal latents + conditioning tokens, deterministic synthetic weights "
                             "oracle/synth.py seed 4321, all layers non-zero)"})
         res["per_rank_ms_per_step"] = per_rank
+        if os.environ.get("PRIMX_BENCH_SHARE_GPU") == "1":
+            res["test_mode"] = "PRIMX_BENCH_SHARE_GPU=1: all ranks on one GPU over gloo - a code-path check, not a measurement"
         res["world_size_seen"] = len(ranks_seen)
         res["ranks_seen"] = ranks_seen
         res["weight_broadcast_ms"] = wb_ms

@@ -50,3 +50,33 @@ def test_workload_names_follow_the_arguments():
     assert bench.workload_name(4, 4096, "bf16", "ddim25").startswith("BASELINE configs[4] per-GPU shape")
     assert bench.workload_name(1, 2048, "bf16", "ddim25").startswith("not a BASELINE configuration")
     assert bench.workload_name(2, 1024, "fp16", "ddim25").startswith("not a BASELINE configuration")
+
+
+def test_kernel_report_corrects_the_event_readings(tmp_path):
+    """`kernel_report`: every per-launch reading has HALF the empty event-pair reading subtracted (never more than half the reading
+    itself), the dominant kernel is chosen among the MFMA kernels by corrected time, and the sums stand in the record - so that
+    kernels_sum_ms_per_step <= ms_per_step can be checked from the line."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Ev:
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    prof = []
+    for _ in range(4):                                     # two steps x (2 GEMM launches + 1 row kernel)
+        prof.append(("gemmA 8x8x8", 1e9, Ev(0.0), Ev(0.050)))
+    for _ in range(2):
+        prof.append(("rowop", 0.0, Ev(0.0), Ev(0.004)))
+        prof.append(("gemmB 4x4x4", 2e9, Ev(0.0), Ev(0.030)))
+    roof, kernels = bench.kernel_report(prof, 2, str(tmp_path / "none.json"), overhead_ms=0.006)
+    assert roof["kernel"] == "gemmA 8x8x8" and roof["launches"] == 4
+    assert abs(roof["avg_launch_ms"] - 0.047) < 1e-12 and abs(roof["avg_launch_ms_raw_event_reading"] - 0.050) < 1e-12
+    assert abs(kernels["rowop"]["ms_per_step"] - 0.002) < 1e-12          # 4 us reading, 3 us half-pair: capped at half the reading
+    assert abs(kernels["gemmB 4x4x4"]["ms_per_step"] - 0.027) < 1e-12
+    assert abs(roof["kernels_sum_ms_per_step"] - (4 * 0.047 + 2 * 0.002 + 2 * 0.027) / 2) < 1e-12
+    assert abs(roof["kernels_sum_ms_per_step_raw"] - (4 * 0.050 + 2 * 0.004 + 2 * 0.030) / 2) < 1e-12
+    assert roof["traffic"] is None and abs(roof["achieved"] - 1e9 / 0.047e-3 / 1e12) < 1e-9

@@ -468,7 +468,8 @@ def test_persistent_pass_kernel_edges(ops, dtype, M, N, K, monkeypatch):
     x3 = x0.clone()
     ops.linear_gate_residual(A, W, b, gate, x3[:M], rpb)
     assert not _lib.load().primx_last_gemm_kernel().decode().startswith("gemm144pp")
-    assert rel_l2(x3[:M] - x0[:M], x[:M] - x0[:M]) < 1e-5
+    # (another kernel sums K in another order - the 128 x 144 tile in two halves: a few 16-bit roundings of the branch flip by one ulp)
+    assert rel_l2(x3[:M] - x0[:M], x[:M] - x0[:M]) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

@@ -129,3 +129,28 @@ def test_bench_under_the_launcher_with_one_rank_on_rccl():
     rec = json.loads(line)
     assert rec["n_gpus"] == 1 and rec["unit"] == "denoise-steps/s" and rec["value"] > 0
     assert rec["config"]["weight_broadcast_bytes"] > 1.8e9, rec["config"]
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """The N > 1 code path of bench.py on a ONE-GPU box (PRIMX_BENCH_SHARE_GPU=1: both ranks on cuda:0, gloo process group - RCCL refuses
+    two ranks on one device): rank 1 receives the packed blob into a packed-only model, both ranks run their own loop, the line
+    carries what the driver's SCALE record is audited with - two ranks seen by an all_gather, two per-rank times, the broadcast's bytes
+    and wall time - and `value` is the whole job's rate (2 x batch x steps / MAX time).  Measures nothing."""
+    env = dict(os.environ)
+    env.update(PRIMX_BENCH_SHARE_GPU="1", PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "PRIMX_FORCE_COLLECTIVES"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "1",
+           "--no-cpu-baseline", "--no-parity", "--no-decode-leg", "--no-kernel-events", "--no-side-legs"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and sorted(x[0] for x in d["ranks_seen"]) == [0, 1]
+    assert len(d["per_rank_ms_per_step"]["all"]) == 2 and d["per_rank_ms_per_step"]["max"] >= d["per_rank_ms_per_step"]["min"] > 0
+    assert d["config"]["weight_broadcast_bytes"] > 1.8e9 and d["weight_broadcast_ms"] > 0 and "test_mode" in d
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"] and d["scaling"] == "weak"
+    assert d["ms_per_step"] >= d["per_rank_ms_per_step"]["max"] * 0.999
