@@ -141,6 +141,7 @@ def test_planned_and_unplanned_loops_give_identical_samples(pkg, dtype, monkeypa
     step's sample is bit-identical to the loop that computes the modulation per step, and the plan does not outlive the loop."""
     from importlib import import_module
     sampler = import_module(pkg.__name__ + ".diffusion.sampler")
+    monkeypatch.setattr(sampler, "PLAN_TIMESTEPS", True)        # (the test is about planning: independent of PRIMX_PLAN_TIMESTEPS=0 in the environment)
     name, sd, heads, m, x, y, t = _case(pkg, 1)
     d = pkg.create_diffusion("ddim10", noise_schedule="squaredcos_cap_v2", parameterization="v")
     kw = dict(y=y.to(DEV), cfg_scale=6.0, precision_dtype=dtype, enable_amp=True)
