@@ -178,6 +178,15 @@ __device__ __forceinline__ pf_u32x2 gemm_prefetch_lines(const GemmArgs<DT>& p, i
 #ifndef PRIMX_STORE_POLICY
 #define PRIMX_STORE_POLICY 0
 #endif
+// PRIMX_LOADER_PRIO / PRIMX_COMPUTE_PRIO (build-time experiments): s_setprio of the loader / compute waves of the loader-wave kernels
+// (0 = the default priority).  Measured in round 5 (tools/gpu/r5_prio.sh, same box, configs[1] step): loaders at 1 or 3, compute
+// waves at 1: 8.61 - 8.62 ms against 8.60 - the issue arbiter is not what these kernels wait for.
+#ifndef PRIMX_LOADER_PRIO
+#define PRIMX_LOADER_PRIO 0
+#endif
+#ifndef PRIMX_COMPUTE_PRIO   // the same for their compute waves
+#define PRIMX_COMPUTE_PRIO 0
+#endif
 template <typename T>
 __device__ __forceinline__ void out_store(T* ptr, const T v) {
 #if PRIMX_STORE_POLICY == 1
@@ -1163,6 +1172,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     const int nk = pl_K / BK;
 
     if (wave >= 8) {
+        if (PRIMX_LOADER_PRIO) __builtin_amdgcn_s_setprio(PRIMX_LOADER_PRIO);
         // ---------------- loader wave lw: instructions t = lw * 17 + i, rows 8t .. 8t+7 of the 272-row stage image
         const int lw = wave - 8;
         const S* gp[NL];
@@ -1198,6 +1208,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     }
 
     // ---------------- compute waves: the tile / wave roles of gemm144_dma_kernel
+    if (PRIMX_COMPUTE_PRIO) __builtin_amdgcn_s_setprio(PRIMX_COMPUTE_PRIO);
     const int kg = wave >> 2, wm = wave & 3;
     const int lr = lane & 15, lg = lane >> 4;
     f32x4 acc[MI][NI];
@@ -1977,6 +1988,7 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     const int nk = pl_K / BK, total = NPASS * nk;
 
     if (wave >= 8) {
+        if (PRIMX_LOADER_PRIO) __builtin_amdgcn_s_setprio(PRIMX_LOADER_PRIO);
         // ---------------- loader wave lw: instructions t = lw * 25 + i, rows 8 t .. 8 t + 7 of the 400-row stage image (rows
         // < 256: activations, the same for both passes; the rest: the pass's 144 weight rows)
         const int lw = wave - 8;
@@ -2011,6 +2023,7 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     }
 
     // ---------------- compute wave w: rows 32 w .. 32 w + 31 of the tile, all 144 columns of the pass, the whole K
+    if (PRIMX_COMPUTE_PRIO) __builtin_amdgcn_s_setprio(PRIMX_COMPUTE_PRIO);
     const int lr = lane & 15, lg = lane >> 4;
     const int a_row = wave * 32 + lr;
     auto read_frags = [&](int stage, int ks, V8 (&a)[MI], V8 (&b)[NI]) {
@@ -2229,6 +2242,7 @@ __global__ __launch_bounds__(640) void gemm144pp_dma_kernel(PRIMX_GEMM_PARAMS(DT
     };
 
     if (wave >= 8) {
+        if (PRIMX_LOADER_PRIO) __builtin_amdgcn_s_setprio(PRIMX_LOADER_PRIO);
         // ---------------- loader wave lw: instructions t = lw * 25 + i, rows 8 t .. 8 t + 7 of the 400-row stage image (rows < 256:
         // activations, the rest: the pass's 144 weight rows).  One stream of k-tiles over all rounds; the row pointers are formed
         // again at every seam (a handful of 64-bit adds per pass - kept across the loop they would be the wave's whole budget twice)
@@ -2274,6 +2288,7 @@ __global__ __launch_bounds__(640) void gemm144pp_dma_kernel(PRIMX_GEMM_PARAMS(DT
     }
 
     // ---------------- compute wave w: rows 32 w .. 32 w + 31 of the pass, all 144 columns, the whole K
+    if (PRIMX_COMPUTE_PRIO) __builtin_amdgcn_s_setprio(PRIMX_COMPUTE_PRIO);
     const int lr = lane & 15, lg = lane >> 4;
     const int a_row = wave * 32 + lr;
     auto read_frags = [&](int stage, int ks, V8 (&a)[MI], V8 (&b)[NI]) {
