@@ -209,10 +209,10 @@ def vae_check(args, vsd, n_prims: int = 256) -> dict:
             "ref_abs_max": float(ref.abs().max()), "pass": rl < TOL["vae_rel"]}
 
 
-def write_selftest_checkpoints(tmp: str):
+def write_selftest_checkpoints(tmp: str, xl: bool = False):
     from oracle import synth
     import topia_xl_amd as pkg
-    cfg = dict(in_channels=68, condition_channels=768, hidden_size=288, depth=2)
+    cfg = dict(in_channels=68, condition_channels=768, hidden_size=1152 if xl else 288, depth=2)
     sd = {k: v.half() for k, v in synth.dit_state_dict(97, **cfg).items()}
     dit = os.path.join(tmp, "model_sview_dit_fp16.pt")
     torch.save({"ema": sd}, dit)
@@ -236,13 +236,15 @@ def main() -> int:
     ap.add_argument("--heads", type=int, default=16)
     ap.add_argument("--out", default=None)
     ap.add_argument("--selftest", action="store_true", help="run on a synthetic small checkpoint (checks the script itself)")
+    ap.add_argument("--selftest-xl", action="store_true", help="--selftest at the released model's WIDTH (d = 1152, 16 heads, N_prim 2048, "
+                    "1370 conditioning tokens, two blocks): the shapes at which planned forwards fold their LayerNorms")
     args = ap.parse_args()
 
     tmp = None
-    if args.selftest:
+    if args.selftest or args.selftest_xl:
         tmp = tempfile.TemporaryDirectory()
-        args.dit, args.vae = write_selftest_checkpoints(tmp.name)
-        args.n_prim, args.heads, args.steps = 256, 4, max(args.steps, 3)
+        args.dit, args.vae = write_selftest_checkpoints(tmp.name, xl=args.selftest_xl)
+        args.n_prim, args.heads, args.steps = (2048, 16, max(args.steps, 2)) if args.selftest_xl else (256, 4, max(args.steps, 3))
     if not os.path.exists(args.dit):
         print(json.dumps({"skipped": f"{args.dit} not found: place the released checkpoint there (reference README.md:80-86) "
                                      "or pass --dit / --selftest"}))
@@ -258,7 +260,7 @@ def main() -> int:
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     g = torch.Generator().manual_seed(2024)
     x = torch.randn(1, args.n_prim, cfg["in_channels"], generator=g)
-    y = torch.load(args.cond, map_location="cpu").float() if args.cond else torch.randn(1, 1370 if not args.selftest else 70,
+    y = torch.load(args.cond, map_location="cpu").float() if args.cond else torch.randn(1, 70 if (args.selftest and not args.selftest_xl) else 1370,
                                                                                       cfg["condition_channels"], generator=g)
     n_steps = args.steps
     import topia_xl_amd as pkg
