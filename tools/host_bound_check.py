@@ -35,6 +35,16 @@ torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"sampling loop: enqueue {1e3 * (t1 - t0) / 25:.2f} ms/step   total {1e3 * (t2 - t0) / 25:.3f} ms/step   (the enqueue time includes "
       "back-pressure: HIP blocks the host once a few hundred launches are queued)")
+# without back-pressure: ONE step at a time, the queue empty when its enqueue starts
+one = []
+for _ in range(12):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    next(stream)
+    one.append(time.perf_counter() - t0)
+torch.cuda.synchronize()
+one.sort()
+print(f"one step enqueued into an empty queue: median {1e3 * one[len(one) // 2]:.2f} ms, min {1e3 * one[0]:.2f} ms of host time (the GPU needs ~8.5)")
 stream.close()
 
 t = torch.full((1,), 480, device=dev, dtype=torch.int64)
