@@ -1502,7 +1502,14 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
 // LDS rows are 64 bytes (4 chunks of 16 B); chunk' = chunk ^ 2*((row>>3)&1) makes the ds_read_b128 lane groups
 // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) hit 16 distinct 16-byte slots (rows r&3 pick the 64-byte quarter of a
 // 256-byte bank window, the XOR separates rows 0-7 from 8-15 which the groups pair with chunk c and c+1).
-template <int DT, int EPI>
+// KT = 64 (round 6; K % 64 == 0): the operand stream in 128-BYTE row segments - whole cache lines - instead of 64-byte ones.  The way
+// into a CU is bound by REQUESTS, not bytes (tools/probe/big_ingest.hip, profiles/r6_ingest.txt: this tile's stream alone, no MFMAs, takes
+// 1530 cycles per 32-wide slice as 16 rows x 64 B per instruction and 980 as 8 rows x 128 B - the MFMAs need 1152; the shipped loop
+// measured 1650: it ran at the request rate, not at the matrix pipe's).  The ring becomes TWO stages of 64-wide tiles (the same 139 KB;
+// rows of 64 halves with the 128 x 144 kernels' chunk swizzle on the source address), ONE barrier per tile, placed two MFMA groups into
+// the tile's second half - "everybody has read tile t, tile t + 1 has landed" - behind which tile t + 2 is requested into tile t's stage
+// between the remaining MFMA groups; the first half of every tile runs without any barrier.
+template <int DT, int EPI, int KT = 32>
 __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(DT)) {
     PRIMX_GEMM_ARGS(DT);
     unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pc2 = 0;   // PRIMX_GEMM_PROF=1 timeline (see g_gemm_prof)
@@ -1511,11 +1518,13 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
     using V8 = typename T16<DT>::V8;
     typedef __attribute__((address_space(1))) const void GV;
     typedef __attribute__((address_space(3))) void LV;
-    constexpr int BM = 256, BN = 288, MI = 4, NI = 9, KS = 32, NST = 4;
-    constexpr int ROWS = BM + BN;            // 544 rows of 64 bytes per stage
+    static_assert(KT == 32 || KT == 64, "k-tile");
+    constexpr int BM = 256, BN = 288, MI = 4, NI = 9, KS = KT, NST = KT == 64 ? 2 : 4;
+    constexpr int ROWS = BM + BN;            // 544 rows of 64 (KT = 32) / 128 bytes per stage
     constexpr int STAGE = ROWS * KS;         // halves per stage
-    constexpr int NINST = ROWS / 16;         // 34 wave-instructions (16 rows each) per stage
-    constexpr int NSLOT = (NINST + 7) / 8;   // 5 (waves 0,1) / 4
+    constexpr int RPI = 512 / KS;            // rows per 1 KiB wave-instruction: 16 / 8
+    constexpr int NINST = ROWS / RPI;        // 34 / 68 wave-instructions per stage
+    constexpr int NSLOT = (NINST + 7) / 8;   // 5 (waves 0,1) / 4;  KT = 64: 9 (waves 0..3) / 8
     // EPI_HEADS stages the rounded 16-bit tile in LDS after the main loop (row-major [256][304] for the token-major
     // layouts, transposed [288][272] for PRIMX_HEADS_VT); the strides put the 16 fragment rows of a wave 8 banks apart
     constexpr int RS_ROWS = BN + 16, RS_VT = BM + 16;
@@ -1544,22 +1553,41 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
     }
     const int m0 = mi_t * BM, n0 = ni_t * BN;
 
-    const S* gp[NSLOT];
+    // KT = 64: nine requests per tile and wave - 32-bit byte offsets against the (uniform) operand bases instead of 64-bit pointers (the
+    // launcher checks that both operands are smaller than 4 GB); slots 0 .. 3 are A rows for every wave, 4 .. 8 W rows (256 / 8 / 8 = 4)
+    const S* gp[KT == 64 ? 1 : NSLOT];
+    unsigned go[KT == 64 ? NSLOT : 1];
+    constexpr int NA_SLOTS = BM / RPI / 8;
+    if constexpr (KT == 64) {
 #pragma unroll
-    for (int i = 0; i < NSLOT; ++i) {
-        const int t = min(wave + 8 * i, NINST - 1);
-        const int row = 16 * t + (lane >> 2);
-        const int c = (lane & 3) ^ (((row >> 3) & 1) << 1);
-        gp[i] = (row < BM) ? pl_A + (int64_t)min(m0 + row, pl_M - 1) * pl_K + c * 8
-                           : pl_W + (int64_t)(n0 + row - BM) * pl_K + c * 8;
+        for (int i = 0; i < NSLOT; ++i) {
+            const int t = min(wave + 8 * i, NINST - 1);
+            const int row = RPI * t + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);   // LDS position (row, 16-byte slot lane & 7) holds chunk slot ^ ((row >> 1) & 7) (lds_off)
+            go[i] = (unsigned)(((i < NA_SLOTS ? (int64_t)min(m0 + row, pl_M - 1) : (int64_t)(n0 + row - BM)) * pl_K + c * 8) * 2);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int t = min(wave + 8 * i, NINST - 1);
+            const int row = 16 * t + (lane >> 2);
+            const int c = (lane & 3) ^ (((row >> 3) & 1) << 1);
+            gp[i] = (row < BM) ? pl_A + (int64_t)min(m0 + row, pl_M - 1) * pl_K + c * 8
+                               : pl_W + (int64_t)(n0 + row - BM) * pl_K + c * 8;
+        }
     }
-    const bool last_slot = wave + 8 * (NSLOT - 1) < NINST;  // wave-uniform (waves 0,1)
+    const bool last_slot = wave + 8 * (NSLOT - 1) < NINST;  // wave-uniform (waves 0,1; KT = 64: waves 0..3)
     auto issue_one = [&](int ks, int stage, int i) {        // slot i of this wave for k-slice ks
         // (non-temporal policy on the weight rows - do the streamed weights flush the Infinity Cache? - measured in round 3: every
         // GEMM slower, the step 9.05 -> 10.16 ms; the 16 - 32 workgroups of an XCD that share a weight panel then miss in L2)
-        if (i < NSLOT - 1 || last_slot)
-            __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + ks * KS),
-                                             (LV*)(smem + stage * STAGE + (wave + 8 * i) * 512), 16, 0, 0);
+        if (i < NSLOT - 1 || last_slot) {
+            if constexpr (KT == 64)
+                __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(reinterpret_cast<const char*>((i < NA_SLOTS ? pl_A : pl_W) + ks * KS) + go[i]),
+                                                 (LV*)(smem + stage * STAGE + (wave + 8 * i) * 512), 16, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + ks * KS),
+                                                 (LV*)(smem + stage * STAGE + (wave + 8 * i) * 512), 16, 0, 0);
+        }
     };
 
     f32x4 acc[MI][NI];
@@ -1569,8 +1597,10 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int sw2 = ((lr >> 3) & 1) << 1;
-    const int a_off = (wm * 64 + lr) * KS + ((lg ^ sw2) << 3);            // + i * 16 rows
-    const int w_off = (BM + wn * 144 + lr) * KS + ((lg ^ sw2) << 3);      // + j * 16 rows
+    // KT = 64: chunk lg of the tile's first half (k 0 .. 31); the second half's chunk 4 + lg sits at `^ 32` halves (the swizzle is an XOR
+    // of the 16-byte slot index, and the fragment rows are 16 apart, so (row >> 1) & 7 depends on lr alone)
+    const int a_off = KT == 64 ? (wm * 64 + lr) * 64 + ((lg ^ ((lr >> 1) & 7)) << 3) : (wm * 64 + lr) * KS + ((lg ^ sw2) << 3);            // + i * 16 rows
+    const int w_off = KT == 64 ? (BM + wn * 144 + lr) * 64 + ((lg ^ ((lr >> 1) & 7)) << 3) : (BM + wn * 144 + lr) * KS + ((lg ^ sw2) << 3);      // + j * 16 rows
 
     const int nks = pl_K / KS;
     // fold consumer: the partial sums are requested in front of the first DMAs (vmcnt is in-order) and used behind their issue
@@ -1587,9 +1617,10 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
         }
     }
 #pragma unroll
-    for (int pre = 0; pre < NST - 1; ++pre)
+    for (int pre = 0; pre < (KT == 64 ? 2 : NST - 1); ++pre)
 #pragma unroll
-        for (int i = 0; i < NSLOT; ++i) issue_one(min(pre, nks - 1), pre, i);
+        for (int i = 0; i < NSLOT; ++i)
+            if (KT == 32 || pre < nks) issue_one(min(pre, nks - 1), pre, i);
     if constexpr (FOLD_C) {
         if (wave < BM / 64) fold_stats_finish<DT>(p, fpart, pl_M, pl_K, m0, tid, ni_t == 0, fstat);
         else if (tuv < BN / 2) {
@@ -1601,7 +1632,8 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
     // run (they need slice ks+1 to have landed one barrier earlier: "vmcnt(4)" = only slice ks+2 still in flight).
     constexpr int NPF = 3;
     V8 a_n[MI], b_n[NPF];
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");     // slice 0 landed
+    if (KT == 64 && nks < 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");     // slice 0 landed (KT = 64: tile 0; tile 1's 8 - 9 requests may be out)
     if (pl_prof) pc1 = __builtin_readcyclecounter();
     {
         const S* base0 = smem;
@@ -1620,6 +1652,57 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
     }
     auto main_loop = [&](auto swapped) {
     constexpr bool SW = decltype(swapped)::value;
+    if constexpr (KT == 64) {
+        for (int t = 0; t < nks; ++t) {
+            const S* base = smem + (t & 1) * STAGE;
+            const S* base_n = smem + ((t + 1) & 1) * STAGE;
+            const bool more = t + 2 < nks;                               // (uniform) tile t + 2 exists: it goes into tile t's stage
+            const bool late = t >= 1 && t + 1 < nks;                     // tile t + 1's last four requests (tiles 0 and 1: the prologue)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                V8 a[MI], b[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = a_n[i];
+#pragma unroll
+                for (int j = 0; j < NPF; ++j) b[j] = b_n[j];
+#pragma unroll
+                for (int j = NPF; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(base + ((w_off + j * 16 * 64) ^ (h << 5)));
+                // the next half's first fragments: tile t's second half, or tile t + 1's first (other stage: behind the barrier below)
+                const S* nb = h == 0 ? base : base_n;
+                const int nx = h == 0 ? 32 : 0;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    if (h == 1 && j == 2) {
+                        // every read of tile t has been issued; when this wave's have returned and its requests of tile t + 1 have landed
+                        // it may say so.  Behind the barrier: tile t + 1 is readable, tile t's stage is free.
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    }
+                    // tile t + 2 goes into tile t's stage: five of a wave's nine requests behind the barrier, four more between the first
+                    // MFMA groups of tile t + 1 - the request queue takes 68 x ~29 cycles of a 2304-cycle tile, so the issue is spread over
+                    // the whole period (a wave waits in the queue for every request it issues; bunched behind the barrier the requests cost
+                    // the loop 850 cycles per tile: 3150 measured)
+                    if (h == 1 && more) {
+                        if (j == 2) issue_one(t + 2, t & 1, 0);
+                        else if (j == 3) issue_one(t + 2, t & 1, 1);
+                        else if (j == 5) issue_one(t + 2, t & 1, 2);
+                        else if (j == 6) issue_one(t + 2, t & 1, 3);
+                        else if (j == 8) issue_one(t + 2, t & 1, 4);
+                    }
+                    if (h == 0 && late && j < 4) issue_one(t + 1, (t + 1) & 1, 5 + j);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        acc[i][j] = SW ? T16<DT>::mfma16(b[j], a[i], acc[i][j]) : T16<DT>::mfma16(a[i], b[j], acc[i][j]);
+                    if (j == NPF) {
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) a_n[i] = *reinterpret_cast<const V8*>(nb + ((a_off + i * 16 * 64) ^ nx));
+#pragma unroll
+                        for (int jj = 0; jj < NPF; ++jj) b_n[jj] = *reinterpret_cast<const V8*>(nb + ((w_off + jj * 16 * 64) ^ nx));
+                    }
+                }
+            }
+        }
+        return;
+    }
     int st = 0;
     for (int ks = 0; ks < nks; ++ks) {
         // slice ks+2 may stay in flight (4..5 DMAs per wave): <= 4 outstanding means slices ks and ks+1 have landed;
@@ -1819,11 +1902,15 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * 64 + i * 16 + lr;
 #ifdef PRIMX_PROBE_SKIPSTORE   // measurement builds only: 1 = odd tile columns store nothing, 2 = nobody stores (results invalid)
-        const bool ok = m < pl_M && !(PRIMX_PROBE_SKIPSTORE == 2 || (ni_t & 1));
+        const bool ok = m < pl_M && !(PRIMX_PROBE_SKIPSTORE == 2 || (PRIMX_PROBE_SKIPSTORE == 1 && (ni_t & 1)));
 #else
         const bool ok = m < pl_M;
 #endif
+#if defined(PRIMX_PROBE_SKIPSTORE) && PRIMX_PROBE_SKIPSTORE == 3   // every tile stores (and updates) rows 0 .. 255: the epilogue's instructions without its HBM traffic
+        const int mc = m & 255;
+#else
         const int mc = ok ? m : pl_M - 1;
+#endif
         if (EPI == EPI_GATE_RESIDUAL || FOLD_P) {
             const S* grow = p.gate + (int64_t)(mc / p.rows_per_batch) * p.gate_stride + nb;
             float* xrow = p.x + (int64_t)mc * pl_N + nb;
@@ -2598,6 +2685,38 @@ bool launch_pp(const GemmArgs<DT>& a, hipStream_t st) {
     return false;
 }
 
+static const bool g_kt32 = [] {   // PRIMX_GEMM_KT32=1: the 256x288 kernel on its round 1 - 5 ring of 32-wide slices (64-byte requests) for every K
+    const char* e = getenv("PRIMX_GEMM_KT32");
+    return e && atoi(e) != 0;
+}();
+
+static const int g_kt64_min = [] {   // PRIMX_GEMM_KT64_MIN: fewest 256x288 workgroups for which the dense-output epilogues take 128-byte row segments
+    const char* e = getenv("PRIMX_GEMM_KT64_MIN");
+    return e ? atoi(e) : 257;
+}();
+
+// Which ring: 128-byte row segments (KT = 64) for the dense-output epilogues of launches with more than one round of workgroups -
+// measured (profiles/r6_kt64_experiments.txt, same box): fc1 + GELU at T = 32768 466 -> 437 us, proj 145 -> 134, fc2 371 -> 345; at
+// ONE round (qkv at T = 4096: 192 workgroups) the two-stage ring's longer first wait costs more than the request rate gives (44.5 ->
+// 46.5 us), and the heads epilogues neither gain (T = 16384 qkv 137 vs 137 us) nor fit the registers (the compiler spills 7 - 29
+// dwords next to their two main loops): both keep the 32-wide ring.  (KT = 64 addresses its operands by 32-bit byte offsets.)
+template <int DT, int EPI>
+static void launch288q(const GemmArgs<DT>& x, dim3 grid, hipStream_t st) {
+    constexpr bool DENSE = EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_GATE_RESIDUAL_FOLD || EPI == EPI_LINEAR_FOLD ||
+                           EPI == EPI_RES;
+    if constexpr (DENSE) {
+        if (x.K % 64 == 0 && !g_kt32 && (int)grid.x >= g_kt64_min && (int64_t)x.M * x.K < (1ll << 31) && (int64_t)x.N * x.K < (1ll << 31)) {
+            PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d, 64>", DT, EPI);
+            hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI, 64>), grid, dim3(512), 0, st, PRIMX_GEMM_PASS(x));
+            return;
+        }
+    }
+    {
+        PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d>", DT, EPI);
+        hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI, 32>), grid, dim3(512), 0, st, PRIMX_GEMM_PASS(x));
+    }
+}
+
 template <int DT, int EPI, int BIG = 0>
 void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     const dim3 grid(BIG ? ((a.M + 255) / 256) * (a.N / 288) : mt * (a.N / 144));
@@ -2635,8 +2754,7 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
                     hipLaunchKernelGGL((gemm288p_dma_kernel<DT, true>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
                 }
             } else if constexpr (BIG) {
-                PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d>", DT, EPI);
-                hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, PRIMX_GEMM_PASS(x));
+                launch288q<DT, EPI>(x, grid, st);
             } else {
                 PRIMX_NOTE_KERNEL("gemm144l_dma_kernel<%d, %d>", DT, EPI);
                 hipLaunchKernelGGL((gemm144l_dma_kernel<DT, EPI>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
@@ -2650,8 +2768,7 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
             PRIMX_NOTE_KERNEL("gemm288p_dma_kernel<%d, false>", DT);
             hipLaunchKernelGGL((gemm288p_dma_kernel<DT>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
         } else if (BIG) {
-            PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d>", DT, EPI);
-            hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI>), grid, dim3(512), 0, st, PRIMX_GEMM_PASS(x));
+            launch288q<DT, EPI>(x, grid, st);
         } else if (g_loader && loader_ok && !g_gemm_prof_on) {   // (no timeline stamps in the loader-wave kernel)
             if constexpr (EPI == EPI_GATE_RESIDUAL) {
                 // LayerNorm of the updated rows in the kernel's tail: N = 1152 (nine 128-column chunks per half-wave row), 8-byte

@@ -87,7 +87,10 @@ def broadcast_packed_(model: torch.nn.Module, dtype: torch.dtype, src: int = 0) 
     rank, world = _world()
     if _single(world):
         return 0
-    pk = model.packed(dtype) if rank == src else model.packed_alloc(dtype)
+    if rank == src:
+        pk = model.packed(dtype)
+    else:                                                          # (an allocation the caller made ahead of the collective is reused)
+        pk = next((v for (d, _), v in getattr(model, "_pack", {}).items() if d == dtype), None) or model.packed_alloc(dtype)
     dist.broadcast(pk["_flat"], src=src)
     small = model.small_fp32_tensors()
     flat32 = torch.cat([t.reshape(-1).float() for t in small])

@@ -376,11 +376,19 @@ def main() -> None:
         if rank == 0:
             load_synth_weights(model, 28)
         model.reuse_cond_kv = bool(args.reuse_cond_kv)
+        pack_ms = 0.0
+        if world > 1:                                              # rank 0's fp32 -> 16-bit pack and the receivers' allocation are
+            torch.cuda.synchronize()                               # timed on their own: weight_broadcast_ms is the collective alone
+            tp0 = time.perf_counter()
+            model.packed(dt) if rank == 0 else model.packed_alloc(dt)
+            torch.cuda.synchronize()
+            pack_ms = 1e3 * (time.perf_counter() - tp0)
+            dist.barrier()
         torch.cuda.synchronize()
         tb0 = time.perf_counter()
         wbytes = broadcast_packed_(model, dt, 0)                  # RCCL: the packed 16-bit blob (N > 1)
         torch.cuda.synchronize()
-        wb_ms = 1e3 * (time.perf_counter() - tb0) if wbytes else 0.0   # (includes rank 0's fp32 -> 16-bit pack when it has not run yet)
+        wb_ms = 1e3 * (time.perf_counter() - tb0) if wbytes else 0.0
     decode_leg = args.config == "ddim" and not args.no_decode_leg
     if args.config in ("decode", "c4") or decode_leg:
         from oracle import synth
@@ -505,9 +513,11 @@ def main() -> None:
     # configs[3] per-GPU batch of 8 (T = 32768 tokens per launch: every GEMM on the 256 x 288 tile) and configs[1] in bf16 - the
     # north star's target dtype.  Same model, same kernels, K steps between synchronisations, median of R.
     side = {}
-    if args.config == "ddim" and rank == 0 and world == 1 and B == 1 and N == 2048 and not args.no_side_legs and not args.reuse_cond_kv:
+    # At N > 1 the `batch8` leg runs on EVERY rank (barrier on both sides, MAX over ranks, value = whole job) - the configs[2] shape
+    # of a SCALE record; the bf16 and stock-PyTorch legs stay single-GPU context.
+    if args.config == "ddim" and B == 1 and N == 2048 and not args.no_side_legs and not args.reuse_cond_kv:
         def side_leg(bs, sdt, k):
-            g2 = torch.Generator().manual_seed(77)
+            g2 = torch.Generator().manual_seed(77 + rank)
             xs = x if bs == 1 else torch.randn(bs, N, 68, generator=g2).to(dev)
             ys = y if bs == 1 else torch.randn(bs, L_COND, 768, generator=g2).to(dev)
             st = step_stream(diffusion, model, xs, dict(y=ys, cfg_scale=6.0, precision_dtype=sdt, enable_amp=True))
@@ -516,22 +526,29 @@ def main() -> None:
                 for _ in range(kk):
                     last["side"] = next(st)
             run(2)
-            el, _ = timed_repeats(run, k, max(1, args.repeats), 1, dist, dev)
+            el, own = timed_repeats(run, k, max(1, args.repeats), world, dist, dev)
             assert torch.isfinite(last["side"]["sample"]).all(), "non-finite sample (side leg)"
             e = statistics.median(el)
+            own_ms = [1e3 * statistics.median(own) / k]
+            if world > 1:
+                tt = torch.tensor(own_ms, dtype=torch.float64, device=dev)
+                allr = [torch.zeros_like(tt) for _ in range(world)]
+                dist.all_gather(allr, tt)
+                own_ms = [float(a.item()) for a in allr]
             fl = 2 * bs * forward_flops(N, L_COND)
             ln = 64 + (L_COND % 64 if L_COND > 64 else 0)
             ex = fl - (bs * kv_projection_flops(L_COND) * (1.0 - ln / L_COND) if getattr(model, "dedup_null_kv", False) else 0.0)
             return {"workload": workload_name(bs, N, "fp16" if sdt == torch.float16 else "bf16", "ddim25"), "steps": k,
-                    "ms_per_step": 1e3 * e / k, "value": bs * k / e, "unit": "denoise-steps/s",
-                    "repeats_ms_per_step": [1e3 * v / k for v in el],
+                    "ms_per_step": 1e3 * e / k, "value": world * bs * k / e, "unit": "denoise-steps/s",
+                    "repeats_ms_per_step": [1e3 * v / k for v in el], "per_rank_ms_per_step": own_ms,
                     "algorithmic_tflops_per_step": fl / 1e12, "executed_tflops_per_step": ex / 1e12,
-                    "achieved_tflops_whole_step": ex * k / e / 1e12, "frac_of_mfma_peak_whole_step": ex * k / e / 1e12 / PEAK_TFLOPS}
+                    "achieved_tflops_whole_step": world * ex * k / e / 1e12, "frac_of_mfma_peak_whole_step": ex * k / e / 1e12 / PEAK_TFLOPS}
         side["batch8"] = side_leg(8, dt, 5)
-        side["bf16" if dt == torch.float16 else "fp16"] = side_leg(1, torch.bfloat16 if dt == torch.float16 else torch.float16, args.steps)
-        torch.cuda.empty_cache()
-        side["torch_rocm_reference"] = torch_rocm_reference(model, x, y, dt, dev)
-        for bk, key in (("batch1", None), ("batch8", "batch8")):
+        if world == 1:
+            side["bf16" if dt == torch.float16 else "fp16"] = side_leg(1, torch.bfloat16 if dt == torch.float16 else torch.float16, args.steps)
+            torch.cuda.empty_cache()
+            side["torch_rocm_reference"] = torch_rocm_reference(model, x, y, dt, dev)
+        for bk, key in (("batch1", None), ("batch8", "batch8")) if world == 1 else ():
             mine_ms = (1e3 * elapsed / args.steps) if key is None else side[key]["ms_per_step"]
             if bk in side["torch_rocm_reference"]:
                 side["torch_rocm_reference"][bk]["this_framework_ms_per_step"] = mine_ms
@@ -601,7 +618,10 @@ def main() -> None:
             res["test_mode"] = "PRIMX_BENCH_SHARE_GPU=1: all ranks on one GPU over gloo - a code-path check, not a measurement"
         res["world_size_seen"] = len(ranks_seen)
         res["ranks_seen"] = ranks_seen
-        res["weight_broadcast_ms"] = wb_ms
+        res["weight_broadcast_ms"] = wb_ms                      # the collective alone (MAX over ranks), outside every timed loop
+        if world > 1 and args.config in ("ddim", "c4"):
+            res["weight_pack_ms_rank0"] = pack_ms
+            res["weight_broadcast_GBps"] = wbytes / wb_ms / 1e6 if wb_ms else None
         par = f"batch-sharded replicas x{world}, no collective in the loop"
         if args.config == "ddim":
             steps_per_s = world * B * args.steps / elapsed

@@ -26,7 +26,7 @@ def _default_dispatch() -> bool:
     import os
     return not any(os.environ.get(v) for v in ("PRIMX_GEMM_LOADER", "PRIMX_GEMM_NOBIG", "PRIMX_GEMM_P2", "PRIMX_GEMM_BIG_MIN",
                                                "PRIMX_GEMM_BIGHEADS_MIN", "PRIMX_GEMM_NOGEMV", "PRIMX_GEMM_PROF", "PRIMX_LIB",
-                                               "PRIMX_LN_FUSE", "PRIMX_LN_FUSE_MAXGRID", "PRIMX_GEMM_PP_ROUNDS"))
+                                               "PRIMX_LN_FUSE", "PRIMX_LN_FUSE_MAXGRID", "PRIMX_GEMM_PP_ROUNDS", "PRIMX_GEMM_KT32", "PRIMX_GEMM_KT64_MIN"))
 
 
 def _mk(seed, M, N, K, dtype):
@@ -221,6 +221,40 @@ def test_big_tile_edges(ops, dtype, M, K):
     xd = x.to(DEV)
     ops.linear_gate_residual(A.to(DEV), W.to(DEV), b.to(DEV), gate.to(DEV), xd, rows)
     assert rel_l2(xd - x.to(DEV), want - x.double()) < 2 * TOL[dtype]
+
+
+def test_large_batch_dense_epilogues_take_the_128_byte_ring(ops):
+    """Round 6: the 256 x 288 kernel streams its operands in 128-byte row segments (gemm288q_dma_kernel<., ., 64>) when a dense-output launch
+    has more than one round of workgroups; the 64-byte ring (PRIMX_GEMM_KT32=1) computes the same sums in the same order - per 32-wide
+    half of a tile - so the two agree to the last bit."""
+    import os
+    import subprocess
+    import sys
+    from topia_xl_amd import _lib
+    if not _default_dispatch():
+        pytest.skip("a kernel-selection switch is set")
+    f16, T, D = torch.float16, 8192, 1152
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = torch.randn(T, D, generator=g).to(DEV).to(f16)
+    W = (torch.randn(4 * D, D, generator=g) * D ** -0.5).to(DEV).to(f16)
+    b = torch.randn(4 * D, generator=g).to(DEV).to(f16)
+    out = ops.linear(A, W, b, act=1)
+    assert _lib.load().primx_last_gemm_kernel().decode() == "gemm288q_dma_kernel<1, 0, 64>"
+    ref = torch.nn.functional.gelu(torch.nn.functional.linear(A.double(), W.double(), b.double()).to(f16).double(), approximate="tanh")
+    err = float((out.double() - ref).norm() / ref.norm())
+    assert err < 6e-4, err
+    code = ("import sys, torch; sys.path.insert(0, %r); import topia_xl_amd; from topia_xl_amd import ops, _lib\n"
+            "g = torch.Generator(device='cpu').manual_seed(5); T, D = 8192, 1152\n"
+            "A = torch.randn(T, D, generator=g).cuda().half(); W = (torch.randn(4 * D, D, generator=g) * D ** -0.5).cuda().half(); b = torch.randn(4 * D, generator=g).cuda().half()\n"
+            "o = ops.linear(A, W, b, act=1); assert _lib.load().primx_last_gemm_kernel().decode() == 'gemm288q_dma_kernel<1, 0>'\n"
+            "torch.save(o.cpu(), sys.argv[1])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, "o.pt")
+        env = dict(os.environ, PRIMX_GEMM_KT32="1")
+        r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert torch.equal(torch.load(f), out.cpu())
 
 
 def test_reported_kernel_names_of_the_headline_shapes(ops):
