@@ -1898,6 +1898,70 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
         bpre[j] = V4e{};
         if (p.bias && EPI != EPI_CONVT && EPI != EPI_LINEAR_FOLD) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + nb + j * 16);
     }
+#ifndef PRIMX_PROBE_SKIPSTORE
+    if constexpr (EPI == EPI_GATE_RESIDUAL && KT == 64) {
+        // Round 6: the fp32 read-modify-write of the residual rows as a pipeline.  The epilogue below asks for a row group's 36 + 18
+        // registers of x and gate, waits a full memory round trip, updates, stores, and only then asks for the next group: four exposed
+        // round trips, 30 - 37k cycles per tile.  Here two row groups are always on their way: the accumulators are rounded to their
+        // 16-bit values rnd16(acc + bias) - the reference's Linear output: what the gate multiplies is a 16-bit number - which halves
+        // their registers and pays for the second buffer, and group i + 2 is requested the moment group i has been stored: 26 - 28k
+        // cycles (profiles/r6_kt64_experiments.txt).  Full tiles inside one batch entry only (one gate row, no row clamp): the launcher
+        // sends only M % 256 == 0 && rows_per_batch % 256 == 0 to this instantiation (launch288q).  Same arithmetic, same order:
+        // bit-identical results.  The ORDER of the requests below is the one that fits 256 registers: every other one tried (group 0
+        // requested before the first rounding; both buffers before the second; gate row in LDS) spilled 10 - 40 dwords, and a reload
+        // from scratch waits in the in-order vmcnt queue behind the row group requested in front of it - 71k cycles measured.
+        // The LayerNorm-fold producer (EPI_GATE_RESIDUAL_FOLD: + operand store + partial sums) does not fit two buffers; it keeps the loop.
+        {
+            const S* grow = p.gate + (int64_t)(m0 / p.rows_per_batch) * p.gate_stride + nb;
+            float* xrow0 = p.x + (int64_t)(m0 + wm * 64 + lr) * pl_N + nb;
+            const int64_t gstep = (int64_t)16 * pl_N;          // floats between the row groups of a lane
+            f32x4 xa[NI], xb[NI];
+            auto load_x = [&](f32x4 (&xv)[NI], int i) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) xv[j] = *reinterpret_cast<const f32x4*>(xrow0 + i * gstep + j * 16);
+            };
+            V4e pk[MI][NI];                                     // rnd16(acc + bias)
+            auto pack = [&](int i) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk[i][j][r] = (S)(acc[i][j][r] + (p.bias ? (float)bpre[j][r] : 0.f));
+            };
+            pack(2);                                            // (first: 72 accumulator registers become 36 before the loads need theirs)
+            pack(3);
+            { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+            load_x(xa, 0);
+            { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+            pack(0);
+            pack(1);
+            { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+            load_x(xb, 1);
+            V4e gv[NI];                                         // (behind the last use of the bias registers)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) gv[j] = *reinterpret_cast<const V4e*>(grow + j * 16);
+            auto update = [&](f32x4 (&xv)[NI], int i) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xv[j][r] += rnd16<DT>((float)gv[j][r] * (float)pk[i][j][r]);
+                    out_store(reinterpret_cast<f32x4*>(xrow0 + i * gstep + j * 16), xv[j]);
+                }
+            };
+            update(xa, 0);
+            { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+            load_x(xa, 2);
+            { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+            update(xb, 1);
+            { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+            load_x(xb, 3);
+            { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+            update(xa, 2);
+            update(xb, 3);
+            prof_end();
+            return;
+        }
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * 64 + i * 16 + lr;
@@ -2705,7 +2769,8 @@ static void launch288q(const GemmArgs<DT>& x, dim3 grid, hipStream_t st) {
     constexpr bool DENSE = EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_GATE_RESIDUAL_FOLD || EPI == EPI_LINEAR_FOLD ||
                            EPI == EPI_RES;
     if constexpr (DENSE) {
-        if (x.K % 64 == 0 && !g_kt32 && (int)grid.x >= g_kt64_min && (int64_t)x.M * x.K < (1ll << 31) && (int64_t)x.N * x.K < (1ll << 31)) {
+        const bool full = EPI != EPI_GATE_RESIDUAL || (x.M % 256 == 0 && x.rows_per_batch % 256 == 0);   // (its pipelined epilogue: no ragged tile, one gate row per tile)
+        if (x.K % 64 == 0 && !g_kt32 && full && (int)grid.x >= g_kt64_min && (int64_t)x.M * x.K < (1ll << 31) && (int64_t)x.N * x.K < (1ll << 31)) {
             PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d, 64>", DT, EPI);
             hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI, 64>), grid, dim3(512), 0, st, PRIMX_GEMM_PASS(x));
             return;
