@@ -15,12 +15,31 @@ LIB_PATH = os.environ.get("PRIMX_LIB") or os.path.join(_HERE, "csrc", "libprimx_
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
 HEADS_ROWS, HEADS_VT, HEADS_KROWS = 0, 1, 2
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
+
+
+class DitBlockFold(C.Structure):
+    """PrimxDitBlockFold (include/primx_hip.h): weights, cross-attention operands, fold tables and prefetch ranges of one DiT block."""
+    _fields_ = [(n, _p) for n in ("w_q", "b_q", "w_cproj", "b_cproj", "w_qkv", "w_proj", "b_proj", "w_fc1", "w_fc2", "b_fc2",
+                                  "Kc", "Vc", "Kb", "Vb", "uv_q", "uv_qkv", "uv_fc1",
+                                  "carry_q", "carry_cproj", "carry_fc1", "carry_fc2")] + \
+               [(n, _l) for n in ("carry_q_bytes", "carry_cproj_bytes", "carry_fc1_bytes", "carry_fc2_bytes")]
+
+
+class DitForwardFold(C.Structure):
+    """PrimxDitForwardFold (include/primx_hip.h): one forward's shapes, workspaces and tables."""
+    _fields_ = [(n, _i) for n in ("dtype", "Be", "N", "D", "H", "dh", "hidden", "depth", "L", "nq_pad", "nkv_pad_c", "nkv_pad_b",
+                                  "b_from", "step", "n_steps")] + \
+               [("ln_eps", _f), ("scale", _f)] + \
+               [(n, _p) for n in ("h", "xn", "att", "hid", "Qc", "Qs", "Ks", "Vs", "mod", "center0", "center1", "part")]
+
+
 # name -> argument ctypes (return type is always int unless listed in _RESTYPES)
 SIGNATURES = {
+    "primx_dit_blocks_fold": [C.POINTER(DitForwardFold), C.POINTER(DitBlockFold), _p],
     "primx_abi_version": [],
     "primx_last_error": [],
     "primx_last_gemm_kernel": [],
@@ -77,11 +96,14 @@ _RESTYPES = {"primx_last_error": C.c_char_p, "primx_last_gemm_kernel": C.c_char_
 # an alternate build named by PRIMX_LIB (same-box A/B against another build) must speak the same ABI: version 21 changed the
 # argument lists of the GEMM / LayerNorm entry points (explicit prefetch ranges), so older libraries cannot be bound any more;
 # versions 22 / 23 only added / re-typed the LayerNorm-fold entry points, so a version-21 or -22 build can stand in as long as
-# nothing folds: the fold prototypes are not bound to such a build and `fold_available()` is False (ops.fold_shapes_ok asks)
+# nothing folds: the fold prototypes are not bound to such a build and `fold_available()` is False (ops.fold_shapes_ok asks);
+# version 24 added primx_dit_blocks_fold (one foreign call for a forward's blocks): a version-23 build lacks only that one, and the
+# host then issues the launches itself (`blocks_call_available()`)
 _FOLD_ENTRY_POINTS: set = {"primx_linear_f32out", "primx_row_stats", "primx_linear_gate_residual_fold", "primx_linear_heads_fold",
                            "primx_linear_fold"}
-_AB_ABI_VERSIONS: tuple = (21, 22)
+_AB_ABI_VERSIONS: tuple = (21, 22, 23)
 _fold_available: dict = {}
+_blocks_call: dict = {}
 
 _lib: Optional[C.CDLL] = None
 
@@ -123,12 +145,15 @@ def load(path: Optional[str] = None) -> C.CDLL:
     if got != ABI_VERSION and not (ab and got in _AB_ABI_VERSIONS):
         raise RuntimeError(f"libprimx_hip.so ABI {got} != expected {ABI_VERSION}; rebuild it")
     for name, argtypes in SIGNATURES.items():
-        if got != ABI_VERSION and name in _FOLD_ENTRY_POINTS:
+        if got < 23 and name in _FOLD_ENTRY_POINTS:
             continue                # an older A/B build: its fold entry points (if any) have other argument lists
+        if got < 24 and name == "primx_dit_blocks_fold":
+            continue
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
-    _fold_available[path] = got == ABI_VERSION
+    _fold_available[path] = got >= 23
+    _blocks_call[path] = got >= 24
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -138,6 +163,12 @@ def fold_available() -> bool:
     """Does the loaded library carry the LayerNorm-fold entry points of this ABI?  (False only for an older PRIMX_LIB A/B build.)"""
     load()
     return _fold_available.get(LIB_PATH, False)
+
+
+def blocks_call_available() -> bool:
+    """Does the loaded library carry primx_dit_blocks_fold (ABI 24)?"""
+    load()
+    return _blocks_call.get(LIB_PATH, False)
 
 
 def check(status: int, name: str) -> None:

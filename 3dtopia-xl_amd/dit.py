@@ -32,7 +32,9 @@ from typing import Dict, Optional
 import torch
 from torch import nn
 
-from . import ops
+import ctypes as C
+
+from . import _lib, ops
 from ._lib import ACT_GELU_TANH, HEADS_KROWS, HEADS_ROWS, HEADS_VT
 from .attention import MemEffAttention, MemEffCrossAttention, _c16
 
@@ -186,6 +188,10 @@ class DiT(nn.Module):
         # call - unplanned forwards included - takes the LayerNorm launches.
         self.fold_ln = os.environ.get("PRIMX_DIT_FOLD", "1") != "0"
         self._fold_ws: Dict = {}              # (device, rows) -> (center, part) workspaces of the fold
+        # `blocks_call` (round 6; PRIMX_DIT_BLOCKS_CALL=0 turns it off): a folded forward hands its block loop to the library in ONE
+        # foreign call (primx_dit_blocks_fold, ABI 24: the same entry points with the same arguments, issued from C) instead of 8
+        # Python + ctypes calls per block.  Bit-identical; what changes is the host's time per step (tools/host_bound_check.py).
+        self.blocks_call = os.environ.get("PRIMX_DIT_BLOCKS_CALL", "1") != "0"
         # Dynamic range (fp16): the folded operand cast16((x - c) rho_p (1 + scale)) is normalised with the PREVIOUS site's (mean, rstd)
         # of the row (ABI 23) - the LayerNorm output up to the factor rho_p / rho by which one gated branch changes the row's spread.
         # Magnitude and spread of the residual stream do not enter (tests/test_hip_fold.py: spreads 3e4 and 1e-5, magnitude 1e4); the
@@ -862,6 +868,38 @@ class DiT(nn.Module):
                         side.wait_event(lag)             # the side chain starts when the main one is three kernels in
                     block(i, w, B, Be)
             main.wait_stream(side)
+        elif (fold_uv is not None and self.blocks_call and sync is None and ops.PROFILE is None and self.block_probe is None
+              and _lib.blocks_call_available()):
+            # ONE foreign call for the forward's blocks (primx_dit_blocks_fold, ABI 24): the C side issues the launches block() below
+            # would - same entry points, same arguments, same order, bit-identical results - at ~1 us of host time each instead of
+            # ~21 us of Python + ctypes (tools/host_bound_check.py).  The per-block descriptors are built once per planned loop.
+            fd = plan["fold"]
+            dkey = (Kc.data_ptr(), Vc.data_ptr(), Kn_blk[0].data_ptr() if dedup else 0, wpf, Bkv)
+            if fd.get("desc_key") != dkey:
+                arr = (_lib.DitBlockFold * self.depth)()
+                rng = lambda t: ops._range(t) if wpf == 2 else (None, 0)
+                for i, w in enumerate(blocks):
+                    d = arr[i]
+                    for name in ("w_q", "b_q", "w_cproj", "b_cproj", "w_qkv", "w_proj", "b_proj", "w_fc1", "w_fc2", "b_fc2"):
+                        setattr(d, name, None if w[name] is None else w[name].data_ptr())
+                    d.Kc, d.Vc = Kc_blk[i].data_ptr(), Vc_blk[i].data_ptr()
+                    d.Kb, d.Vb = (Kn_blk[i].data_ptr(), Vn_blk[i].data_ptr()) if dedup else (None, None)
+                    d.uv_q = None if fold_uv[i][0] is None else fold_uv[i][0].data_ptr()
+                    d.uv_qkv, d.uv_fc1 = fold_uv[i][1].data_ptr(), fold_uv[i][2].data_ptr()
+                    for cname, t in (("carry_q", w["w_cproj"]), ("carry_cproj", w["w_proj"]), ("carry_fc1", w["w_fc2"]),
+                                     ("carry_fc2", blocks[i + 1]["w_q"] if i + 1 < self.depth else None)):
+                        cp, cn = rng(t) if t is not None else (None, 0)
+                        setattr(d, cname, cp)
+                        setattr(d, cname + "_bytes", cn)
+                fd["desc"], fd["desc_key"] = arr, dkey
+            f = _lib.DitForwardFold(
+                dtype=ops.dtype_code(dt), Be=Be, N=N, D=D, H=H, dh=dh, hidden=hid.shape[1], depth=self.depth, L=L, nq_pad=nq_pad,
+                nkv_pad_c=Kc.shape[2], nkv_pad_b=Kn_blk[0].shape[2] if dedup else 0, b_from=B if dedup else Be, step=prow,
+                n_steps=plan["t"].numel(), ln_eps=self.LN_EPS, scale=scale, h=h.data_ptr(), xn=xn.data_ptr(), att=att.data_ptr(),
+                hid=hid.data_ptr(), Qc=Qc.data_ptr(), Qs=Qs.data_ptr(), Ks=Ks.data_ptr(), Vs=Vs.data_ptr(), mod=mod.data_ptr(),
+                center0=fcent[0].data_ptr(), center1=fcent[1].data_ptr(), part=fpart.data_ptr())
+            ops._dev(h, "h", torch.float32)                 # (the launch-device check of every op: ops._stream)
+            _lib.check(_lib.load().primx_dit_blocks_fold(C.byref(f), fd["desc"], ops._stream()), "primx_dit_blocks_fold")
         else:
             for i, w in enumerate(pk["blocks"]):
                 block(i, w, 0, Be)

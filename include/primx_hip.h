@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 23
+#define PRIMX_ABI_VERSION 24
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -264,6 +264,51 @@ int primx_attention(const void* Qp, const void* Kp, const void* Vt, void* out, i
 int primx_attention_bcast(const void* Qp, const void* Kp, const void* Vt, void* out, int B, int H, int nq, int nq_pad, int nkv,
                           int nkv_pad, int dh, float scale, const void* Kb, const void* Vb, int b_from, int nkv_pad_b, int dtype,
                           void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * The DiT blocks of one planned, folded forward from ONE call (ABI 24)
+ * -------------------------------------------------------------------------------------------- */
+
+/* Weights and per-block operands of DiTBlock i (models/dit_crossattn.py:26-58): 16-bit (out, in) matrices and biases of
+ * CrossAttention.to_q / .proj (models/attention.py:83-87), Attention.qkv / .proj (:37-39), Mlp.fc1 / .fc2 (models/utils.py:87-101);
+ * the block's cross-attention operands as primx_linear_heads wrote them (Kc / Vc: the entries with their own conditioning tokens,
+ * Kb / Vb: the broadcast entry of primx_attention_bcast or NULL); the LayerNorm fold's per-timestep rows of the block's three sites
+ * (primx_linear_f32out: fp32 [2][n_steps][N_site], u rows then v rows; uv_q == NULL: the site keeps its LayerNorm launch - block 0).
+ * `carry_*`: the cache-prefetch range (pointer, bytes; (NULL, 0) = none) that the launch of that GEMM carries. */
+typedef struct PrimxDitBlockFold {
+    const void *w_q, *b_q, *w_cproj, *b_cproj, *w_qkv, *w_proj, *b_proj, *w_fc1, *w_fc2, *b_fc2;
+    const void *Kc, *Vc, *Kb, *Vb;
+    const float *uv_q, *uv_qkv, *uv_fc1;
+    const void *carry_q, *carry_cproj, *carry_fc1, *carry_fc2;
+    int64_t carry_q_bytes, carry_cproj_bytes, carry_fc1_bytes, carry_fc2_bytes;
+} PrimxDitBlockFold;
+
+/* One forward's shapes, workspaces and tables.  Be = effective batch (2 B under classifier-free guidance), T = Be * N token rows.
+ * h: fp32 residual stream [T, D] (in / out); xn: 16-bit [T, D] (LayerNorm output / folded operand); att: 16-bit [Be, N, D];
+ * hid: 16-bit [T, hidden]; Qc, Qs: ROWS operands [Be, H, nq_pad, DP]; Ks: KROWS [Be, H, nq_pad, DP + 8]; Vs: VT [Be, H, DP, nq_pad];
+ * mod: this forward's adaLN row (16-bit, depth * 9 D + 2 D elements: per block shift / scale / gate of the cross-attention,
+ * self-attention and MLP branch, then the final layer's shift / scale - dit_crossattn.py:54,69-75), shared by all batch entries;
+ * center0 / center1: the fold's two (centre, scale) arrays [T][2] fp32; part: [T][D / 144][2] fp32; step: this forward's row of the
+ * u / v tables, n_steps their row count.  b_from: first batch entry that attends to the broadcast conditioning entry (== Be: none);
+ * L: conditioning tokens, nkv_pad_c / nkv_pad_b: padded key counts of Kc / Kb. */
+typedef struct PrimxDitForwardFold {
+    int dtype, Be, N, D, H, dh, hidden, depth, L, nq_pad, nkv_pad_c, nkv_pad_b, b_from, step, n_steps;
+    float ln_eps, scale;
+    float* h;
+    void *xn, *att, *hid, *Qc, *Qs, *Ks, *Vs;
+    const void* mod;
+    float *center0, *center1, *part;
+} PrimxDitForwardFold;
+
+/* The `depth` DiT blocks of a forward whose LayerNorms are folded (every call below is one of this header's entry points, issued
+ * in the order and with the arguments `DiT._forward16` of the Python host issues them - same kernels, bit-identical results; the
+ * host makes ONE foreign call per forward instead of 8 per block: 231 -> 10 per DDIM step at depth 28).  Per block:
+ *   block 0 only: primx_layernorm_modulate + primx_row_stats + primx_linear_heads (to_q);  other blocks: primx_linear_heads_fold (to_q)
+ *   primx_attention[_bcast] (cross)  ->  primx_linear_gate_residual_fold (cross proj)  ->  primx_linear_heads_fold (qkv)
+ *   ->  primx_attention (self)  ->  primx_linear_gate_residual_fold (proj)  ->  primx_linear_fold (fc1 + GELU-tanh)
+ *   ->  primx_linear_gate_residual_fold (fc2; last block: primx_linear_gate_residual_ln with the final layer's shift / scale).
+ * Replaces the loop `for block in self.blocks: x = block(x, y, c)` (models/dit_crossattn.py:198-199) of a planned sampling loop. */
+int primx_dit_blocks_fold(const PrimxDitForwardFold* f, const PrimxDitBlockFold* blocks, void* stream);
 
 /* Gather a [B, M, H, dh] tensor with arbitrary element strides (the xFormers BMHK operand, e.g.
  * a view into the fused qkv buffer) into an attention operand layout. */

@@ -453,3 +453,65 @@ def test_dit_fold_with_massive_activation_channels(ops, dtype):
         m.clear_timestep_plan()
     print(f"massive channels {dtype} forward_with_cfg vs fp32 oracle: unfolded {errs[False]:.3e}, folded {errs[True]:.3e}")
     assert errs[True] < 1.25 * errs[False] + 1e-4
+
+
+@pytest.mark.parametrize("dtype,batch,dedup", [(torch.float16, 1, True), (torch.bfloat16, 1, True), (torch.float16, 2, False)])
+def test_blocks_call_is_bit_identical_to_the_python_block_loop(ops, dtype, batch, dedup):
+    """primx_dit_blocks_fold (ABI 24): a folded forward's blocks issued by the library from ONE foreign call - the same entry points with
+    the same arguments as DiT._forward16's Python loop (`blocks_call = False`), so every sample of a planned DDIM loop is the same to the
+    last bit, with the broadcast null K / V entry and with expanded ones, at batch 1 and 2; the host really makes one call per forward."""
+    import topia_xl_amd as pkg
+    from topia_xl_amd import _lib
+    if not _lib.blocks_call_available():
+        pytest.skip("the loaded library has no primx_dit_blocks_fold")
+    sd, m = _fold_model(pkg, 3, 83)
+    m.dedup_null_kv = dedup
+    x, y = synth.tensor(83, "x", (batch, 2048, 68)), synth.tensor(83, "y", (batch, 1370, 768))
+    d = pkg.create_diffusion("ddim4", noise_schedule="squaredcos_cap_v2", parameterization="v")
+    kw = dict(y=y.to(DEV), cfg_scale=6.0, precision_dtype=dtype, enable_amp=True)
+
+    def loop():
+        return [o["sample"].clone() for o in d.ddim_sample_loop_progressive(m.forward_with_cfg, tuple(x.shape), noise=x.to(DEV),
+                                                                            clip_denoised=False, model_kwargs=kw)]
+    lib = _lib.load()
+    calls = []
+    real = lib.primx_dit_blocks_fold
+
+    class Spy:          # (ctypes function objects cannot be monkeypatched in place: wrap the attribute)
+        def __call__(self, *a):
+            calls.append(1)
+            return real(*a)
+    m.blocks_call = False
+    base = loop()
+    m.blocks_call = True
+    lib.primx_dit_blocks_fold = Spy()
+    try:
+        got = loop()
+    finally:
+        lib.primx_dit_blocks_fold = real
+    folds = m.fold_ln and m._fold_ok(2 * batch * 2048, 2048) and os.environ.get("PRIMX_PLAN_TIMESTEPS", "1") != "0" \
+        and not os.environ.get("PRIMX_CFG_STREAMS") and os.environ.get("PRIMX_DIT_LN_TAIL") != "1" and os.environ.get("PRIMX_DIT_FUSE_LN") != "0" \
+        and os.environ.get("PRIMX_WPREFETCH", "2") != "1" and os.environ.get("PRIMX_DIT_BLOCKS_CALL") != "0"
+    assert len(calls) == (4 if folds else 0), len(calls)
+    for a, b in zip(got, base):
+        assert torch.equal(a, b)
+
+
+def test_blocks_call_rejects_bad_descriptors(ops):
+    """Argument validation of primx_dit_blocks_fold happens before anything is launched (no compute needed to see the error codes)."""
+    import ctypes as C
+    from topia_xl_amd import _lib
+    if not _lib.blocks_call_available():
+        pytest.skip("the loaded library has no primx_dit_blocks_fold")
+    lib = _lib.load()
+    blk = (_lib.DitBlockFold * 1)()
+    f = _lib.DitForwardFold(dtype=_lib.F16, Be=2, N=2048, D=1152, H=16, dh=72, hidden=4608, depth=1, L=1370, nq_pad=2048, nkv_pad_c=1536,
+                            nkv_pad_b=128, b_from=1, step=0, n_steps=1, ln_eps=1e-6, scale=72 ** -0.5)
+    assert lib.primx_dit_blocks_fold(C.byref(f), blk, None) == -1 and b"null workspace" in lib.primx_last_error()
+    f.dh = 64
+    assert lib.primx_dit_blocks_fold(C.byref(f), blk, None) == -1 and b"bad shape" in lib.primx_last_error()
+    f.dh, f.step = 72, 3
+    assert lib.primx_dit_blocks_fold(C.byref(f), blk, None) == -1 and b"outside the u / v tables" in lib.primx_last_error()
+    f.step, f.dtype = 0, 0
+    assert lib.primx_dit_blocks_fold(C.byref(f), blk, None) == -1 and b"dtype" in lib.primx_last_error()
+    assert lib.primx_dit_blocks_fold(None, blk, None) == -1

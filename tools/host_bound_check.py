@@ -35,16 +35,21 @@ torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"sampling loop: enqueue {1e3 * (t1 - t0) / 25:.2f} ms/step   total {1e3 * (t2 - t0) / 25:.3f} ms/step   (the enqueue time includes "
       "back-pressure: HIP blocks the host once a few hundred launches are queued)")
-# without back-pressure: ONE step at a time, the queue empty when its enqueue starts
-one = []
-for _ in range(12):
+# without back-pressure: ONE step at a time, the queue empty when its enqueue starts - with the forward's blocks issued by the library
+# from one foreign call (primx_dit_blocks_fold, the default) and by the Python block loop (DiT.blocks_call = False)
+for bc in (True, False, True, False):
+    model.blocks_call = bc
+    one = []
+    for _ in range(10):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        next(stream)
+        one.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    next(stream)
-    one.append(time.perf_counter() - t0)
-torch.cuda.synchronize()
-one.sort()
-print(f"one step enqueued into an empty queue: median {1e3 * one[len(one) // 2]:.2f} ms, min {1e3 * one[0]:.2f} ms of host time (the GPU needs ~8.5)")
+    one.sort()
+    print(f"blocks_call={bc}: one step enqueued into an empty queue: median {1e3 * one[len(one) // 2]:.2f} ms, min {1e3 * one[0]:.2f} ms of host "
+          "time (the GPU needs ~8.3)", flush=True)
+model.blocks_call = True
 stream.close()
 
 t = torch.full((1,), 480, device=dev, dtype=torch.int64)
