@@ -64,7 +64,7 @@ __device__ __forceinline__ V8 ldg16(const void* ptr) {
 // switches until round 4; their measurements are in DESIGN_LOG.md section 5.)
 __device__ unsigned long long g_attn_prof[8];
 
-template <int DT, int KSTEPS, int DTILES, int KMASK, int PROF = 0, int FUSED = 0>
+template <int DT, int KSTEPS, int DTILES, int KMASK, int PROF = 0>
 __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>::S* __restrict__ Qp,
                                                           const typename T16<DT>::S* __restrict__ Kp,
                                                           const typename T16<DT>::S* __restrict__ Vt,
@@ -413,121 +413,6 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
         qk(kf0, 0, sA);                   // S(0)
     }
     if (PROF) pt = __builtin_readcyclecounter();
-    if constexpr (FUSED) {
-        // ---- Round 6: ONE instruction stream per step, ONE barrier per step.  The ping-pong below gives each SIMD one wave in a
-        // matrix segment and one in a light segment, four barriers per step: its segment profile (PRIMX_ATTN_PROF) reads light 904 |
-        // matrix 931 | waits 414 = 2249 cycles per 64-key step and wave for 704 cycles of MFMA - each wave runs its two segments back
-        // to back, so a SIMD's matrix pipe is busy 2 x 704 of 2249.  Here everything that is not an MFMA sits in the shadow of one:
-        //   R1   QK^T(j+1) k-steps 0 .. KSTEPS-2 (they do not touch the max columns)   ||  row max of S(j)
-        //        (rare, uniform) raise the running max: Q's max columns, S(j), O
-        //   R2a  last QK^T k-step                                                      ||  probabilities of keys 0 .. 15
-        //        wait for MY pieces of pair j+1, barrier (pair j+1 has landed for everybody; pair j-1's stage is free),
-        //        request pair j+2, read K(j+2)'s fragments (the K registers are free)
-        //   R2b  PV keys 0-15 || probabilities 16-31;  PV 16-31 || probabilities 32-47;  read V(j+1) first half;
-        //        PV 32-47 || probabilities 48-63;  PV 48-63;  read V(j+1) second half
-        // so a wave needs ~22 x 32 cycles plus what does not fit the shadows, and the two waves of a SIMD interleave freely.
-        static_assert(QCOL, "the fused loop is built for the operand-carried max (dh = 72)");
-        V8 kf[2][KSTEPS], vf0[DTILES][2], vf1[DTILES][2];
-        // V^T fragment addresses: row t*32 + l31, 16-byte slot (4 half + 2 k2 + hi) ^ sw  =  ((hi ^ sw) ^ (4 half + 2 k2)) - the lane part
-        // is formed once, a step adds the stage and XORs the constant: 5 VALU per step (hipcc's own form of read_v: ~20)
-        const int vA = KT + l31 * 64 + ((hi ^ ((l31 >> 1) & 7)) << 3);
-        auto read_v2 = [&](int stage, int half, V8 (&vf)[DTILES][2]) {
-            const int vs = vA + stage * BUF;                       // (BUF and KT are multiples of 64 halves: bits 3 - 5 stay the slot's)
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const S* vp = smem + (vs ^ ((4 * half + 2 * k2) << 3));
-#pragma unroll
-                for (int t = 0; t < DTILES; ++t) vf[t][k2] = *reinterpret_cast<const V8*>(vp + t * 32 * 64);
-            }
-        };
-        read_k(0, kf);
-        read_v2(0, 0, vf0);
-        read_v2(0, 1, vf1);
-        auto probs16 = [&](const f32x16& sh, int k2, V8& pbk) {     // probabilities of one 16-key MFMA step (exp2 of the MFMA's own output)
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(sh[8 * k2 + e]), p1 = __builtin_amdgcn_exp2f(sh[8 * k2 + e + 1]);
-                if constexpr (DT == PRIMX_F16) {
-                    const auto h2 = __builtin_amdgcn_cvt_pkrtz(p0, p1);
-                    pbk[e] = h2[0];
-                    pbk[e + 1] = h2[1];
-                } else {
-                    const unsigned u = __builtin_amdgcn_perm(__float_as_uint(p1), __float_as_uint(p0), 0x07060302u);
-                    typedef S S2 __attribute__((ext_vector_type(2)));
-                    const S2 h2 = __builtin_bit_cast(S2, u);
-                    pbk[e] = h2[0];
-                    pbk[e + 1] = h2[1];
-                }
-            }
-        };
-        auto pv_step = [&](const V8 (&vf)[DTILES][2], int k2, const V8& pbk) {
-#pragma unroll
-            for (int t = 0; t < DTILES; ++t) o[t] = T16<DT>::mfma32(vf[t][k2], pbk, o[t]);
-        };
-        auto fused_step = [&](int j, int st_next, f32x16 (&sc)[2], f32x16 (&sn)[2], bool first) {   // st_next: stage of pair j+1 = {K(j+2), V(j+1)}
-            // ---- R1
-            float mx = fmaxf(sc[0][0], sc[1][0]);
-#pragma unroll
-            for (int s_ = 0; s_ < KSTEPS - 1; ++s_) {
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) sn[kt] = T16<DT>::mfma32(kf[kt][s_], qf[s_], s_ == 0 ? zero16 : sn[kt]);
-#pragma unroll
-                for (int r = 1 + 4 * s_; r < 1 + 4 * (s_ + 1) && r < 16; ++r) mx = fmaxf(fmaxf(mx, sc[0][r]), sc[1][r]);
-            }
-#pragma unroll
-            for (int r = 1 + 4 * (KSTEPS - 1); r < 16; ++r) mx = fmaxf(fmaxf(mx, sc[0][r]), sc[1][r]);
-            {
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-            }
-            if (first || !__all(mx <= RESCALE_THR)) {           // (see fold_max: a real branch, rare after the first tiles)
-                asm volatile("" ::: "memory");
-                const float delta = first ? mx : fmaxf(mx, 0.f);
-                const float alpha = __builtin_amdgcn_exp2f(-delta);
-                m_run += delta;
-                set_q_cols(m_run);
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sc[kt][r] -= delta;
-#pragma unroll
-                for (int t = 0; t < DTILES; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-            }
-            // ---- R2a
-            V8 pb[4];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) sn[kt] = T16<DT>::mfma32(kf[kt][KSTEPS - 1], qf[KSTEPS - 1], sn[kt]);
-            probs16(sc[0], 0, pb[0]);
-            PRIMX_ATTN_WAITB_N(0);                               // my pieces of pair j+1 have landed, my LDS reads are home; barrier
-            issue_pair(j + 2, st_next == NSTAGE - 1 ? 0 : st_next + 1);
-            read_k(st_next, kf);
-            // ---- R2b
-            pv_step(vf0, 0, pb[0]);
-            probs16(sc[0], 1, pb[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            pv_step(vf0, 1, pb[1]);
-            probs16(sc[1], 0, pb[2]);
-            __builtin_amdgcn_sched_barrier(0);
-            read_v2(st_next, 0, vf0);
-            pv_step(vf1, 0, pb[2]);
-            probs16(sc[1], 1, pb[3]);
-            __builtin_amdgcn_sched_barrier(0);
-            pv_step(vf1, 1, pb[3]);
-            read_v2(st_next, 1, vf1);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        int j = 0, stn = 1;                                        // step j reads pair j+1 from stage (j + 1) % NSTAGE
-        for (; j + 1 < ntiles; j += 2) {
-            fused_step(j, stn, sA, sB, j == 0);
-            stn = stn == NSTAGE - 1 ? 0 : stn + 1;
-            fused_step(j + 1, stn, sB, sA, false);
-            stn = stn == NSTAGE - 1 ? 0 : stn + 1;
-        }
-        if (j < ntiles) fused_step(j, stn, sA, sB, j == 0);
-        __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): drain the clamped tail DMAs before the workgroup retires
-    } else {
     // ---- main loop.  Group 0 runs  L B M B,  group 1 runs  B L B M  per step: the same number of barriers, group 1 half
     // a step late.  Ring safety (NSTAGE = 3): pair j+2 goes to the stage of pair j-1, whose K part was last read in
     // group 1's L(j-1) and whose V^T part in group 1's M(j-1) - both behind a barrier that precedes the issuing
@@ -567,7 +452,6 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
         if (!grp) PRIMX_ATTN_WAITB();
     }
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): drain the clamped tail DMAs before the workgroup retires
-    }
 #undef PRIMX_ATTN_WAITB
 #undef PRIMX_ATTN_WAITB_N
     if (PROF && lane == 0) {
@@ -762,15 +646,6 @@ void launch_attn(const void* Qp, const void* Kp, const void* Vt, void* out, int 
             fprintf(stderr, "attn segment profile (cycles per step per wave, %llu wave-steps): light %.0f (DMA issue %.0f, LDS read "
                             "issue %.0f, max/rescale %.0f) | matrix %.0f | waits + barriers %.0f | total %.0f\n", r[3],
                     (r[0] + r[4] + r[5]) / n, r[4] / n, r[5] / n, r[0] / n, r[1] / n, r[2] / n, (r[0] + r[1] + r[2] + r[4] + r[5]) / n);
-            return;
-        }
-    }
-    if constexpr (KSTEPS == 5 && !KMASK) {
-        // PRIMX_ATTN_FUSED=0: the round 1 - 5 ping-pong schedule (A/B measurements)
-        static const bool fused = [] { const char* e = getenv("PRIMX_ATTN_FUSED"); return !e || atoi(e) != 0; }();
-        if (fused) {
-            hipLaunchKernelGGL((attn_kernel<DT, KSTEPS, DTILES, KMASK, 0, 1>), grid, dim3(64 * NW), 0, st, (const S*)Qp, (const S*)Kp,
-                               (const S*)Vt, (S*)out, H, nq, nq_pad, nkv, nkv_pad, dh, c, (const S*)Kb, (const S*)Vb, b_from, nkv_pad_b);
             return;
         }
     }
