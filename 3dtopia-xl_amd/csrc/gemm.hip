@@ -2324,241 +2324,10 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// PERSISTENT passes (round 5; OPT-IN, PRIMX_GEMM_PP_ROUNDS - measured, a tie, not the default): the pass of gemm288p_dma_kernel -
-// 256 rows x 144 columns over the whole K, 8 compute waves of 32 rows + 2 loader waves, 3-stage LDS-DMA ring - as a kernel that stays
-// on its CU and walks a LIST of passes: workgroup b of G (G = the CU count) takes the units b, b + G, b + 2 G, ... of the
-// mt x (N / 144) grid of passes.  Built for the launches where every CU has many tiles in a row (T >= 8192: fc1, fc2, proj, cproj of
-// a large batch), on the hypothesis that the 8-wave 256 x 288 kernel loses its time at the seams: 8 workgroups per CU back to
-// back, each paying its ring fill, its epilogue and - at s_endpgm - the drain of its stores (~93 - 105k cycles per tile for ~65k of
-// main loop).  Here the seam costs the compute waves their epilogue's ISSUE only: the loader waves never stop at a seam (one stream
-// of k-tiles g = 0 .. rounds x nk - 1 under the two-tiles-of-flight protocol of gemm288p), the stores drain under the next pass's
-// MFMAs (the compute waves do not wait on vmcnt in the loop; loads and stores share vmcnt on this part, so the waves that store
-// must not be the waves that count DMA arrivals), nothing is launched, filled or drained per tile.
-// WHAT THE DEVICE SAID (profiles/r5_pp_experiments.txt; same box, rotating buffers): correct (tests/test_hip_gemm.py: edges, ragged,
-// uneven rounds, bit-stable) and EQUAL to the kernel it was to beat - fc1 + GELU 32768 x 4608 x 1152: 451 - 460 us vs 453 - 455;
-// proj 144 vs 142 - 144; fc2 362 - 368 vs 374 - and the batch-8 step within 1 % either way.  Its own timeline (PRIMX_GEMM_PROF=1) shows
-// why the hypothesis was wrong: the seams ARE gone (entry 8k cycles once, final drain 2 - 4k once), but a k-tile takes 2200 - 2300
-// cycles at K = 1152 and 1650 - 1700 at K = 4608 where the same loop runs 1400 at T = 4096, and an epilogue still costs 20 - 22k cycles
-// per pass: at T = 32768 the loop is bound by operand delivery from beyond the L2 (80 % hits here against 88 % for the 256 x 288
-// tile, which needs 1.47 x fewer operand bytes per FLOP: fabric reads 321 vs 237 MB per launch) and the epilogue by its own loads'
-// round trips and by issuing 74 - 147 KB of stores into a write path that the OTHER 255 CUs keep full.  Non-temporal and write-through
-// stores (builds of both): 3 - 10 % slower on either kernel; other XCD walk shapes (gm 2 / 4 / 8 x sr 1 .. 16): within +-3 %, the
-// default below is among the best.  An L2 touch-ahead was built too - the compute waves, whose vector-memory queue is idle in the
-// loop, requesting one dword per 64-byte sector of the k-tile the loaders would ask for 2 - 16 steps later (4-byte LDS-DMA into a
-// strip nobody reads, each sector once per XCD by splitting a panel's rows between the tiles that share it): 2 - 5 % SLOWER at every
-// distance, the k-tile unchanged at ~2000 cycles - the loop is not waiting for first-touch misses either.  What moves with the
-// problem size is the shader clock (1.54 - 1.71 GHz under these launches, 1.9 - 2.0 under the T = 4096 ones): at T = 32768 the chip
-// is power-limited, and the lever is energy per FLOP - fewer LDS and L2 bytes per MFMA, i.e. a larger tile than 8 waves x 256
-// registers hold - not the seams and not the latency.  Kept opt-in with its tests: the structure (loader waves streaming across tiles, stores never waited for) is what a
-// larger-tile successor would start from.
-// Unit order: the virtual workgroup id v = b + round x G goes through the same XCD-aware 2-D walk as a one-pass-per-workgroup
-// launch would (xcd_tile2d; G % 8 == 0 keeps v's XCD = b's), so the 32 CUs of an XCD hold an sr x sc block of passes in every round
-// and share its sr activation and sc weight panels through their L2.
-// Epilogues, from registers (acc[i][j][r] = C[m0 + 32 w + 16 i + lr][n0 + 16 j + 4 lg + r]): EPI_LINEAR (bias, activation, 16-byte
-// stores by v_permlane16_swap - gemm288p's) and EPI_GATE_RESIDUAL (fp32 read-modify-write of the residual rows, 16 bytes per lane).
-template <int DT, int EPI>
-__global__ __launch_bounds__(640) void gemm144pp_dma_kernel(PRIMX_GEMM_PARAMS(DT)) {
-    PRIMX_GEMM_ARGS(DT);
-    static_assert(EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL, "persistent passes: dense-output epilogues only");
-    unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pca = 0, ploop = 0, pepi = 0;   // PRIMX_GEMM_PROF=1 timeline (see g_gemm_prof)
-    if (pl_prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
-    using S = typename T16<DT>::S;
-    using V8 = typename T16<DT>::V8;
-    using V4e = typename T16<DT>::V4;
-    typedef __attribute__((address_space(1))) const void GV;
-    typedef __attribute__((address_space(3))) void LV;
-    constexpr int BM = 256, BN = 144, MI = 2, NI = 9, NST = 3;
-    constexpr int ROWS = BM + BN, STAGE = ROWS * 64, NINST = ROWS / 8, NL = NINST / 2;   // 50 wave-instructions per k-tile, 25 per loader
-    static_assert(NST * STAGE * 2 <= 160 * 1024 && NINST % 2 == 0 && BM % 8 == 0, "LDS budget / loader split");
-    __shared__ __attribute__((aligned(16))) S smem[NST * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = pl_N / BN, mt = (pl_M + BM - 1) / BM;
-    const int units = mt * nt, G = (int)gridDim.x;
-    const int rounds = (units - (int)blockIdx.x + G - 1) / G;                            // >= 1 (host: G <= units)
-    const int nk = pl_K / BK, total = rounds * nk;
-    auto unit_tile = [&](int round, int& m0, int& n0) __attribute__((always_inline)) {
-        const int v = (int)blockIdx.x + round * G;
-        int mi_t, ni_t;
-        if (pl_xcd_gm > 0) {   // packed gm | sr << 8 | sc << 16 (xcd_pack_pp)
-            xcd_tile2d(v, mt, nt, pl_xcd_gm, mi_t, ni_t);
-        } else {
-            const int id = xcd_remap(v, units);
-            mi_t = id / nt;
-            ni_t = id - mi_t * nt;
-        }
-        m0 = mi_t * BM;
-        n0 = ni_t * BN;
-    };
-
-    if (wave >= 8) {
-        if (PRIMX_LOADER_PRIO) __builtin_amdgcn_s_setprio(PRIMX_LOADER_PRIO);
-        // ---------------- loader wave lw: instructions t = lw * 25 + i, rows 8 t .. 8 t + 7 of the 400-row stage image (rows < 256:
-        // activations, the rest: the pass's 144 weight rows).  One stream of k-tiles over all rounds; the row pointers are formed
-        // again at every seam (a handful of 64-bit adds per pass - kept across the loop they would be the wave's whole budget twice)
-        const int lw = wave - 8;
-        const S* gp[NL];
-        auto point = [&](int round) __attribute__((always_inline)) {
-            int m0, n0;
-            unit_tile(round, m0, n0);
-#pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                const int row = 8 * (lw * NL + i) + (lane >> 3);
-                const int c = (lane & 7) ^ ((row >> 1) & 7);
-                gp[i] = (row < BM) ? pl_A + (int64_t)min(m0 + row, pl_M - 1) * pl_K + c * 8 : pl_W + (int64_t)(n0 + row - BM) * pl_K + c * 8;
-            }
-        };
-        int ir = 0, ikt = 0;                                                             // the next k-tile to request: (round, kt)
-        point(0);
-        auto issue_next = [&](int stage) __attribute__((always_inline)) {
-            // (behind the last k-tile the stream repeats it: the waits below count NL instructions per step)
-#pragma unroll
-            for (int i = 0; i < NL; ++i)
-                __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + ikt * BK), (LV*)(smem + stage * STAGE + (lw * NL + i) * 512), 16, 0, 0);
-            if (ikt + 1 < nk) {
-                ++ikt;
-            } else if (ir + 1 < rounds) {
-                ++ir;
-                ikt = 0;
-                point(ir);
-            }
-        };
-        issue_next(0);
-        issue_next(1);
-        issue_next(2);
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NL) : "memory");      // P: k-tile 0 landed
-        int st = 0;
-        for (int g = 0; g < total; ++g) {
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");     // B_g: k-tile g + 1 landed, g + 2 may fly
-            issue_next(st);                                                              // k-tile g's stage is free now
-            st = (st == NST - 1) ? 0 : st + 1;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 // the repeated tail must not outlive the LDS
-        return;
-    }
-
-    // ---------------- compute wave w: rows 32 w .. 32 w + 31 of the pass, all 144 columns, the whole K
-    if (PRIMX_COMPUTE_PRIO) __builtin_amdgcn_s_setprio(PRIMX_COMPUTE_PRIO);
-    const int lr = lane & 15, lg = lane >> 4;
-    const int a_row = wave * 32 + lr;
-    auto read_frags = [&](int stage, int ks, V8 (&a)[MI], V8 (&b)[NI]) {
-        const S* As = smem + stage * STAGE;
-        const S* Ws = As + BM * 64;
-        const int chunk = ks * 4 + lg;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const V8*>(As + lds_off(a_row + i * 16, chunk));
-#pragma unroll
-        for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(Ws + lds_off(lr + j * 16, chunk));
-    };
-    f32x4 acc[MI][NI];
-    // operands swapped (A = weight rows, B = activation rows): the accumulator holds C^T, a lane owns ONE row and four
-    // consecutive columns, and the epilogue needs no LDS (the ring belongs to the loaders throughout)
-    auto multiply = [&](const V8 (&a)[MI], const V8 (&b)[NI]) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(b[j], a[i], acc[i][j]);
-    };
-    asm volatile("s_barrier" ::: "memory");                                              // P
-    if (pl_prof) pc1 = pca = __builtin_readcyclecounter();
-    int st = 0;
-#pragma unroll 1
-    for (int round = 0; round < rounds; ++round) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        V8 a0[MI], b0[NI], a1[MI], b1[NI];
-        read_frags(st, 0, a0, b0);                 // (the round's k-tile 0 has landed: P, or B of the previous round's last k-tile)
-#pragma unroll 1
-        for (int kt = 0; kt < nk; ++kt) {
-            const int st_next = (st == NST - 1) ? 0 : st + 1;
-            read_frags(st, 1, a1, b1);
-            multiply(a0, b0);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // B_g
-            // (unconditional: behind the round's last k-tile the stage holds the next round's first one - or the repeated last one -
-            // and the values are simply not used; a conditional read kept both fragment sets live through the loop)
-            read_frags(st_next, 0, a0, b0);
-            multiply(a1, b1);
-            st = st_next;
-        }
-        if (pl_prof) { const unsigned long long c = __builtin_readcyclecounter(); ploop += c - pca; pca = c; }
-        // ---- epilogue of the pass, from registers.  Nothing below waits for the stores: the next round's fragments and MFMAs
-        // follow immediately; the loads at its head (bias, gate, residual rows) are the only vector-memory waits of a compute wave
-        int m0, n0;
-        unit_tile(round, m0, n0);
-        V4e bpre[NI];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            bpre[j] = V4e{};
-            if (p.bias) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + n0 + j * 16 + 4 * lg);
-        }
-        if constexpr (EPI == EPI_LINEAR) {
-            typedef unsigned int u32;
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int m = m0 + wave * 32 + i * 16 + lr;
-                const bool ok = m < pl_M;
-                S* orow = p.out + (int64_t)(ok ? m : pl_M - 1) * pl_N + n0;
-#pragma unroll
-                for (int j = 0; j + 1 < NI; j += 2) {
-                    const u32x2 a = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j], bpre[j]));
-                    const u32x2 b = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j + 1], bpre[j + 1]));
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-                    const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
-                    if (ok) out_store(reinterpret_cast<u32x4*>(orow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
-                }
-                if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), linear_out4<DT>(p, acc[i][NI - 1], bpre[NI - 1]));
-            }
-        } else {
-            // x[m, :] += cast16(gate[b, :] * cast16(acc + bias)) (models/dit_crossattn.py:55-57): one row group at a time, in two
-            // column halves (5 + 4 pieces of 16 bytes per lane, all of a half requested before the first is used - the whole row at
-            // once, next to the 72 accumulators and the bias, left the 168 registers of a 10-wave workgroup)
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int m = m0 + wave * 32 + i * 16 + lr;
-                const bool ok = m < pl_M;
-                const int mc = ok ? m : pl_M - 1;
-                const S* grow = p.gate + (int64_t)(mc / p.rows_per_batch) * p.gate_stride + n0 + 4 * lg;
-                float* xrow = p.x + (int64_t)mc * pl_N + n0 + 4 * lg;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    constexpr int J0[2] = {0, 5}, JN[2] = {5, 4};
-                    V4e gv[5];
-                    f32x4 xv[5];
-#pragma unroll
-                    for (int jj = 0; jj < JN[h]; ++jj) {
-                        gv[jj] = *reinterpret_cast<const V4e*>(grow + (J0[h] + jj) * 16);
-                        xv[jj] = *reinterpret_cast<const f32x4*>(xrow + (J0[h] + jj) * 16);
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < JN[h]; ++jj) {
-                        const int j = J0[h] + jj;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            xv[jj][r] += rnd16<DT>((float)gv[jj][r] * rnd16<DT>(acc[i][j][r] + (p.bias ? (float)bpre[j][r] : 0.f)));
-                        if (ok) out_store(reinterpret_cast<f32x4*>(xrow + j * 16), xv[jj]);
-                    }
-                    asm volatile("" ::: "memory");     // (keeps the next half's loads behind this half's stores: the register budget)
-                }
-            }
-        }
-        if (pl_prof) { const unsigned long long c = __builtin_readcyclecounter(); pepi += c - pca; pca = c; }
-    }
-    if (pl_prof) {
-        __builtin_amdgcn_s_waitcnt(0);   // the stores have been acknowledged
-        const unsigned long long pc3 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0) {   // per workgroup: entry -> first k-tile | sum of the k-loops | sum of the epilogues' issue | the final drain
-            atomicMin(&g_gemm_prof[0], pr0); atomicMax(&g_gemm_prof[1], pr1);
-            atomicAdd(&g_gemm_prof[2], pc1 - pc0); atomicAdd(&g_gemm_prof[3], ploop);
-            atomicAdd(&g_gemm_prof[4], pepi); atomicAdd(&g_gemm_prof[5], 1ull); atomicAdd(&g_gemm_prof[6], pr0);
-            atomicAdd(&g_gemm_prof[7], pc3 - pca);
-            atomicAdd(&g_gemm_prof[8], pr1 - pr0); atomicAdd(&g_gemm_prof[9], pc3 - pc0); atomicAdd(&g_gemm_prof[10], (unsigned long long)rounds);
-        }
-    }
-}
+// (Round 5's persistent-pass kernel gemm144pp_dma_kernel - the two-pass tile's 256 x 144 pass as one workgroup per CU walking a list of
+// passes, opt-in, measured a tie at T = 32768 (profiles/r5_pp_experiments.txt) - left the library in round 6.  The round-6 probes say why it
+// could only tie: a 256 x 144 pass needs 44 bytes per clock and CU of operands at the MFMA rate, and the way into a CU takes 35 - 48 of
+// them as 128-byte requests whoever issues them (profiles/r6_largeM_diagnosis.txt); the seams it removed were never the bound.)
 
 // (Round 4 built a PERSISTENT form of the big tile here - four waves of 128 x 144 with the whole register file, one per SIMD, walking
 // many tiles as one operand stream, first fed by LDS-DMA, then through registers - to overlap ring fill and store drain at T >= 8192,
@@ -2662,92 +2431,6 @@ static int xcd_pack(int gm, int mtb, int ntb, bool row_major) {
     return gm | (sr << 8) | (sc << 16);
 }
 
-// ---- persistent passes (gemm144pp_dma_kernel): PRIMX_GEMM_PP_ROUNDS = fewest passes per CU for which the dense-output epilogues
-// take the persistent kernel.  Default 0 = never: MEASURED (round 5, profiles/r5_pp_experiments.txt) it ties the 8-wave 256 x 288
-// kernel at T = 32768 (fc1 451 - 460 vs 453 - 455 us, proj 144 vs 142 - 144, fc2 362 - 368 vs 374) - see the kernel's header for why.
-// Read at every launch (not once per process), so one process can A/B it (tests/test_hip_gemm.py sets it around its calls).
-// The grid is the CU count rounded down to a multiple of 8 (the XCD walk).
-static int pp_rounds() {
-    const char* e = getenv("PRIMX_GEMM_PP_ROUNDS");
-    return e ? atoi(e) : 0;
-}
-static int cu_count() {
-    static int cus[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (cus[dev] == 0) {
-        int n = 0;
-        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) ? (n / 8) * 8 : -1;
-    }
-    return cus[dev] > 0 ? cus[dev] : 0;
-}
-// XCD block shape for a grid of mtb x ntb passes of 256 rows x 144 columns (xcd_tile2d's packed form, 0 = linear walk): gm as in
-// launch144_dma (fewest operand bytes over the splits the grid allows), the sub-block sr x sc of the <= 32 passes an XCD's CUs hold
-// together chosen for the fewest panel rows per pass, (256 sr + 144 sc) / (sr sc), over the divisors sr of the block's rows.
-static int xcd_pack_pp(int M, int N, int mtb, int ntb) {
-    double best = 1e300;
-    int gm = 0;
-    for (int g = 1; g <= 8; g *= 2) {
-        if (mtb % g || ntb % (8 / g)) continue;
-        const double cost = (double)M * (8 / g) + (double)N * g;
-        if (cost < best) { best = cost; gm = g; }
-    }
-    static const int force_gm = [] { const char* e = getenv("PRIMX_GEMM_PP_GM"); return e ? atoi(e) : 0; }();     // (A/B measurements)
-    static const int force_sr = [] { const char* e = getenv("PRIMX_GEMM_PP_SR"); return e ? atoi(e) : 0; }();
-    if (force_gm > 0 && 8 % force_gm == 0 && mtb % force_gm == 0 && ntb % (8 / force_gm) == 0) gm = force_gm;
-    if (!gm) return 0;
-    const int bm = mtb / gm, bn = ntb / (8 / gm);
-    if (force_sr > 0 && bm % force_sr == 0) return gm | (force_sr << 8) | (std::max(1, std::min(bn, 32 / force_sr)) << 16);
-    int sr = 1, sc = std::min(bn, 32);
-    double bc = 1e300;
-    for (int r = 1; r <= 32 && r <= bm; ++r) {
-        if (bm % r) continue;
-        const int c = std::max(1, std::min(bn, 32 / r));
-        const double cost = (256.0 * r + 144.0 * c) / ((double)r * c);
-        if (cost < bc) { bc = cost; sr = r; sc = c; }
-    }
-    return gm | (sr << 8) | (sc << 16);
-}
-template <int DT, int EPI>
-bool launch_pp(const GemmArgs<DT>& a, hipStream_t st) {
-    if constexpr (EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL) {
-        const int mtb = (a.M + 255) / 256, ntb = a.N / 144;
-        const int min_rounds = pp_rounds();
-        if (min_rounds <= 0 || !g_loader || a.N % 144 || a.K % BK)
-            return false;
-        const int G = cu_count();
-        if (G <= 0 || (int64_t)mtb * ntb < (int64_t)min_rounds * G) return false;
-        GemmArgs<DT> a2 = a;
-        a2.xcd_gm = g_xcd2d ? xcd_pack_pp(a.M, a.N, mtb, ntb) : 0;
-        PRIMX_NOTE_KERNEL("gemm144pp_dma_kernel<%d, %d>", DT, EPI);
-        if (!g_gemm_prof_on) {
-            hipLaunchKernelGGL((gemm144pp_dma_kernel<DT, EPI>), dim3(G), dim3(640), 0, st, PRIMX_GEMM_PASS(a2));
-            return true;
-        }
-        // PRIMX_GEMM_PROF=1: synchronous launch + the workgroups' timeline sums
-        a2.prof = 1;
-        unsigned long long z[12] = {~0ull, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, r[12];
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof(z));
-        hipEvent_t e0, e1;
-        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-        (void)hipEventRecord(e0, st);
-        hipLaunchKernelGGL((gemm144pp_dma_kernel<DT, EPI>), dim3(G), dim3(640), 0, st, PRIMX_GEMM_PASS(a2));
-        (void)hipEventRecord(e1, st);
-        (void)hipEventSynchronize(e1);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        (void)hipMemcpyFromSymbol(r, HIP_SYMBOL(g_gemm_prof), sizeof(r));
-        const double n = r[5] ? (double)r[5] : 1.0, passes = r[10] ? (double)r[10] : 1.0;
-        fprintf(stderr, "gemm144pp_dma<%d,%d> M=%d N=%d K=%d: %llu workgroups x %.1f passes, events %.1f us, first start -> last end %.1f us, "
-                        "shader clock %.2f GHz; per workgroup (core cycles): entry->k-tile 0 %.0f | k-loops %.0f (%.0f per pass, %.0f per k-tile) | "
-                        "epilogue issue %.0f (%.0f per pass) | final drain %.0f\n",
-                DT, EPI, a.M, a.N, a.K, r[5], passes / n, ms * 1e3, (r[1] - r[0]) * 0.01, r[8] ? (double)r[9] / (double)r[8] * 0.1 : 0.0,
-                r[2] / n, r[3] / n, r[3] / passes, r[3] / passes / (a.K / BK), r[4] / n, r[4] / passes, r[7] / n);
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        return true;
-    }
-    return false;
-}
 
 static const bool g_kt32 = [] {   // PRIMX_GEMM_KT32=1: the 256x288 kernel on its round 1 - 5 ring of 32-wide slices (64-byte requests) for every K
     const char* e = getenv("PRIMX_GEMM_KT32");
@@ -2938,10 +2621,6 @@ int launch(const GemmArgs<DT>& a_in, hipStream_t st, const char* name) {
             PRIMX_NOTE_KERNEL("gemm_kernel<%d, %d, 32, 4, 1, 1, 1, %d>", DT, EPI, GATHER);
             hipLaunchKernelGGL((gemm_kernel<DT, EPI, 32, 4, 1, 1, 1, GATHER>), dim3(mt * ((a.N + 31) / 32)), dim3(256), 0, st, a);
         }
-    } else if (!tail && !GATHER &&
-               !(EPI == EPI_LINEAR && use_big && g_two_pass && ((a.M + 255) / 256) * (a.N / 288) <= 256) &&   // (one round of two-pass tiles: gemm288p)
-               launch_pp<DT, EPI>(a, st)) {
-        // (many passes per CU: the persistent 256 x 144 passes - see gemm144pp_dma_kernel)
     } else if (use_big && !tail && !GATHER) {
         launch144_dma<DT, EPI, 1>(a, mt, st);
     } else if (a.N % 144 == 0 && !GATHER && !tail) {

@@ -51,7 +51,8 @@ C_DDIM_X0, C_DDIM_EPS, C_DDIM_SIGMA, C_NONZERO, C_FIXED_VAR = 9, 10, 11, 12, 13
 PLAN_TIMESTEPS = __import__("os").environ.get("PRIMX_PLAN_TIMESTEPS", "1") != "0"
 # Longest loop that is planned.  Device memory per planned step for DiT-XL: 0.6 MB of 16-bit modulation rows (n x (depth * 9 + 2) * D)
 # + 2.1 MB of fp32 u / v rows when the LayerNorm fold applies (2 x 9216 columns x depth; DiT._fold_tables) + their 16-bit A operands
-# (0.4 MB): ~0.8 GB at 256 steps, freed when the loop ends (clear_timestep_plan drops the plan).
+# (0.4 MB): ~0.8 GB at 256 steps, freed when the loop ends (clear_timestep_plan drops the plan).  The fold's share is capped separately:
+# loops longer than DiT.fold_max_steps (128: BASELINE configs[3]'s 100 steps fold, 0.33 GB) are planned WITHOUT the fold.
 PLAN_MAX_STEPS = 256
 _MEAN_CODE = {ModelMeanType.EPSILON: 0, ModelMeanType.START_X: 1, ModelMeanType.VELOCITY: 2}
 _VAR_CODE = {
@@ -234,13 +235,21 @@ class GaussianDiffusion(DiffusionTables):
         normalised with the previous site's statistics, so it leaves the fp16 range only if ONE gated branch multiplies a row's
         spread by > 1e3 - no model of the suite comes near.  If it ever happens the loop is run again with the LayerNorm launches
         (whose operand cannot overflow, as in the reference) and THAT result is returned: same contract as the reference, which
-        returns whatever its fp16 arithmetic gives."""
+        returns whatever its fp16 arithmetic gives.
+
+        What a caller sees on that (never observed) path: `*_sample_loop` return the second loop's sample.  A consumer of the
+        `*_progressive` generators has already been handed the FIRST loop's intermediate items - a generator cannot take them back - and
+        gets the second loop's final item last: the trajectory it saw is not one loop's (a RuntimeWarning says so).  The second loop
+        draws its own noise where the sampler is stochastic (ancestral steps, DDIM with eta > 0): it is a new sample of the same
+        distribution, not a replay.  A NaN that does not come from the fold (bad weights or conditioning) survives the second loop and
+        is returned as it is, after the same warning."""
         over = getattr(planner, "fold_overflowed", None) if planner is not None else None
         if not callable(over) or not over(out["sample"]):
             return out
         import warnings
         warnings.warn("non-finite sample after a sampling loop with the fp16 LayerNorm fold: running the loop again with "
-                      "LayerNorm launches (PRIMX_DIT_FOLD=0 / model.fold_ln = False avoids the first attempt)", RuntimeWarning)
+                      "LayerNorm launches (PRIMX_DIT_FOLD=0 / model.fold_ln = False avoids the first attempt); items already "
+                      "yielded by a *_progressive generator belong to the first loop", RuntimeWarning)
         keep, planner.fold_ln = planner.fold_ln, False
         try:
             img = img0

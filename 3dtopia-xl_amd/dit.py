@@ -188,6 +188,9 @@ class DiT(nn.Module):
         # call - unplanned forwards included - takes the LayerNorm launches.
         self.fold_ln = os.environ.get("PRIMX_DIT_FOLD", "1") != "0"
         self._fold_ws: Dict = {}              # (device, rows) -> (center, part) workspaces of the fold
+        # the fold's u / v tables are built for a whole planned loop at once (2.5 MB per step for DiT-XL, 3 x depth small GEMMs):
+        # loops of more steps than this keep their LayerNorm launches (PRIMX_DIT_FOLD_MAX_STEPS)
+        self.fold_max_steps = int(os.environ.get("PRIMX_DIT_FOLD_MAX_STEPS", "128"))
         # `blocks_call` (round 6; PRIMX_DIT_BLOCKS_CALL=0 turns it off): a folded forward hands its block loop to the library in ONE
         # foreign call (primx_dit_blocks_fold, ABI 24: the same entry points with the same arguments, issued from C) instead of 8
         # Python + ctypes calls per block.  Bit-identical; what changes is the host's time per step (tools/host_bound_check.py).
@@ -744,7 +747,7 @@ class DiT(nn.Module):
         fold_uv = fcent = fpart = None
         prow = plan["row"] if plan is not None else None
         if (prow is not None and fuse and not collapse and not (self.cfg_streams and null_half and ops.PROFILE is None)
-                and self._fold_ok(T, N)):
+                and plan["t"].numel() <= self.fold_max_steps and self._fold_ok(T, N)):
             fold_uv = self._fold_tables(plan, dt, pk)["uv"]
             if dt == torch.float16:
                 self._fold_fp16_used = True

@@ -8,9 +8,11 @@ unit of sharding is the user sample and the DDIM loop itself needs NO collective
              large broadcast is link-efficient on point-to-point xGMI, 515 small ones are latency-bound)
              scatter(noise), scatter(conditioning)   (rank 0 draws the whole batch's INITIAL noise from one seeded CPU
              generator, so a seed gives the same starting latents for any world size - the role of the seeded
-             `torch.randn` of inference.py:251,316.  `reference_rng=True` replays the reference CLI's own draws instead
-             (global `manual_seed`, the unused `randn(1, N, 1, 4, 4, 4)`, then the noise: `initial_noise`) - seed 42 then
-             gives the CLI's seed-42 latents)
+             `torch.randn` of inference.py:251,316.  `reference_rng=True` replays the reference CLI's DRAW ORDER instead
+             (global `manual_seed`, the unused `randn(1, N, 1, 4, 4, 4)`, then the noise: `initial_noise`).  That equals the
+             CLI's seed-42 latents only when nothing else consumes the global CPU generator between the seeding and the
+             first image: inference.py builds model, VAE and conditioner in between (:254-256), whose constructors draw
+             from it - a caller that wants the CLI's bits has to construct in the same order)
     loop   : per-rank ``ddim_sample_loop`` on its slice            (zero collectives)
     end    : gather(samples) to rank 0
 

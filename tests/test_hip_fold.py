@@ -515,3 +515,51 @@ def test_blocks_call_rejects_bad_descriptors(ops):
     f.step, f.dtype = 0, 0
     assert lib.primx_dit_blocks_fold(C.byref(f), blk, None) == -1 and b"dtype" in lib.primx_last_error()
     assert lib.primx_dit_blocks_fold(None, blk, None) == -1
+
+
+def test_fold_guard_rerun_on_a_real_dit(ops):
+    """The repeat-unfolded path of `diffusion/sampler.py::_fold_guard` with a real DiT: `fold_overflowed` is forced to answer True once,
+    the loop is run again with LayerNorm launches and THAT sample is returned (bit-identical to a `fold_ln = False` loop), `fold_ln` is
+    restored, the plan is cleared, a warning is raised; a progressive consumer sees the first loop's intermediates and the second loop's
+    final item (documented in the guard's docstring)."""
+    import topia_xl_amd as pkg
+    sd, m = _fold_model(pkg, 2, 85)
+    x, y = synth.tensor(85, "x", (1, 2048, 68)), synth.tensor(85, "y", (1, 1370, 768))
+    d = pkg.create_diffusion("ddim3", noise_schedule="squaredcos_cap_v2", parameterization="v")
+    kw = dict(y=y.to(DEV), cfg_scale=6.0, precision_dtype=torch.float16, enable_amp=True)
+    run = lambda: list(d.ddim_sample_loop_progressive(m.forward_with_cfg, tuple(x.shape), noise=x.to(DEV), clip_denoised=False, model_kwargs=kw))
+    m.fold_ln = False
+    unfolded = run()
+    m.fold_ln = True
+    folded = run()
+    answers = [True]
+    real = m.fold_overflowed
+    m.fold_overflowed = lambda sample: answers.pop() if answers else real(sample)
+    try:
+        with pytest.warns(RuntimeWarning, match="LayerNorm fold"):
+            got = run()
+    finally:
+        del m.fold_overflowed
+    assert m.fold_ln is True and m._t_plan is None
+    assert torch.equal(got[-1]["sample"], unfolded[-1]["sample"])            # the final item is the second loop's ...
+    if m._fold_ok(4096, 2048) and os.environ.get("PRIMX_PLAN_TIMESTEPS", "1") != "0":
+        assert torch.equal(got[0]["sample"], folded[0]["sample"])            # ... the earlier ones were yielded by the first
+
+
+def test_fold_is_capped_by_the_loop_length(ops, monkeypatch):
+    """Loops longer than `DiT.fold_max_steps` are planned without the fold (its u / v tables are built for the whole loop at once)."""
+    import topia_xl_amd as pkg
+    sd, m = _fold_model(pkg, 1, 86)
+    x, y = synth.tensor(86, "x", (1, 2048, 68)), synth.tensor(86, "y", (1, 1370, 768))
+    t = torch.full((3,), 500, dtype=torch.int64, device=DEV)
+    built = []
+    real = m._fold_tables
+    monkeypatch.setattr(m, "_fold_tables", lambda *a, **k: (built.append(1), real(*a, **k))[1])
+    for cap, want in ((2, 0), (3, 1)):
+        m.fold_max_steps = cap
+        m.plan_timesteps(t)
+        m.select_planned_timestep(1)
+        m.forward_with_cfg(x.to(DEV), t[:1], y.to(DEV), 6.0, torch.float16, True)
+        m.clear_timestep_plan()
+        if m._fold_ok(4096, 2048):
+            assert len(built) == want, (cap, built)

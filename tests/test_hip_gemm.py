@@ -26,7 +26,7 @@ def _default_dispatch() -> bool:
     import os
     return not any(os.environ.get(v) for v in ("PRIMX_GEMM_LOADER", "PRIMX_GEMM_NOBIG", "PRIMX_GEMM_P2", "PRIMX_GEMM_BIG_MIN",
                                                "PRIMX_GEMM_BIGHEADS_MIN", "PRIMX_GEMM_NOGEMV", "PRIMX_GEMM_PROF", "PRIMX_LIB",
-                                               "PRIMX_LN_FUSE", "PRIMX_LN_FUSE_MAXGRID", "PRIMX_GEMM_PP_ROUNDS", "PRIMX_GEMM_KT32", "PRIMX_GEMM_KT64_MIN"))
+                                               "PRIMX_LN_FUSE", "PRIMX_LN_FUSE_MAXGRID", "PRIMX_GEMM_KT32", "PRIMX_GEMM_KT64_MIN"))
 
 
 def _mk(seed, M, N, K, dtype):
@@ -450,60 +450,6 @@ def test_gate_residual_layernorm_two_launch_route(ops):
         ops.linear_gate_residual(A.to(DEV), W.to(DEV), b.to(DEV), gd, xb, rpb, ln=(sh, sc, lnb, 1e-6, sync))
         assert not _lib.load().primx_last_gemm_kernel().decode().endswith(", 5>")
         assert torch.equal(xa, xb) and torch.equal(lna, lnb)
-
-
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(16384 + 77, 1152, 64), (16384 + 77, 1152, 128), (16384, 1152, 192), (4096 + 300, 4608, 320),
-                                   (171 * 256 - 9, 432, 64)])
-def test_persistent_pass_kernel_edges(ops, dtype, M, N, K, monkeypatch):
-    """gemm144pp_dma_kernel (round 5; opt-in: PRIMX_GEMM_PP_ROUNDS, read by the library at every launch): a workgroup per CU walks a
-    list of 256 x 144 passes as ONE stream of k-tiles.  The seams are
-    what can go wrong: K of one, two and three k-tiles (the ring is three deep: the loaders are up to three passes ahead), a
-    ragged last row tile, pass counts that are not a multiple of the grid (workgroups with different numbers of rounds), a pass
-    grid no XCD block shape divides (171 x 3: the linear walk) - Linear (+ GELU, canary row behind the end) and gate-residual
-    against float64 on the device, and bit-identical results from a second run (no ordering race shows as a flicker)."""
-    from topia_xl_amd import _lib
-    monkeypatch.setenv("PRIMX_GEMM_PP_ROUNDS", "2")
-    r16 = lambda t: t.to(dtype).double()
-    g = torch.Generator(device=DEV).manual_seed(M + N + K)
-    A = torch.randn(M, K, device=DEV, generator=g).to(dtype)
-    W = (torch.randn(N, K, device=DEV, generator=g) * K ** -0.5).to(dtype)
-    b = (torch.randn(N, device=DEV, generator=g) * 0.3).to(dtype)
-    ref = A.double() @ W.double().t() + b.double()
-    out = torch.full((M + 1, N), 7.0, dtype=dtype, device=DEV)
-    ops.linear(A, W, b, out=out[:M], act=1)
-    two_pass = N % 288 == 0 and 224 <= ((M + 255) // 256) * (N // 288) <= 256      # one round of two-pass tiles stays on gemm288p
-    if _default_dispatch() and not two_pass:
-        assert _lib.load().primx_last_gemm_kernel().decode() == f"gemm144pp_dma_kernel<{1 if dtype == torch.float16 else 2}, 0>"
-    want = r16(F.gelu(r16(ref).float(), approximate="tanh"))
-    assert rel_l2(out[:M], want) < 2 * TOL[dtype], rel_l2(out[:M], want)
-    assert float(out[M].float().min()) == 7.0 and float(out[M].float().max()) == 7.0
-    worst = (out[:M].double() - want).abs().amax(1)                 # a wrong k-tile would be a whole wrong row piece, not an rms shift
-    assert float(worst.max()) < 0.05 * max(1.0, float(want.abs().max())), float(worst.max())
-    again = torch.empty(M, N, dtype=dtype, device=DEV)
-    ops.linear(A, W, b, out=again, act=1)
-    assert torch.equal(again, out[:M])
-    rpb = (M + 2) // 3
-    gate = (torch.randn(3, N, device=DEV, generator=g) * 0.5).to(dtype)
-    x0 = torch.randn(M + 1, N, device=DEV, generator=g)
-    x = x0.clone()
-    ops.linear_gate_residual(A, W, b, gate, x[:M], rpb)
-    if _default_dispatch():
-        assert _lib.load().primx_last_gemm_kernel().decode() == f"gemm144pp_dma_kernel<{1 if dtype == torch.float16 else 2}, 1>"
-    bidx = torch.arange(M, device=DEV) // rpb
-    xr = x0[:M].double() + r16(gate.double()[bidx] * r16(ref))
-    assert rel_l2(x[:M] - x0[:M], xr - x0[:M].double()) < 2 * TOL[dtype]
-    assert float((x[:M].double() - xr).abs().max()) < 0.05 and torch.equal(x[M], x0[M])
-    x2 = x0.clone()
-    ops.linear_gate_residual(A, W, b, gate, x2[:M], rpb)
-    assert torch.equal(x2, x)
-    # ... and the default dispatch (the switch off) gives the same numbers from the other kernels
-    monkeypatch.delenv("PRIMX_GEMM_PP_ROUNDS")
-    x3 = x0.clone()
-    ops.linear_gate_residual(A, W, b, gate, x3[:M], rpb)
-    assert not _lib.load().primx_last_gemm_kernel().decode().startswith("gemm144pp")
-    # (another kernel sums K in another order - the 128 x 144 tile in two halves: a few 16-bit roundings of the branch flip by one ulp)
-    assert rel_l2(x3[:M] - x0[:M], x[:M] - x0[:M]) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

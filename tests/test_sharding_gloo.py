@@ -145,11 +145,13 @@ def test_two_rank_sharded_sampling(batch):
     assert ret.get(timeout=5) == "ok"
 
 
-def test_reference_rng_gives_the_cli_latents():
-    """`initial_noise(reference_rng=True)` = the reference CLI's draws in its order (inference.py:251: torch.manual_seed(seed);
-    :313 latent = torch.randn(1, num_prims, 1, 4, 4, 4); :316 inf_x = torch.randn(inf_bs, num_prims, 68)): seed 42 gives the
-    CLI's seed-42 latents at the shipped shape; a second call continues the stream like the CLI's per-image loop; a larger
-    batch keeps entry 0; the default (private generator) leaves the global stream alone and gives other numbers."""
+def test_reference_rng_replays_the_cli_draw_order():
+    """`initial_noise(reference_rng=True)` = the reference CLI's draws in its ORDER (inference.py:251: torch.manual_seed(seed);
+    :313 latent = torch.randn(1, num_prims, 1, 4, 4, 4); :316 inf_x = torch.randn(inf_bs, num_prims, 68)): given the same state of
+    the global CPU generator it produces the same latents (the CLI's own bits additionally depend on what its model / VAE /
+    conditioner constructors draw between the seeding and the first image, inference.py:254-256 - not replayed here); a second
+    call continues the stream like the CLI's per-image loop; a larger batch keeps entry 0; the default (private generator) leaves
+    the global stream alone and gives other numbers."""
     sys.path.insert(0, ROOT)
     from topia_xl_amd.sharding import initial_noise
     N = 2048

@@ -148,7 +148,8 @@ def hip_side(sd, cfg, heads, x, y, t, n_steps, dtype, blocks):
     for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
         rec = {}
         for fold in (True, False):
-            keep, m.fold_ln = m.fold_ln, fold
+            # (a model whose fold is switched off - PRIMX_DIT_FOLD=0 / m.fold_ln = False - stays unfolded in both legs: `fold_active` says so)
+            keep, m.fold_ln = m.fold_ln, fold and bool(m.fold_ln)
             m.plan_timesteps(td)
             m.select_planned_timestep(0)
             m.block_probe = []
