@@ -2324,275 +2324,6 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Round 6: 256 x 192 tiles, one workgroup per CU walking its tiles, the EPILOGUE OF TILE i INSIDE THE K-LOOP OF TILE i + 1.
-// Why: at T = 32768 a 256 x 288 tile spends 55k cycles in its k-loop and 18 - 35k in an epilogue during which the CU's matrix pipe idles
-// (plus ~6.5k between a workgroup's start and its first landed tile): profiles/r6_kt64_experiments.txt.  Hiding the epilogue needs the
-// finished tile's values to live through the next tile's loop - 72 registers of packed 16-bit values next to 144 accumulators do not
-// fit 256 - so the tile is 256 x 192: 96 accumulators + 48 packed registers + the loop's fragments.  What is deferred is exact: the
-// Linear's output is a 16-bit number in the reference (autocast), so after a tile's loop the accumulators are rounded to
-// rnd16(acc + bias) (48 registers: P), and the rest - GELU + store, or the gate multiply and the fp32 read-modify-write of the residual
-// rows - is cut into twelve units of two 4-column quads that the next tile's loop executes one per 64-wide k-tile, between its two
-// halves (a uniform `switch` on the k-tile index: register indices stay static; the SIMD's other wave multiplies meanwhile).  The
-// loop's one barrier per k-tile waits vmcnt(0), so a unit's loads (gate-residual: the x quads of unit u + 1 are requested in k-tile u)
-// have landed one k-tile later by construction, and its stores have a whole k-tile to be acknowledged.  The last tile of a workgroup
-// runs its epilogue behind the loop.  Loop and ring are gemm288q's KT = 64 form (two stages of 64-wide tiles, 128-byte row segments,
-// 7 requests per wave and tile, four behind the barrier and three between the first MFMA groups of the next k-tile).
-// Launch rules (launch192d): N % 192 == 0, K % 64 == 0, K >= 13 x 64 (twelve units + the read-ahead), M % 256 == 0 (and rows_per_batch
-// % 256 == 0 for the gate), both operands < 4 GB, at least two tiles per CU; EPI_LINEAR (out_scale 1) and EPI_GATE_RESIDUAL.
-template <int DT>
-struct D192Args {
-    using S = typename T16<DT>::S;
-    const S* A;
-    const S* W;
-    const S* bias;
-    S* out;
-    float* x;
-    const S* gate;
-    int64_t gate_stride;
-    int M, N, K, rows_per_batch, act, xcd_gm;
-};
-
-template <int DT, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm192d_dma_kernel(const D192Args<DT> p) {
-    using S = typename T16<DT>::S;
-    using V8 = typename T16<DT>::V8;
-    using V4e = typename T16<DT>::V4;
-    typedef __attribute__((address_space(1))) const void GV;
-    typedef __attribute__((address_space(3))) void LV;
-    typedef unsigned int u32;
-    static_assert(EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL, "epilogue");
-    constexpr int BM = 256, BN = 192, MI = 4, NI = 6, ROWS = BM + BN, STAGE = ROWS * 64, NSLOT = ROWS / 8 / 8;   // 7 requests per wave and tile
-    constexpr int NA_SLOTS = BM / 8 / 8, NUNIT = MI * NI / 2;                                       // 12 epilogue units per tile
-    __shared__ __attribute__((aligned(16))) S smem[2 * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 15, lg = lane >> 4;
-    const int nt = p.N / BN, mt = p.M / BM, ntile = nt * mt, nks = p.K / 64;
-    auto tile_of = [&](int id_, int& m0_, int& n0_) {
-        int mi_, ni_;
-        if (p.xcd_gm > 0) {
-            xcd_tile2d(id_, mt, nt, p.xcd_gm, mi_, ni_);
-        } else {
-            const int id = xcd_remap(id_, ntile);
-            mi_ = id / nt;
-            ni_ = id - mi_ * nt;
-        }
-        m0_ = mi_ * BM;
-        n0_ = ni_ * BN;
-    };
-    // requests: slot i (0 .. 6) of a wave = rows 8 (wave + 8 i) .. + 7 of the stage (slots 0 .. 3: A rows, 4 .. 6: W rows).  The source
-    // address is a UNIFORM base (operand + first row of the slot + k-tile) + ONE lane offset: row lane >> 3 of the eight, 16-byte chunk
-    // (lane & 7) ^ ((row >> 1) & 7) - and (row >> 1) & 7 = (4 wave + (lane >> 4)) & 7 whatever the slot.
-    const unsigned go_lane = (unsigned)((((lane >> 3) * p.K) + (((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7)) << 3)) * 2);
-    auto request = [&](int m0_, int n0_, int kt, int stage, int i) {
-        // (tile origin and k-tile index opaque: for the thirteen unrolled k-tiles hipcc otherwise keeps the operand base pointers of
-        // every (slot, k-tile) in scalar registers across the whole tile loop, runs out of them and spills - through vector registers -
-        // to scratch inside the k-loop)
-        kt = __builtin_amdgcn_readfirstlane(kt);
-        asm volatile("" : "+s"(kt));
-        const int r0 = (i < NA_SLOTS ? m0_ : n0_ - BM) + 8 * (wave + 8 * i);
-        const S* src = (i < NA_SLOTS ? p.A : p.W) + ((int64_t)r0 * p.K + kt * 64);                  // uniform
-        __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(reinterpret_cast<const char*>(src) + go_lane),
-                                         (LV*)(smem + stage * STAGE + (wave + 8 * i) * 512), 16, 0, 0);
-    };
-    const int a_off = (wm * 64 + lr) * 64 + ((lg ^ ((lr >> 1) & 7)) << 3);            // + i * 16 rows; second half of a k-tile: ^ 32
-    const int w_off = (BM + wn * 96 + lr) * 64 + ((lg ^ ((lr >> 1) & 7)) << 3);       // + j * 16 rows
-
-    // ---- the deferred epilogue: P = rnd16(acc + bias) of the previous tile at (pm0, pn0); unit u = quads (i, j), (i, j + 1), i = u / 3, j = 2 (u % 3)
-    V4e P[MI][NI];
-    int pm0 = 0, pn0 = 0;
-    const S* pgate = p.gate;                                   // the previous tile's gate row (uniform)
-    bool have_prev = false;
-    f32x4 xq[1][2];                                            // gate-residual: the two x quads of the unit in flight
-    V4e gq[1][2];
-    auto unit_rows = [&](int u, int& i, int& j) { i = u / 3; j = 2 * (u - 3 * i); };
-    // Addresses: a uniform 64-bit base (tile origin + the unit's quad, formed per call from OPAQUE copies of the tile origin: otherwise
-    // hipcc hoists the thirteen units' address pairs out of the k-loop - 50 registers, 1.1 KB of scratch) + one 32-bit lane offset.
-    const unsigned lane_el = (unsigned)((wm * 64 + lr) * p.N + wn * 96 + 4 * lg);           // elements; M x N < 2^31 (launcher)
-    auto opaque = [](int v) {
-        v = __builtin_amdgcn_readfirstlane(v);
-        asm volatile("" : "+s"(v));
-        return v;
-    };
-    auto unit_load = [&](int u, int buf) {                     // (gate-residual) request unit u's x quads and gate values
-        if constexpr (EPI == EPI_GATE_RESIDUAL) {
-            int i, j;
-            unit_rows(u, i, j);
-            const int pm = opaque(pm0), pn = opaque(pn0);
-            const float* xr = p.x + ((int64_t)(pm + i * 16) * p.N + pn + j * 16);           // uniform
-            const S* gr = pgate + (pn + j * 16);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                xq[buf][q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xr + 16 * q) + (size_t)lane_el * 4);
-                gq[buf][q] = *reinterpret_cast<const V4e*>(gr + 16 * q + wn * 96 + 4 * lg);
-            }
-        }
-    };
-    auto unit_finish = [&](int u, int buf) {                   // unit u: activation + 16-byte store, or gate + residual update + store
-        int i, j;
-        unit_rows(u, i, j);
-        const int pm = opaque(pm0), pn = opaque(pn0);
-        if constexpr (EPI == EPI_LINEAR) {
-            V4e o2[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float y = (float)P[i][j + q][r];
-                    if (p.act == PRIMX_ACT_GELU_TANH) y = gelu_tanh_f(y);
-                    o2[q][r] = (S)y;
-                }
-            // the lane groups of a row trade halves of the two quads (see gemm288q's EPI_LINEAR): 16 bytes per lane
-            const u32x2 a = __builtin_bit_cast(u32x2, o2[0]);
-            const u32x2 b = __builtin_bit_cast(u32x2, o2[1]);
-            const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-            const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-            const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
-            S* orow = p.out + ((int64_t)(pm + i * 16) * p.N + pn + j * 16);                  // uniform
-            // lane: row lr, columns of quad j + (lg & 1), halves 8 (lg >> 1) .. + 7
-            const unsigned le = (unsigned)((wm * 64 + lr) * p.N + wn * 96 + (lg & 1) * 16 + 8 * (lg >> 1));
-            out_store(reinterpret_cast<u32x4*>(reinterpret_cast<char*>(orow) + (size_t)le * 2), o);
-        } else {
-            float* xr = p.x + ((int64_t)(pm + i * 16) * p.N + pn + j * 16);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                f32x4 xv = xq[buf][q];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xv[r] += rnd16<DT>((float)gq[buf][q][r] * (float)P[i][j + q][r]);
-                out_store(reinterpret_cast<f32x4*>(reinterpret_cast<char*>(xr + 16 * q) + (size_t)lane_el * 4), xv);
-            }
-        }
-    };
-    // k-tile T of a loop (T = 0 .. 12, a compile-time constant: the first thirteen k-tiles of every tile but a workgroup's first are
-    // unrolled - a `switch` on the run-time k-tile index made hipcc spill 70 registers around it) carries: (gate-residual) the request
-    // of unit T, and the finish of unit T (Linear) / T - 1 (gate-residual)
-    auto deferred_step = [&](auto tc) {
-        constexpr int T_ = decltype(tc)::value;
-        if constexpr (EPI == EPI_LINEAR) {
-            if constexpr (T_ < NUNIT) unit_finish(T_, 0);
-        } else {
-            if constexpr (T_ >= 1) unit_finish(T_ - 1, 0);        // (finish first, then request into the SAME registers: one buffer)
-            if constexpr (T_ < NUNIT) unit_load(T_, 0);
-        }
-    };
-    int tile = blockIdx.x, m0, n0;
-    tile_of(tile, m0, n0);
-#pragma unroll
-    for (int i = 0; i < NSLOT; ++i) {
-        request(m0, n0, 0, 0, i);
-        request(m0, n0, 1, 1, i);
-    }
-    for (;;) {
-        f32x4 acc[MI][NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // Fragments: the A fragments of a half are prefetched whole (a_n, read while the previous half multiplies); the W fragments
-        // stream - at most four of the six alive at a time (b_j is requested two MFMA groups before its use and dies with its group;
-        // the next half's first two are requested in groups 4, 5) - 48 registers of fragments instead of 68: next to 96 accumulators
-        // and 48 packed values of the previous tile nothing may spill INSIDE this loop (a reload from scratch waits in the in-order
-        // vmcnt queue behind the requests just issued: 2 - 3k cycles per k-tile, measured).
-        V8 a_n[MI], b0_n, b1_n;
-        // k-tile 0 has landed when at most k-tile 1's 7 requests are out (the in-order loads; stores of the previous tile's last units
-        // only make the wait longer); barrier: for everybody
-        asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a_n[i] = *reinterpret_cast<const V8*>(smem + a_off + i * 16 * 64);
-        b0_n = *reinterpret_cast<const V8*>(smem + w_off);
-        b1_n = *reinterpret_cast<const V8*>(smem + w_off + 16 * 64);
-        auto ktile = [&](int t, auto tc) {                            // tc: integral_constant<int, unit k-tile> or -1 (no deferred work)
-            const S* base = smem + (t & 1) * STAGE;
-            const S* base_n = smem + ((t + 1) & 1) * STAGE;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                V8 a[MI], b[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) a[i] = a_n[i];
-                b[0] = b0_n;
-                b[1] = b1_n;
-                const S* nb = h == 0 ? base : base_n;
-                const int nx = h == 0 ? 32 : 0;
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    if (h == 1 && j == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everybody has read k-tile t; k-tile t + 1 has landed
-                    if (h == 1 && j >= 2 && t + 2 < nks) request(m0, n0, t + 2, t & 1, j - 2);              // slots 0 .. 3 of k-tile t + 2 into k-tile t's stage
-                    if (h == 0 && j < 3 && t >= 1 && t + 1 < nks) request(m0, n0, t + 1, (t + 1) & 1, 4 + j);   // slots 4 .. 6 of k-tile t + 1
-                    if (j + 2 < NI) b[j + 2] = *reinterpret_cast<const V8*>(base + ((w_off + (j + 2) * 16 * 64) ^ (h << 5)));
-                    else if (j + 2 == NI) b0_n = *reinterpret_cast<const V8*>(nb + (w_off ^ nx));
-                    else b1_n = *reinterpret_cast<const V8*>(nb + ((w_off + 16 * 64) ^ nx));
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) acc[i][j] = T16<DT>::mfma16(b[j], a[i], acc[i][j]);
-                    if (j == 2) {
-#pragma unroll
-                        for (int i = 0; i < MI; ++i) a_n[i] = *reinterpret_cast<const V8*>(nb + ((a_off + i * 16 * 64) ^ nx));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);          // (keeps the fragment requests where they are: hoisted, all six W fragments live again)
-                }
-                // the previous tile's epilogue, one unit per k-tile - BEHIND this k-tile's barrier, so that its requests and stores have a
-                // whole k-tile before the next barrier's vmcnt(0) asks for them
-                if constexpr (decltype(tc)::value >= 0) {
-                    if (h == 1) deferred_step(tc);
-                }
-            }
-        };
-        using NoUnit = std::integral_constant<int, -1>;
-        if (!have_prev) {
-            for (int t = 0; t < nks; ++t) ktile(t, NoUnit{});
-        } else {
-#define PRIMX_D192_K(T_) ktile(T_, std::integral_constant<int, T_>{});
-            PRIMX_D192_K(0) PRIMX_D192_K(1) PRIMX_D192_K(2) PRIMX_D192_K(3) PRIMX_D192_K(4) PRIMX_D192_K(5) PRIMX_D192_K(6)
-            PRIMX_D192_K(7) PRIMX_D192_K(8) PRIMX_D192_K(9) PRIMX_D192_K(10) PRIMX_D192_K(11) PRIMX_D192_K(12)
-#undef PRIMX_D192_K
-            for (int t = NUNIT + 1; t < nks; ++t) ktile(t, NoUnit{});
-        }
-        // ---- behind the loop: the next tile's first two k-tiles (both stages are free behind the last barrier), then this tile's P
-        const int next = tile + (int)gridDim.x;
-        int m1 = 0, n1 = 0;
-        if (next < ntile) {
-            tile_of(next, m1, n1);
-#pragma unroll
-            for (int i = 0; i < NSLOT; ++i) {
-                request(m1, n1, 0, 0, i);
-                request(m1, n1, 1, 1, i);
-            }
-        }
-        {
-            const S* bp = p.bias ? p.bias + n0 + wn * 96 + 4 * lg : nullptr;
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                V4e bv = V4e{};
-                if (bp) bv = *reinterpret_cast<const V4e*>(bp + j * 16);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) P[i][j][r] = (S)(acc[i][j][r] + (float)bv[r]);
-            }
-        }
-        pm0 = m0;
-        pn0 = n0;
-        if constexpr (EPI == EPI_GATE_RESIDUAL) pgate = p.gate + (int64_t)(m0 / p.rows_per_batch) * p.gate_stride;
-        have_prev = true;
-        if (next >= ntile) break;
-        tile = next;
-        m0 = m1;
-        n0 = n1;
-    }
-    // ---- the last tile's epilogue, behind everything
-    if constexpr (EPI == EPI_LINEAR) {
-#pragma unroll
-        for (int u = 0; u < NUNIT; ++u) unit_finish(u, 0);
-    } else {
-#pragma unroll
-        for (int u = 0; u < NUNIT; ++u) {
-            unit_load(u, 0);
-            unit_finish(u, 0);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // (Round 5's persistent-pass kernel gemm144pp_dma_kernel - the two-pass tile's 256 x 144 pass as one workgroup per CU walking a list of
 // passes, opt-in, measured a tie at T = 32768 (profiles/r5_pp_experiments.txt) - left the library in round 6.  The round-6 probes say why it
 // could only tie: a 256 x 144 pass needs 44 bytes per clock and CU of operands at the MFMA rate, and the way into a CU takes 35 - 48 of
@@ -2860,52 +2591,6 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 }
 
-// gemm192d_dma_kernel (deferred epilogue, one workgroup per CU): PRIMX_GEMM_D192 = fewest tiles per CU for which the dense-output
-// epilogues take it (0 = never)
-static int cu_count8() {
-    static int cus[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (cus[dev] == 0) {
-        int n = 0;
-        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) ? (n / 8) * 8 : -1;
-    }
-    return cus[dev] > 0 ? cus[dev] : 0;
-}
-static const int g_d192_min = [] {
-    const char* e = getenv("PRIMX_GEMM_D192");
-    return e ? atoi(e) : 0;
-}();
-template <int DT, int EPI>
-static bool launch192d(const GemmArgs<DT>& a, hipStream_t st) {
-    if constexpr (EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL) {
-        if (g_d192_min <= 0 || g_gemm_prof_on || a.N % 192 || a.K % 64 || a.K < 13 * 64 || a.M % 256) return false;
-        if ((int64_t)a.M * a.K >= (1ll << 31) || (int64_t)a.N * a.K >= (1ll << 31)) return false;
-        if (EPI == EPI_LINEAR && (a.out_scale != 1.0f || !a.out || a.act == PRIMX_ACT_GELU_ERF)) return false;
-        if (EPI == EPI_GATE_RESIDUAL && (a.rows_per_batch % 256 || a.ln_out || !a.x || !a.gate)) return false;
-        const int cus = cu_count8(), mtb = a.M / 256, ntb = a.N / 192;
-        if (cus <= 0 || (int64_t)mtb * ntb < (int64_t)g_d192_min * cus) return false;
-        D192Args<DT> d;
-        d.A = a.A; d.W = a.W; d.bias = a.bias; d.out = a.out; d.x = a.x; d.gate = a.gate; d.gate_stride = a.gate_stride;
-        d.M = a.M; d.N = a.N; d.K = a.K; d.rows_per_batch = a.rows_per_batch > 0 ? a.rows_per_batch : a.M; d.act = a.act;
-        d.xcd_gm = 0;
-        if (g_xcd2d) {
-            double best = 1e300;
-            int gm0 = 0;
-            for (int gm = 1; gm <= 8; gm *= 2) {
-                if (mtb % gm || ntb % (8 / gm)) continue;
-                const double cost = (double)a.M * (8 / gm) + (double)a.N * gm;
-                if (cost < best) { best = cost; gm0 = gm; }
-            }
-            if (gm0 > 0) d.xcd_gm = xcd_pack(gm0, mtb, ntb, false);
-        }
-        PRIMX_NOTE_KERNEL("gemm192d_dma_kernel<%d, %d>", DT, EPI);
-        hipLaunchKernelGGL((gemm192d_dma_kernel<DT, EPI>), dim3(std::min(cus, mtb * ntb)), dim3(512), 0, st, d);
-        return true;
-    }
-    return false;
-}
-
 template <int DT, int EPI, int GATHER = 0>
 int launch(const GemmArgs<DT>& a_in, hipStream_t st, const char* name) {
     GemmArgs<DT> a = a_in;
@@ -2936,8 +2621,6 @@ int launch(const GemmArgs<DT>& a_in, hipStream_t st, const char* name) {
             PRIMX_NOTE_KERNEL("gemm_kernel<%d, %d, 32, 4, 1, 1, 1, %d>", DT, EPI, GATHER);
             hipLaunchKernelGGL((gemm_kernel<DT, EPI, 32, 4, 1, 1, 1, GATHER>), dim3(mt * ((a.N + 31) / 32)), dim3(256), 0, st, a);
         }
-    } else if (!tail && !GATHER && launch192d<DT, EPI>(a, st)) {
-        // (many tiles per CU: 256 x 192 tiles with the epilogue inside the next tile's loop - gemm192d_dma_kernel)
     } else if (use_big && !tail && !GATHER) {
         launch144_dma<DT, EPI, 1>(a, mt, st);
     } else if (a.N % 144 == 0 && !GATHER && !tail) {
