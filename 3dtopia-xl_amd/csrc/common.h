@@ -97,6 +97,23 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// Four values at once in PACKED fp32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per issue slot): the
+// same operations in the same order as gelu_tanh_f, so the results are the same to the last bit; 2 + 4 x 0.5 issue slots per value
+// instead of 2 + 5.  The fc1 epilogue is bound by exactly this arithmetic (144 values per lane, two waves per SIMD: round 6,
+// profiles/r6_epilogue_valu.txt).
+__device__ __forceinline__ f32x4 gelu_tanh4(const f32x4 x) {
+    const float kC1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+    const float kC2 = kC1 * 0.044715f;
+    const f32x4 a = x * __builtin_elementwise_fma(f32x4{kC2, kC2, kC2, kC2}, x * x, f32x4{kC1, kC1, kC1, kC1});
+    f32x4 e;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(a[j]);
+    e = e + 1.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_rcpf(e[j]);
+    return x * e;
+}
+
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 
 // Dispatch a 16-bit dtype code to a template instantiation.

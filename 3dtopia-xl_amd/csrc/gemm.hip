@@ -392,10 +392,24 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs<DT>& p, const ColIn
 // round trip: 9 x ~775 cycles per tile, PRIMX_GEMM_PROF).
 // EPI_LINEAR arithmetic of four consecutive columns: bias, rounding, activation, scale - each rounded to the 16-bit
 // type like the separate autocast ops of the reference.
+// rnd16 -> GELU-tanh -> rnd16 of four values in packed fp32 arithmetic (gelu_tanh4): the Linear + GELU epilogue when no scale follows
 template <int DT>
+__device__ __forceinline__ typename T16<DT>::V4 gelu_out4(const f32x4 y) {
+    using V4 = typename T16<DT>::V4;
+    return __builtin_convertvector(gelu_tanh4(__builtin_convertvector(__builtin_convertvector(y, V4), f32x4)), V4);
+}
+
+// GELU = true: the caller has established (one uniform branch per tile, not per quad) that p.act == PRIMX_ACT_GELU_TANH and
+// p.out_scale == 1, and passes zeros in `bv` when there is no bias.
+template <bool B>
+struct BoolC {
+    static constexpr bool value = B;
+};
+template <int DT, bool GELU = false>
 __device__ __forceinline__ typename T16<DT>::V4 linear_out4(const GemmArgs<DT>& p, const f32x4 a,
                                                             const typename T16<DT>::V4 bv) {
     using S = typename T16<DT>::S;
+    if constexpr (GELU) return gelu_out4<DT>(a + __builtin_convertvector(bv, f32x4));
     typename T16<DT>::V4 o;
     float y[4];
 #pragma unroll
@@ -482,16 +496,16 @@ __device__ __forceinline__ void fold_stats_finish(const GemmArgs<DT>& p, const F
 
 // the consumer's value of four columns: st = (rho_p mu', rho / rho_p) -> (rho / rho_p) acc - rho mu' u + v
 __device__ __forceinline__ f32x4 fold_apply(const f32x4 a, const f32x2 st, const f32x4 u, const f32x4 v) {
-    f32x4 y;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) y[j] = st[1] * (a[j] - st[0] * u[j]) + v[j];
-    return y;
+    // (two fused multiply-adds per value, as the scalar expression st[1] * (a - st[0] * u) + v contracts; packed: v_pk_fma_f32)
+    const f32x4 s0 = {st[0], st[0], st[0], st[0]}, s1 = {st[1], st[1], st[1], st[1]};
+    return __builtin_elementwise_fma(s1, __builtin_elementwise_fma(-s0, u, a), v);
 }
 
 // linear_out4 behind the fold: `y` already holds what bias + accumulator are there
-template <int DT>
+template <int DT, bool GELU = false>
 __device__ __forceinline__ typename T16<DT>::V4 fold_out4(const GemmArgs<DT>& p, const f32x4 yin) {
     using S = typename T16<DT>::S;
+    if constexpr (GELU) return gelu_out4<DT>(yin);
     typename T16<DT>::V4 o;
     float y[4];
 #pragma unroll
@@ -1062,7 +1076,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(PRIMX_GEMM_PARAMS(D
                 V4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float y = rnd16<DT>(v0[j] + v1[j] + (p.bias ? (float)bv[j] : 0.f));
+                    float y = rnd16<DT>(v0[j] + v1[j] + (float)bv[j]);
                     if (h_seg == 0 && p.scale0 != 1.0f) y = rnd16<DT>(p.scale0 * y);
                     o[j] = (S)y;
                 }
@@ -1074,7 +1088,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_dma_kernel(PRIMX_GEMM_PARAMS(D
                 f32x4 xv = xpre[i];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    xv[j] = xv[j] + rnd16<DT>((float)gv[j] * rnd16<DT>(v0[j] + v1[j] + (p.bias ? (float)bv[j] : 0.f)));
+                    xv[j] = xv[j] + rnd16<DT>((float)gv[j] * rnd16<DT>(v0[j] + v1[j] + (float)bv[j]));
                 out_store(reinterpret_cast<f32x4*>(p.x + (int64_t)m * pl_N + n), xv);
             } else {
                 epilogue_row4<DT, EPI>(p, m0 + row, n0 + 4 * c4, v0 + v1, bpre[i]);
@@ -1355,7 +1369,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float y = rnd16<DT>(v0[j] + v1[j] + (p.bias ? (float)bv[j] : 0.f));
+                    float y = rnd16<DT>(v0[j] + v1[j] + (float)bv[j]);
                     if (h_seg == 0 && p.scale0 != 1.0f) y = rnd16<DT>(p.scale0 * y);
                     o[j] = (S)y;
                 }
@@ -1366,7 +1380,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
             f32x4 xv = xpre[i];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                xv[j] = xv[j] + rnd16<DT>((float)gv[j] * rnd16<DT>(v0[j] + v1[j] + (p.bias ? (float)bv[j] : 0.f)));
+                xv[j] = xv[j] + rnd16<DT>((float)gv[j] * rnd16<DT>(v0[j] + v1[j] + (float)bv[j]));
             out_store(reinterpret_cast<f32x4*>(p.x + (int64_t)(m0 + row) * pl_N + n0 + 4 * c4), xv);
             if constexpr (FOLD_P) {
                 // the next site's operand and this unit's share of the row statistics; the partial sums go back into the unit's
@@ -1892,6 +1906,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
     // burst of 256 workgroups finishing together (2.1 TB/s), not store issue.)
     // ---- epilogue from registers: acc[i][j][r] = C[m0 + wm*64 + i*16 + lr][n0 + wn*144 + j*16 + 4*lg + r]
     const int nb = n0 + wn * 144 + 4 * lg;
+    const bool gelu_fast = p.act == PRIMX_ACT_GELU_TANH && p.out_scale == 1.0f;   // (uniform: one branch per row group, see linear_out4)
     V4e bpre[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -2044,20 +2059,23 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
             const f32x2 fst = fstat[wm * 64 + i * 16 + lr];
             const float* up = fu + wn * 144 + 4 * lg;
             const float* vp = fu + BN + wn * 144 + 4 * lg;
-            auto out4 = [&](int j) -> V4e {
-                return fold_out4<DT>(p, fold_apply(acc[i][j], fst, *reinterpret_cast<const f32x4*>(up + j * 16),
-                                                   *reinterpret_cast<const f32x4*>(vp + j * 16)));
-            };
+            auto rows = [&](auto gelu) {
+                auto out4 = [&](int j) -> V4e {
+                    return fold_out4<DT, decltype(gelu)::value>(p, fold_apply(acc[i][j], fst, *reinterpret_cast<const f32x4*>(up + j * 16),
+                                                                              *reinterpret_cast<const f32x4*>(vp + j * 16)));
+                };
 #pragma unroll
-            for (int j = 0; j + 1 < NI; j += 2) {
-                const u32x2 a = __builtin_bit_cast(u32x2, out4(j));
-                const u32x2 b = __builtin_bit_cast(u32x2, out4(j + 1));
-                const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-                const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
-                if (ok) out_store(reinterpret_cast<u32x4*>(orow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
-            }
-            if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), out4(NI - 1));
+                for (int j = 0; j + 1 < NI; j += 2) {
+                    const u32x2 a = __builtin_bit_cast(u32x2, out4(j));
+                    const u32x2 b = __builtin_bit_cast(u32x2, out4(j + 1));
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                    const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
+                    if (ok) out_store(reinterpret_cast<u32x4*>(orow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
+                }
+                if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), out4(NI - 1));
+            };
+            if (gelu_fast) rows(BoolC<true>{}); else rows(BoolC<false>{});
         } else if (EPI == EPI_LINEAR) {
             // 16-bit outputs.  Stored straight from the accumulator layout a lane writes 8 bytes and an instruction touches 16 rows
             // x 32 bytes; the store path of a CU then needs ~21k cycles for the tile's 147 KB (tools/probe/write_burst.hip: "fc1
@@ -2067,18 +2085,22 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
             // half the instructions (probe "fc1 regs 16B": 12k cycles).  The ninth tile has no partner and keeps the 8-byte form.
             typedef unsigned int u32;
             S* orow = p.out + (int64_t)mc * pl_N + n0 + wn * 144;
+            auto rows = [&](auto gelu) {
+                constexpr bool G = decltype(gelu)::value;
 #pragma unroll
-            for (int j = 0; j + 1 < NI; j += 2) {
-                const u32x2 a = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j], bpre[j]));
-                const u32x2 b = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j + 1], bpre[j + 1]));
-                // odd 16-lane rows of the first operand <-> even rows of the second: (g1, g3)'s tile-j halves go to (g0, g2), their
-                // tile-(j+1) halves come back
-                const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-                const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
-                if (ok) out_store(reinterpret_cast<u32x4*>(orow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
-            }
-            if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), linear_out4<DT>(p, acc[i][NI - 1], bpre[NI - 1]));
+                for (int j = 0; j + 1 < NI; j += 2) {
+                    const u32x2 a = __builtin_bit_cast(u32x2, linear_out4<DT, G>(p, acc[i][j], bpre[j]));
+                    const u32x2 b = __builtin_bit_cast(u32x2, linear_out4<DT, G>(p, acc[i][j + 1], bpre[j + 1]));
+                    // odd 16-lane rows of the first operand <-> even rows of the second: (g1, g3)'s tile-j halves go to (g0, g2), their
+                    // tile-(j+1) halves come back
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                    const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
+                    if (ok) out_store(reinterpret_cast<u32x4*>(orow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
+                }
+                if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), linear_out4<DT, G>(p, acc[i][NI - 1], bpre[NI - 1]));
+            };
+            if (gelu_fast) rows(BoolC<true>{}); else rows(BoolC<false>{});
         } else {
 #pragma unroll
             for (int j = 0; j < NI; ++j)
@@ -2218,6 +2240,7 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     asm volatile("s_barrier" ::: "memory");                                              // P
     if (pl_prof) pc1 = __builtin_readcyclecounter();
     int st = 0;
+    const bool gelu_fast = p.act == PRIMX_ACT_GELU_TANH && p.out_scale == 1.0f;   // (uniform: one branch per row group, see linear_out4)
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
 #pragma unroll
@@ -2263,22 +2286,34 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
             for (int j = 0; j + 1 < NI; j += 2) {
                 const f32x4 u0 = *reinterpret_cast<const f32x4*>(up + j * 16), v0 = *reinterpret_cast<const f32x4*>(vp + j * 16);
                 const f32x4 u1 = *reinterpret_cast<const f32x4*>(up + j * 16 + 16), v1 = *reinterpret_cast<const f32x4*>(vp + j * 16 + 16);
+                auto rows = [&](auto gelu) {
+                    constexpr bool G = decltype(gelu)::value;
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const u32x2 a = __builtin_bit_cast(u32x2, fold_out4<DT>(p, fold_apply(acc[i][j], fst[i], u0, v0)));
-                    const u32x2 b = __builtin_bit_cast(u32x2, fold_out4<DT>(p, fold_apply(acc[i][j + 1], fst[i], u1, v1)));
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-                    const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
-                    if (ok[i]) out_store(reinterpret_cast<u32x4*>(orow[i] + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
-                }
+                    for (int i = 0; i < MI; ++i) {
+                        const u32x2 a = __builtin_bit_cast(u32x2, fold_out4<DT, G>(p, fold_apply(acc[i][j], fst[i], u0, v0)));
+                        const u32x2 b = __builtin_bit_cast(u32x2, fold_out4<DT, G>(p, fold_apply(acc[i][j + 1], fst[i], u1, v1)));
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                        const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
+                        if (ok[i]) out_store(reinterpret_cast<u32x4*>(orow[i] + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
+                    }
+                };
+                if (gelu_fast) rows(BoolC<true>{}); else rows(BoolC<false>{});
             }
             const f32x4 u8 = *reinterpret_cast<const f32x4*>(up + (NI - 1) * 16), v8 = *reinterpret_cast<const f32x4*>(vp + (NI - 1) * 16);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                if (ok[i])
-                    out_store(reinterpret_cast<V4e*>(orow[i] + (NI - 1) * 16 + 4 * lg),
-                              fold_out4<DT>(p, fold_apply(acc[i][NI - 1], fst[i], u8, v8)));
+                if (ok[i]) {
+                    const f32x4 y8 = fold_apply(acc[i][NI - 1], fst[i], u8, v8);
+                    V4e o8;
+                    if (gelu_fast) {
+                        asm volatile("" ::: "memory");
+                        o8 = fold_out4<DT, true>(p, y8);
+                    } else {
+                        o8 = fold_out4<DT>(p, y8);
+                    }
+                    out_store(reinterpret_cast<V4e*>(orow[i] + (NI - 1) * 16 + 4 * lg), o8);
+                }
         } else {
         V4e bpre[NI];
 #pragma unroll
@@ -2286,22 +2321,35 @@ __global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)
             bpre[j] = V4e{};
             if (p.bias) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + n0 + j * 16 + 4 * lg);
         }
+        // column pairs outermost, as in the fold branch: the pair's bias values are converted once for both row groups (with the row
+        // groups outermost the compiler keeps all 36 converted values alive across them: 92 bytes of scratch in the 168-register budget)
+        bool ok[MI];
+        S* orow[MI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = m0 + wave * 32 + i * 16 + lr;
-            const bool ok = m < pl_M;
-            S* orow = p.out + (int64_t)(ok ? m : pl_M - 1) * pl_N + n0;
+            ok[i] = m < pl_M;
+            orow[i] = p.out + (int64_t)(ok[i] ? m : pl_M - 1) * pl_N + n0;
+        }
+        auto cols = [&](auto gelu) {
+            constexpr bool G = decltype(gelu)::value;
 #pragma unroll
             for (int j = 0; j + 1 < NI; j += 2) {
-                const u32x2 a = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j], bpre[j]));
-                const u32x2 b = __builtin_bit_cast(u32x2, linear_out4<DT>(p, acc[i][j + 1], bpre[j + 1]));
-                const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-                const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
-                if (ok) out_store(reinterpret_cast<u32x4*>(orow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const u32x2 a = __builtin_bit_cast(u32x2, linear_out4<DT, G>(p, acc[i][j], bpre[j]));
+                    const u32x2 b = __builtin_bit_cast(u32x2, linear_out4<DT, G>(p, acc[i][j + 1], bpre[j + 1]));
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                    const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
+                    if (ok[i]) out_store(reinterpret_cast<u32x4*>(orow[i] + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
+                }
             }
-            if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), linear_out4<DT>(p, acc[i][NI - 1], bpre[NI - 1]));
-        }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                if (ok[i]) out_store(reinterpret_cast<V4e*>(orow[i] + (NI - 1) * 16 + 4 * lg), linear_out4<DT, G>(p, acc[i][NI - 1], bpre[NI - 1]));
+        };
+        if (gelu_fast) cols(BoolC<true>{}); else cols(BoolC<false>{});
         }
     }
     asm volatile("" ::"v"(pf_v[0]), "v"(pf_v[1]));
