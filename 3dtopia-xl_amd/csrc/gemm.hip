@@ -78,7 +78,7 @@ struct GemmArgs {
     int heads, dh, DP, n_pad, n_seg;
     int kind[3];
     int xcd_gm;  // 256x288 kernel: workgroups of one XCD form an (mt / xcd_gm) x (nt / (8 / xcd_gm)) block of tiles (0 / 8: whole tile rows)
-    int prof;  // PRIMX_GEMM_PROF=1: per-workgroup timeline stamps into g_gemm_prof (128x144 LDS-DMA kernel only)
+    int prof;  // PRIMX_GEMM_PROF=1: per-workgroup timeline stamps into g_gemm_prof
     S* dst[3];
     float scale0;
     int64_t rep_stride[3];  // the n_seg column groups repeat; repetition r writes at dst[s] + r * rep_stride[s]
@@ -1144,6 +1144,8 @@ __device__ unsigned g_ln_sync_timeouts = 0;
 template <int DT, int EPI>
 __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)) {
     PRIMX_GEMM_ARGS(DT);
+    unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pc2 = 0, pc_stg = 0, pc_iss = 0;   // PRIMX_GEMM_PROF=1 timeline of compute wave 0 (see g_gemm_prof)
+    if (pl_prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
     static_assert(EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_HEADS || EPI == EPI_GATE_RESIDUAL_LN ||
                   EPI == EPI_GATE_RESIDUAL_FOLD || EPI == EPI_HEADS_FOLD || EPI == EPI_LINEAR_FOLD || EPI == EPI_F32OUT,
                   "row-major epilogues only");
@@ -1271,6 +1273,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
         }
     }
     asm volatile("s_barrier" ::: "memory");                                              // P
+    if (pl_prof) pc1 = __builtin_readcyclecounter();
     V8 a0[MI], b0[NI], a1[MI], b1[NI];
     read_frags(0, a0, b0);
     int st_next = 1;
@@ -1288,6 +1291,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
     if (kt < nk) step(a0, b0, a1, b1);
     asm volatile("" ::"v"(pf_v[0]), "v"(pf_v[1]));                                                        // the prefetch requests have returned
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                     // D: the stages may be reused
+    if (pl_prof) pc2 = __builtin_readcyclecounter();
 
     // ---------------- epilogue: both K halves park their accumulators as fp32 [half][128][148]; row-major walk, 4 columns
     // per thread, 9 row-chunks each (the form of gemm144_dma_kernel).  The residual / gate / bias vectors are
@@ -1341,6 +1345,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                     // E
+    if (pl_prof) pc_stg = __builtin_readcyclecounter();
 #pragma unroll
     for (int i = 0; i < NROWCH; ++i) {
         const int cid = tid + 512 * i;
@@ -1415,6 +1420,7 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
                                                   *reinterpret_cast<const f32x4*>(fu + BN + 4 * c4))));
         }
     }
+    if (pl_prof) pc_iss = __builtin_readcyclecounter();
     if constexpr (FOLD_P) {
         // row sums of the tile: 36 units per row -> thread (row, quarter) adds nine, the four quarters meet by DPP - a fixed order
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                 // H
@@ -1497,6 +1503,23 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
             if (d == per - 1) {                                // everybody has passed the wait: the words go back to zero
                 __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (pl_prof) {
+        __builtin_amdgcn_s_waitcnt(0);   // the stores have been acknowledged
+        const unsigned long long pc3 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            atomicMin(&g_gemm_prof[0], pr0); atomicMax(&g_gemm_prof[1], pr1);
+            atomicAdd(&g_gemm_prof[2], pc1 - pc0); atomicAdd(&g_gemm_prof[3], pc2 - pc1);
+            atomicAdd(&g_gemm_prof[4], pc3 - pc2); atomicAdd(&g_gemm_prof[5], 1ull); atomicAdd(&g_gemm_prof[6], pr0);
+            atomicAdd(&g_gemm_prof[7], ((pc_stg - pc2) << 32) | (pc_iss - pc_stg));          // (parking + the barrier behind it | the walk's issue)
+            atomicAdd(&g_gemm_prof[8], pr1 - pr0); atomicAdd(&g_gemm_prof[9], pc3 - pc0);
+            if (blockIdx.x < 4096) {
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                g_gemm_wg[blockIdx.x][0] = pr0; g_gemm_wg[blockIdx.x][1] = pr1 - pr0; g_gemm_wg[blockIdx.x][2] = pc3 - pc0;
+                g_gemm_wg[blockIdx.x][3] = ((unsigned long long)(xcc & 15) << 32) | (unsigned)(pc3 - pc2);
             }
         }
     }
@@ -2565,7 +2588,7 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
             hipLaunchKernelGGL((gemm288p_dma_kernel<DT>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
         } else if (BIG) {
             launch288q<DT, EPI>(x, grid, st);
-        } else if (g_loader && loader_ok && !g_gemm_prof_on) {   // (no timeline stamps in the loader-wave kernel)
+        } else if (g_loader && loader_ok) {
             if constexpr (EPI == EPI_GATE_RESIDUAL) {
                 // LayerNorm of the updated rows in the kernel's tail: N = 1152 (nine 128-column chunks per half-wave row), 8-byte
                 // aligned modulation vectors, and every row block's column tiles on ONE XCD with consecutive ids (mt % 8 == 0:
@@ -2611,7 +2634,8 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     fprintf(stderr, "%s<%d,%d> M=%d N=%d K=%d: %llu workgroups, events %.1f us, first start -> last end %.1f us, mean start offset "
                     "%.1f us, shader clock %.2f GHz (core cycles / 100 MHz ticks per workgroup); per workgroup (core cycles): entry->tile0 %.0f | main loop "
                     "%.0f | epilogue %.0f (LDS staging %.0f, read+store issue %.0f)\n",
-            BIG ? (EPI == EPI_LINEAR && g_two_pass && (int)grid.x <= 256 ? "gemm288p_dma" : "gemm288q_dma") : "gemm144_dma", DT, EPI, a.M, a.N, a.K,
+            BIG ? ((EPI == EPI_LINEAR || EPI == EPI_LINEAR_FOLD) && g_two_pass && (int)grid.x <= 256 ? "gemm288p_dma" : "gemm288q_dma")
+                : (FOLD_EPI || (g_loader && loader_ok)) ? "gemm144l_dma" : "gemm144_dma", DT, EPI, a.M, a.N, a.K,
             r[5], ms * 1e3, (r[1] - r[0]) * 0.01, (r[6] / n - (double)r[0]) * 0.01, r[8] ? (double)r[9] / (double)r[8] * 0.1 : 0.0,
             r[2] / n, r[3] / n, r[4] / n, (r[7] >> 32) / n,
             (r[7] & 0xffffffffull) / n);
