@@ -53,7 +53,7 @@ constexpr int BK = 64;
 
 // (EPI_GATE_RESIDUAL_LN: gemm144l_dma_kernel only - the gate-residual epilogue followed by the LayerNorm + modulate of the row block)
 // The *_FOLD epilogues are the LayerNorm fold (see "LayerNorm fold" below): EPI_GATE_RESIDUAL_FOLD = the PRODUCER of a folded
-// LayerNorm site (gemm144l only), EPI_HEADS_FOLD / EPI_LINEAR_FOLD = its CONSUMERS (gemm144l, gemm288q heads, gemm288p),
+// LayerNorm site (gemm144l only), EPI_HEADS_FOLD / EPI_LINEAR_FOLD = its CONSUMERS (gemm144l, gemm288q),
 // EPI_F32OUT = fp32 rows out of 16-bit operands (the per-timestep u / v vectors of the fold; generic kernel only).
 enum { EPI_LINEAR = 0, EPI_GATE_RESIDUAL = 1, EPI_HEADS = 2, EPI_RES = 3, EPI_CONVT = 4, EPI_GATE_RESIDUAL_LN = 5,
        EPI_GATE_RESIDUAL_FOLD = 6, EPI_HEADS_FOLD = 7, EPI_LINEAR_FOLD = 8, EPI_F32OUT = 9 };
@@ -139,6 +139,25 @@ __device__ __forceinline__ pf_u32x2 gemm_prefetch_lines(const GemmArgs<DT>& p, i
         // two independent requests per lane cover 1024 lines per workgroup: 33.5 MB with 256 workgroups; longer ranges are cut
         if (l0 < p.pf_lines) v[0] = *reinterpret_cast<const unsigned*>(p.pf_ptr + l0 * 128);
         if (l0 + stride < p.pf_lines) v[1] = *reinterpret_cast<const unsigned*>(p.pf_ptr + (l0 + stride) * 128);
+    }
+    return v;
+}
+
+// The same range from a kernel WITHOUT loader waves (gemm288q_dma_kernel, round 6): its waves wait on their vector-memory queue inside the
+// k-loop, so the requests go out BEHIND the loop - in front of an epilogue that loads nothing - from the LAST round of workgroups (the
+// last min(grid, 256) ids: a multi-round launch streams several times the Infinity Cache's size between its first round and its end).
+// Measured why it matters (profiles/r6_fc1_onepass.txt): fc1 at T = 4096 on this kernel without the carry was 5.5 us faster than the
+// two-pass kernel and made the fc2 launch behind it 8 us slower - fc2's 10.6 MB of weights then came from HBM.
+template <int DT>
+__device__ __forceinline__ pf_u32x2 gemm_prefetch_lines_tail(const GemmArgs<DT>& p, int wave, int lane) {
+    pf_u32x2 v = {0u, 0u};
+    if (p.pf_lines > 0) {                                  // (uniform)
+        const int last = min((int)gridDim.x, 256), b = (int)blockIdx.x - ((int)gridDim.x - last);
+        if (b >= 0) {
+            const int64_t l0 = ((int64_t)b * 8 + wave) * 64 + lane, stride = (int64_t)last * 512;
+            if (l0 < p.pf_lines) v[0] = *reinterpret_cast<const unsigned*>(p.pf_ptr + l0 * 128);
+            if (l0 + stride < p.pf_lines) v[1] = *reinterpret_cast<const unsigned*>(p.pf_ptr + (l0 + stride) * 128);
+        }
     }
     return v;
 }
@@ -1778,7 +1797,14 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
     else main_loop(std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (clamped tail DMAs)
     if (pl_prof) pc2 = __builtin_readcyclecounter();
+    // the launch's carried weight prefetch (gemm_prefetch_lines_tail): the epilogues that load nothing from global memory
+    // (vmcnt is one in-order queue: whatever an epilogue loads must be requested BEFORE these lines, or its wait includes their trip from
+    //  HBM - the fold consumers load nothing, EPI_LINEAR asks behind its bias vector; the other epilogues ignore the range)
+    constexpr bool PF_TAIL = EPI == EPI_HEADS_FOLD || EPI == EPI_LINEAR || EPI == EPI_LINEAR_FOLD;
+    pf_u32x2 pf_v = {0u, 0u};
+    if constexpr (EPI == EPI_HEADS_FOLD || EPI == EPI_LINEAR_FOLD) pf_v = gemm_prefetch_lines_tail<DT>(p, wave, lane);
     auto prof_end = [&]() {
+        if constexpr (PF_TAIL) asm volatile("" ::"v"(pf_v[0]), "v"(pf_v[1]));   // (the requests have returned)
         if (pl_prof) {
             __builtin_amdgcn_s_waitcnt(0);   // the epilogue's stores have been issued AND acknowledged
             const unsigned long long pc3 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
@@ -1936,6 +1962,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
         bpre[j] = V4e{};
         if (p.bias && EPI != EPI_CONVT && EPI != EPI_LINEAR_FOLD) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + nb + j * 16);
     }
+    if constexpr (EPI == EPI_LINEAR) pf_v = gemm_prefetch_lines_tail<DT>(p, wave, lane);
 #ifndef PRIMX_PROBE_SKIPSTORE
     if constexpr (EPI == EPI_GATE_RESIDUAL && KT == 64) {
         // Round 6: the fp32 read-modify-write of the residual rows as a pipeline.  The epilogue below asks for a row group's 36 + 18
@@ -2076,7 +2103,7 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
             }
             }
         } else if (EPI == EPI_LINEAR_FOLD) {
-            // (the epilogue of gemm288p_dma_kernel<., true>: statistics and u / v from LDS, 16-byte stores by permlane swap)
+            // (statistics and u / v from LDS, 16-byte stores by permlane swap)
             typedef unsigned int u32;
             S* orow = p.out + (int64_t)mc * pl_N + n0 + wn * 144;
             const f32x2 fst = fstat[wm * 64 + i * 16 + lr];
@@ -2134,265 +2161,11 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Two-pass big tile for the Linear epilogue (fc1 + GELU): a workgroup owns a 256 x 288 output tile like gemm288q, but computes
-// it as TWO passes of 256 x 144 with the wave roles of the loader-wave kernel (8 compute waves = 8 row groups of 32 rows x
-// 144 columns over the full K, 72 accumulators each; waves 8 and 9 only issue LDS-DMA).
-// Why (round 3, PRIMX_GEMM_PROF timelines + tools/probe/write_burst.hip): inside the DDIM step the fc1 kernel spent 32k of its
-// 97k cycles per workgroup behind its last MFMA - GELU arithmetic and, mostly, waiting for the 37.7 MB of output that all 256
-// workgroups store at once (2.2 TB/s) - and without the stores its main loop ran in 49.5k cycles at a HIGHER clock (26 us for
-// the whole kernel against 53).  A one-tile-per-CU kernel cannot hide that: nothing is left to compute when the stores start.
-// Here the first pass's stores drain while the second pass multiplies (the compute waves never wait on vmcnt in the loop), the
-// loader waves run ahead across the pass boundary (the ring holds the second pass's first tiles when the first epilogue
-// ends), and only the second half of the output is exposed.  The price is bytes per FLOP - (256 + 144) x 128 B per 64-wide
-// k-tile = 50 DMA instructions x 24.5 cycles = 1225 against 1152 cycles of MFMA per SIMD: the loop sits at the DMA unit's rate,
-// which the loader waves reach (DESIGN_LOG.md section 4) where the 8-wave 256 x 288 loop measured 3100 per (twice as large) k-tile.
-// Pipeline: the unit is a 32-wide k-step (18 MFMAs per wave).  Fragments of step u + 1 are read while step u multiplies; the
-// ONE barrier per k-tile sits between its two steps: B_g = "reads of tile g are home (its stage may be refilled), tile g + 1 has
-// landed" - the same two-tiles-of-flight ring protocol as gemm144l_dma_kernel, all ten waves execute every barrier.
-// FOLD: the Linear is the consumer of a folded LayerNorm site (fc1; see fold_stats_load): row statistics from the producer's partial
-// sums at kernel start, y = rho (acc - mu' u) + v in place of acc + bias.
-template <int DT, bool FOLD = false>
-__global__ __launch_bounds__(640) void gemm288p_dma_kernel(PRIMX_GEMM_PARAMS(DT)) {
-    PRIMX_GEMM_ARGS(DT);
-    unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pc2 = 0;   // PRIMX_GEMM_PROF=1 timeline (see g_gemm_prof)
-    if (pl_prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
-    using S = typename T16<DT>::S;
-    using V8 = typename T16<DT>::V8;
-    using V4e = typename T16<DT>::V4;
-    typedef __attribute__((address_space(1))) const void GV;
-    typedef __attribute__((address_space(3))) void LV;
-    constexpr int BM = 256, BN = 144, MI = 2, NI = 9, NST = 3, NPASS = 2;
-    constexpr int ROWS = BM + BN, STAGE = ROWS * 64, NINST = ROWS / 8, NL = NINST / 2;   // 50 wave-instructions per tile, 25 per loader
-    // FOLD, behind the ring: (mu', rho) of the tile's 256 rows, then u and v of its 288 columns (fetched at kernel start: requested
-    // at the head of each pass's epilogue they cost every pass an L2 round trip with nothing to overlap it - fc1 57.5 vs 53.0 us)
-    constexpr int STAT_HALVES = FOLD ? BM * 4 + 2 * NPASS * BN * 2 : 0;
-    static_assert((NST * STAGE + STAT_HALVES) * 2 <= 160 * 1024 && NINST % 2 == 0 && BM % 8 == 0, "LDS budget / loader split");
-    __shared__ __attribute__((aligned(16))) S smem[NST * STAGE + STAT_HALVES];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = pl_N / (NPASS * BN), mt = (pl_M + BM - 1) / BM;
-    int mi_t, ni_t;
-    if (pl_xcd_gm > 0) {   // packed gm | sr << 8 | sc << 16 (xcd_pack)
-        xcd_tile2d(blockIdx.x, mt, nt, pl_xcd_gm, mi_t, ni_t);
-    } else {
-        const int id = xcd_remap(blockIdx.x, nt * mt);
-        mi_t = id / nt;
-        ni_t = id - mi_t * nt;
-    }
-    const int m0 = mi_t * BM, n00 = ni_t * NPASS * BN;
-    const int nk = pl_K / BK, total = NPASS * nk;
-
-    if (wave >= 8) {
-        if (PRIMX_LOADER_PRIO) __builtin_amdgcn_s_setprio(PRIMX_LOADER_PRIO);
-        // ---------------- loader wave lw: instructions t = lw * 25 + i, rows 8 t .. 8 t + 7 of the 400-row stage image (rows
-        // < 256: activations, the same for both passes; the rest: the pass's 144 weight rows)
-        const int lw = wave - 8;
-        const S* gp[NL];
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int row = 8 * (lw * NL + i) + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> 1) & 7);
-            gp[i] = (row < BM) ? pl_A + (int64_t)min(m0 + row, pl_M - 1) * pl_K + c * 8 : pl_W + (int64_t)(n00 + row - BM) * pl_K + c * 8;
-        }
-        auto issue = [&](int g, int stage) {  // global tile g = pass * nk + kt
-            const int pass = g >= nk ? 1 : 0, kt = g - pass * nk;
-            const int64_t wpass = (int64_t)pass * BN * pl_K;                                // pass 1: the next 144 weight rows
-#pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                const int64_t adv = ((lw * NL + i) * 8 >= BM ? wpass : 0) + kt * BK;      // (wave-uniform: an instruction is all activation or all weight rows)
-                __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + adv), (LV*)(smem + stage * STAGE + (lw * NL + i) * 512), 16, 0, 0);
-            }
-        };
-        issue(0, 0);
-        issue(min(1, total - 1), 1);
-        issue(min(2, total - 1), 2);
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NL) : "memory");      // P: tile 0 landed
-        int st = 0;
-        for (int g = 0; g < total; ++g) {
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");     // B_g: tile g + 1 landed, g + 2 may fly
-            issue(min(g + NST, total - 1), st);                                            // tile g's stage is free now
-            st = (st == NST - 1) ? 0 : st + 1;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 // the clamped tail must not outlive the LDS
-        return;
-    }
-
-    // ---------------- compute wave w: rows 32 w .. 32 w + 31 of the tile, all 144 columns of the pass, the whole K
-    if (PRIMX_COMPUTE_PRIO) __builtin_amdgcn_s_setprio(PRIMX_COMPUTE_PRIO);
-    const int lr = lane & 15, lg = lane >> 4;
-    const int a_row = wave * 32 + lr;
-    auto read_frags = [&](int stage, int ks, V8 (&a)[MI], V8 (&b)[NI]) {
-        const S* As = smem + stage * STAGE;
-        const S* Ws = As + BM * 64;
-        const int chunk = ks * 4 + lg;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const V8*>(As + lds_off(a_row + i * 16, chunk));
-#pragma unroll
-        for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(Ws + lds_off(lr + j * 16, chunk));
-    };
-    f32x4 acc[MI][NI];
-    // operands swapped (A = weight rows, B = activation rows): the accumulator holds C^T, a lane owns ONE row and four
-    // consecutive columns - acc[i][j][r] = C[m0 + 32 w + 16 i + lr][n0 + 16 j + 4 lg + r] - and the epilogue needs no LDS
-    auto multiply = [&](const V8 (&a)[MI], const V8 (&b)[NI]) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = T16<DT>::mfma16(b[j], a[i], acc[i][j]);
-    };
-    f32x2* const fstat = reinterpret_cast<f32x2*>(smem + NST * STAGE);
-    float* const fu = reinterpret_cast<float*>(smem + NST * STAGE + BM * 4);             // u[288], then v[288]
-    FoldPartials fpart;
-    f32x2 fu2 = {0.f, 0.f}, fv2 = {0.f, 0.f};
-    const int tuv = tid - BM;                                                            // waves 4 - 7: two columns each
-    if constexpr (FOLD) {
-        if (wave < BM / 64) fpart = fold_stats_load<DT>(p, pl_M, m0, tid);
-        else if (tuv < NPASS * BN / 2) {
-            fu2 = *reinterpret_cast<const f32x2*>(p.fold_u + n00 + 2 * tuv);
-            fv2 = *reinterpret_cast<const f32x2*>(p.fold_v + n00 + 2 * tuv);
-        }
-    }
-    const pf_u32x2 pf_v = gemm_prefetch_lines<DT>(p, wave, lane);                        // (the launch's prefetch range)
-    if constexpr (FOLD) {
-        if (wave < BM / 64) fold_stats_finish<DT>(p, fpart, pl_M, pl_K, m0, tid, ni_t == 0, fstat);
-        else if (tuv < NPASS * BN / 2) {
-            *reinterpret_cast<f32x2*>(fu + 2 * tuv) = fu2;
-            *reinterpret_cast<f32x2*>(fu + NPASS * BN + 2 * tuv) = fv2;
-        }
-    }
-    asm volatile("s_barrier" ::: "memory");                                              // P
-    if (pl_prof) pc1 = __builtin_readcyclecounter();
-    int st = 0;
-    const bool gelu_fast = p.act == PRIMX_ACT_GELU_TANH && p.out_scale == 1.0f;   // (uniform: one branch per row group, see linear_out4)
-#pragma unroll 1
-    for (int pass = 0; pass < NPASS; ++pass) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        V8 a0[MI], b0[NI], a1[MI], b1[NI];
-        read_frags(st, 0, a0, b0);                 // (tile pass * nk has landed: P, or B of the previous pass's last tile)
-#pragma unroll 1
-        for (int kt = 0; kt < nk; ++kt) {
-            const int st_next = (st == NST - 1) ? 0 : st + 1;
-            read_frags(st, 1, a1, b1);
-            multiply(a0, b0);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // B_g
-            // (unconditional: behind the pass's last tile the stage holds the next pass's first tile - or the clamped re-fetch of
-            // the very last one - and the values are simply not used; a conditional read kept both fragment sets live through the loop)
-            read_frags(st_next, 0, a0, b0);
-            multiply(a1, b1);
-            st = st_next;
-        }
-        if (pl_prof && pass == NPASS - 1) pc2 = __builtin_readcyclecounter();
-        // ---- epilogue of the pass, from registers: bias, rounding, activation, 16-byte stores (the lane groups of a row trade
-        // halves of neighbouring 16-column tiles with v_permlane16_swap, see gemm288q_dma_kernel).  Nothing below waits for the
-        // stores: the next pass's fragments and MFMAs follow immediately.
-        const int n0 = n00 + pass * BN;
-        typedef unsigned int u32;
-        if constexpr (FOLD) {
-            // column pairs outermost: the u / v vectors of a pair (16 registers) serve both row groups - all nine tiles' vectors next to
-            // the 72 accumulators did not fit the 168 registers of a 10-wave workgroup
-            f32x2 fst[MI];
-            bool ok[MI];
-            S* orow[MI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int m = m0 + wave * 32 + i * 16 + lr;
-                ok[i] = m < pl_M;
-                orow[i] = p.out + (int64_t)(ok[i] ? m : pl_M - 1) * pl_N + n0;
-                fst[i] = fstat[wave * 32 + i * 16 + lr];
-            }
-            const float* up = fu + pass * BN + 4 * lg;                                   // (LDS)
-            const float* vp = fu + NPASS * BN + pass * BN + 4 * lg;
-#pragma unroll
-            for (int j = 0; j + 1 < NI; j += 2) {
-                const f32x4 u0 = *reinterpret_cast<const f32x4*>(up + j * 16), v0 = *reinterpret_cast<const f32x4*>(vp + j * 16);
-                const f32x4 u1 = *reinterpret_cast<const f32x4*>(up + j * 16 + 16), v1 = *reinterpret_cast<const f32x4*>(vp + j * 16 + 16);
-                auto rows = [&](auto gelu) {
-                    constexpr bool G = decltype(gelu)::value;
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) {
-                        const u32x2 a = __builtin_bit_cast(u32x2, fold_out4<DT, G>(p, fold_apply(acc[i][j], fst[i], u0, v0)));
-                        const u32x2 b = __builtin_bit_cast(u32x2, fold_out4<DT, G>(p, fold_apply(acc[i][j + 1], fst[i], u1, v1)));
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-                        const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
-                        if (ok[i]) out_store(reinterpret_cast<u32x4*>(orow[i] + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
-                    }
-                };
-                if (gelu_fast) rows(BoolC<true>{}); else rows(BoolC<false>{});
-            }
-            const f32x4 u8 = *reinterpret_cast<const f32x4*>(up + (NI - 1) * 16), v8 = *reinterpret_cast<const f32x4*>(vp + (NI - 1) * 16);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                if (ok[i]) {
-                    const f32x4 y8 = fold_apply(acc[i][NI - 1], fst[i], u8, v8);
-                    V4e o8;
-                    if (gelu_fast) {
-                        asm volatile("" ::: "memory");
-                        o8 = fold_out4<DT, true>(p, y8);
-                    } else {
-                        o8 = fold_out4<DT>(p, y8);
-                    }
-                    out_store(reinterpret_cast<V4e*>(orow[i] + (NI - 1) * 16 + 4 * lg), o8);
-                }
-        } else {
-        V4e bpre[NI];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            bpre[j] = V4e{};
-            if (p.bias) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + n0 + j * 16 + 4 * lg);
-        }
-        // column pairs outermost, as in the fold branch: the pair's bias values are converted once for both row groups (with the row
-        // groups outermost the compiler keeps all 36 converted values alive across them: 92 bytes of scratch in the 168-register budget)
-        bool ok[MI];
-        S* orow[MI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wave * 32 + i * 16 + lr;
-            ok[i] = m < pl_M;
-            orow[i] = p.out + (int64_t)(ok[i] ? m : pl_M - 1) * pl_N + n0;
-        }
-        auto cols = [&](auto gelu) {
-            constexpr bool G = decltype(gelu)::value;
-#pragma unroll
-            for (int j = 0; j + 1 < NI; j += 2) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const u32x2 a = __builtin_bit_cast(u32x2, linear_out4<DT, G>(p, acc[i][j], bpre[j]));
-                    const u32x2 b = __builtin_bit_cast(u32x2, linear_out4<DT, G>(p, acc[i][j + 1], bpre[j + 1]));
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-                    const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
-                    if (ok[i]) out_store(reinterpret_cast<u32x4*>(orow[i] + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                if (ok[i]) out_store(reinterpret_cast<V4e*>(orow[i] + (NI - 1) * 16 + 4 * lg), linear_out4<DT, G>(p, acc[i][NI - 1], bpre[NI - 1]));
-        };
-        if (gelu_fast) cols(BoolC<true>{}); else cols(BoolC<false>{});
-        }
-    }
-    asm volatile("" ::"v"(pf_v[0]), "v"(pf_v[1]));
-    if (pl_prof) {
-        __builtin_amdgcn_s_waitcnt(0);   // the stores have been acknowledged
-        const unsigned long long pc3 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0) {
-            atomicMin(&g_gemm_prof[0], pr0); atomicMax(&g_gemm_prof[1], pr1);
-            atomicAdd(&g_gemm_prof[2], pc1 - pc0); atomicAdd(&g_gemm_prof[3], pc2 - pc1);
-            atomicAdd(&g_gemm_prof[4], pc3 - pc2); atomicAdd(&g_gemm_prof[5], 1ull); atomicAdd(&g_gemm_prof[6], pr0);
-            atomicAdd(&g_gemm_prof[8], pr1 - pr0); atomicAdd(&g_gemm_prof[9], pc3 - pc0);
-            if (blockIdx.x < 4096) {
-                unsigned xcc;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                g_gemm_wg[blockIdx.x][0] = pr0; g_gemm_wg[blockIdx.x][1] = pr1 - pr0; g_gemm_wg[blockIdx.x][2] = pc3 - pc0;
-                g_gemm_wg[blockIdx.x][3] = ((unsigned long long)(xcc & 15) << 32) | (unsigned)(pc3 - pc2);
-            }
-        }
-    }
-}
+// (Rounds 3 - 5 had a TWO-PASS form of the big tile here for the Linear epilogue's one-round launches - gemm288p_dma_kernel: the 256 x 288
+// tile as two 256 x 144 passes with loader waves, so that the first pass's stores drained under the second pass; fc1 + GELU at T = 4096
+// 56 -> 50.5 us in the step.  It left in round 6: with the GELU arithmetic in packed fp32 (epilogue 19k -> 10k cycles), 128-byte row
+// segments (KT = 64) and the carried weight prefetch in gemm288q_dma_kernel, the one-pass kernel runs the same launch in 46.3 us and
+// the fc2 launch behind it as fast as before - profiles/r6_fc1_onepass.txt.  The two-pass loop read 37 LDS bytes per kFLOP against 22.)
 
 // ---------------------------------------------------------------------------------------------------
 // (Round 5's persistent-pass kernel gemm144pp_dma_kernel - the two-pass tile's 256 x 144 pass as one workgroup per CU walking a list of
@@ -2425,11 +2198,6 @@ static const int g_big_min = [] {   // PRIMX_GEMM_BIG_MIN: fewest 256x288 workgr
 static const int g_big_heads_min = [] {   // fewest 256x288 workgroups for which the heads epilogue takes the big tile
     const char* e = getenv("PRIMX_GEMM_BIGHEADS_MIN");
     return e ? atoi(e) : 160;
-}();
-
-static const bool g_two_pass = [] {   // PRIMX_GEMM_P2=0: the Linear epilogue's big tile on the one-pass 8-wave kernel (gemm288q) instead of gemm288p
-    const char* e = getenv("PRIMX_GEMM_P2");
-    return !(e && e[0] == '0');
 }();
 
 static const bool g_xcd2d = [] {   // PRIMX_GEMM_XCD2D=0: whole tile rows per XCD in the 256x288 kernel (A/B measurements)
@@ -2510,7 +2278,7 @@ static const bool g_kt32 = [] {   // PRIMX_GEMM_KT32=1: the 256x288 kernel on it
 
 static const int g_kt64_min = [] {   // PRIMX_GEMM_KT64_MIN: fewest 256x288 workgroups for which the dense-output epilogues take 128-byte row segments
     const char* e = getenv("PRIMX_GEMM_KT64_MIN");
-    return e ? atoi(e) : 257;
+    return e ? atoi(e) : -1;   // (-1: the rule of launch288q)
 }();
 
 // Which ring: 128-byte row segments (KT = 64) for the dense-output epilogues of launches with more than one round of workgroups -
@@ -2524,7 +2292,10 @@ static void launch288q(const GemmArgs<DT>& x, dim3 grid, hipStream_t st) {
                            EPI == EPI_RES;
     if constexpr (DENSE) {
         const bool full = EPI != EPI_GATE_RESIDUAL || (x.M % 256 == 0 && x.rows_per_batch % 256 == 0);   // (its pipelined epilogue: no ragged tile, one gate row per tile)
-        if (x.K % 64 == 0 && !g_kt32 && full && (int)grid.x >= g_kt64_min && (int64_t)x.M * x.K < (1ll << 31) && (int64_t)x.N * x.K < (1ll << 31)) {
+        // (default: the Linear epilogues always - fc1 at T = 4096, ONE round of 256 workgroups, 50.5 -> 45.0 us in the step against the
+        //  two-pass kernel once this kernel carries the weight prefetch; the read-modify-write epilogues from two rounds on)
+        const int kt64_min = g_kt64_min >= 0 ? g_kt64_min : (EPI == EPI_LINEAR || EPI == EPI_LINEAR_FOLD) ? 1 : 257;
+        if (x.K % 64 == 0 && !g_kt32 && full && (int)grid.x >= kt64_min && (int64_t)x.M * x.K < (1ll << 31) && (int64_t)x.N * x.K < (1ll << 31)) {
             PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d, 64>", DT, EPI);
             hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI, 64>), grid, dim3(512), 0, st, PRIMX_GEMM_PASS(x));
             return;
@@ -2567,12 +2338,7 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     auto go = [&](const GemmArgs<DT>& x) {
         // the LayerNorm-fold epilogues exist in exactly one kernel per tile shape (launch_fold checked the shape)
         if constexpr (FOLD_EPI) {
-            if (BIG && EPI == EPI_LINEAR_FOLD && g_two_pass && (int)grid.x <= 256) {   // (the rule of the unfolded Linear below)
-                if constexpr (BIG && EPI == EPI_LINEAR_FOLD) {
-                    PRIMX_NOTE_KERNEL("gemm288p_dma_kernel<%d, true>", DT);
-                    hipLaunchKernelGGL((gemm288p_dma_kernel<DT, true>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
-                }
-            } else if constexpr (BIG) {
+            if constexpr (BIG) {
                 launch288q<DT, EPI>(x, grid, st);
             } else {
                 PRIMX_NOTE_KERNEL("gemm144l_dma_kernel<%d, %d>", DT, EPI);
@@ -2580,13 +2346,7 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
             }
             return;
         } else {
-        // two passes only when the launch is ONE round of workgroups (fc1 at T = 4096: exactly 256): there the first pass's stores
-        // drain under the second pass (the step 8.97 -> 8.92 ms same box); with several rounds per CU the next workgroup already
-        // overlaps the previous one's drain and the one-pass tile's fewer bytes per FLOP win (T = 32768: 428 vs 451 us)
-        if (BIG && EPI == EPI_LINEAR && g_two_pass && (int)grid.x <= 256) {
-            PRIMX_NOTE_KERNEL("gemm288p_dma_kernel<%d, false>", DT);
-            hipLaunchKernelGGL((gemm288p_dma_kernel<DT>), grid, dim3(640), 0, st, PRIMX_GEMM_PASS(x));
-        } else if (BIG) {
+        if (BIG) {
             launch288q<DT, EPI>(x, grid, st);
         } else if (g_loader && loader_ok) {
             if constexpr (EPI == EPI_GATE_RESIDUAL) {
@@ -2634,7 +2394,7 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     fprintf(stderr, "%s<%d,%d> M=%d N=%d K=%d: %llu workgroups, events %.1f us, first start -> last end %.1f us, mean start offset "
                     "%.1f us, shader clock %.2f GHz (core cycles / 100 MHz ticks per workgroup); per workgroup (core cycles): entry->tile0 %.0f | main loop "
                     "%.0f | epilogue %.0f (LDS staging %.0f, read+store issue %.0f)\n",
-            BIG ? ((EPI == EPI_LINEAR || EPI == EPI_LINEAR_FOLD) && g_two_pass && (int)grid.x <= 256 ? "gemm288p_dma" : "gemm288q_dma")
+            BIG ? "gemm288q_dma"
                 : (FOLD_EPI || (g_loader && loader_ok)) ? "gemm144l_dma" : "gemm144_dma", DT, EPI, a.M, a.N, a.K,
             r[5], ms * 1e3, (r[1] - r[0]) * 0.01, (r[6] / n - (double)r[0]) * 0.01, r[8] ? (double)r[9] / (double)r[8] * 0.1 : 0.0,
             r[2] / n, r[3] / n, r[4] / n, (r[7] >> 32) / n,
@@ -2742,7 +2502,7 @@ int launch_fold(const GemmArgs<DT>& a, hipStream_t st, const char* name) {
             }
         } else {
             const int wgs = ((a.M + 255) / 256) * (a.N / 288);
-            if (!g_no_big && a.N % 288 == 0 && wgs >= g_big_min) launch144_dma<DT, EPI, 1>(a, mt, st);   // two-pass or one-pass: go()
+            if (!g_no_big && a.N % 288 == 0 && wgs >= g_big_min) launch144_dma<DT, EPI, 1>(a, mt, st);
             else launch144_dma<DT, EPI>(a, mt, st);
         }
     }

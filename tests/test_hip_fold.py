@@ -31,7 +31,7 @@ def ops():
 
 
 def _default_dispatch() -> bool:
-    return not any(os.environ.get(v) for v in ("PRIMX_GEMM_LOADER", "PRIMX_GEMM_NOBIG", "PRIMX_GEMM_P2", "PRIMX_GEMM_BIG_MIN",
+    return not any(os.environ.get(v) for v in ("PRIMX_GEMM_LOADER", "PRIMX_GEMM_NOBIG", "PRIMX_GEMM_BIG_MIN",
                                                "PRIMX_GEMM_BIGHEADS_MIN", "PRIMX_GEMM_PROF", "PRIMX_LIB"))
 
 
@@ -237,11 +237,11 @@ def test_fold_consumer_qkv(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("B,n,kernel", [(2, 2048, "gemm288p_dma_kernel"), (2, 1950, "gemm288p_dma_kernel"), (1, 1024, "gemm144l_dma_kernel"),
+@pytest.mark.parametrize("B,n,kernel", [(2, 2048, "gemm288q_dma_kernel"), (2, 1950, "gemm288q_dma_kernel"), (1, 1024, "gemm144l_dma_kernel"),
                                         (1, 333, "gemm144l_dma_kernel"), (4, 2048, "gemm288q_dma_kernel"), (3, 1500, "gemm288q_dma_kernel")])
 def test_fold_consumer_fc1(ops, dtype, B, n, kernel):
-    """The fc1 form: GELU(tanh) behind the fold, on the two-pass 256 x 288 kernel (T = 4096: 256 workgroups), on the loader-wave
-    128 x 144 kernel (smaller launches) and on the one-pass 256 x 288 kernel (more than 256 workgroups); ragged last tiles."""
+    """The fc1 form: GELU(tanh) behind the fold, on the 256 x 288 kernel (T = 4096: ONE round of 256 workgroups - the two-pass kernel's
+    launches until round 6 - and more) and on the loader-wave 128 x 144 kernel (smaller launches); ragged last tiles."""
     from topia_xl_amd._lib import ACT_GELU_TANH
     D, Hm = 1152, 4608
     Wc = synth.tensor(33, "Wfc1", (Hm, D), D ** -0.5).to(dtype)
@@ -380,7 +380,7 @@ def test_dit_with_the_fold_against_the_unfolded_path_and_the_oracle(ops, dtype, 
         assert len(ln_calls) == 2 * 4, len(ln_calls)                       # the first LayerNorm and the final layer's, per forward
         assert sum(1 for nm in names if ", 6> " in nm) == 4 * (3 * 3 - 1), names   # producers: every gated add but the last
         assert sum(1 for nm in names if ", 7> " in nm) == 4 * (2 * 3 - 1)          # to_q (blocks 1, 2) + qkv
-        assert sum(1 for nm in names if nm.startswith("gemm288p_dma_kernel") and "true" in nm) == 4 * 3
+        assert sum(1 for nm in names if nm.startswith("gemm288q_dma_kernel") and ", 8, 64>" in nm) == 4 * 3
     # one planned forward against the fp32 oracle
     t = torch.tensor([520])
     ref32 = dit_ref.dit_forward_with_cfg(sd, x, t, y, 16, 6.0, None)

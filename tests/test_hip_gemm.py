@@ -24,7 +24,7 @@ def _default_dispatch() -> bool:
     """False when a kernel-selection switch of DESIGN_LOG.md section 8 is set: the arithmetic checks still run (that is what
     tools/gpu/gpu_verify.sh --switches is for), the assertions on WHICH kernel was launched do not apply."""
     import os
-    return not any(os.environ.get(v) for v in ("PRIMX_GEMM_LOADER", "PRIMX_GEMM_NOBIG", "PRIMX_GEMM_P2", "PRIMX_GEMM_BIG_MIN",
+    return not any(os.environ.get(v) for v in ("PRIMX_GEMM_LOADER", "PRIMX_GEMM_NOBIG", "PRIMX_GEMM_BIG_MIN",
                                                "PRIMX_GEMM_BIGHEADS_MIN", "PRIMX_GEMM_NOGEMV", "PRIMX_GEMM_PROF", "PRIMX_LIB",
                                                "PRIMX_LN_FUSE", "PRIMX_LN_FUSE_MAXGRID", "PRIMX_GEMM_KT32", "PRIMX_GEMM_KT64_MIN"))
 
@@ -276,7 +276,7 @@ def test_reported_kernel_names_of_the_headline_shapes(ops):
     ops.linear_gate_residual(A, W[:D].contiguous(), b[:D], gate, x, 2048)
     assert name() == "gemm144l_dma_kernel<1, 1>"                                           # fc2
     ops.linear(A[:, :D].contiguous(), W[:, :D].contiguous(), b)
-    assert name() == "gemm288p_dma_kernel<1, false>"                                              # fc1: 256 workgroups of 256 x 288, two passes
+    assert name() == "gemm288q_dma_kernel<1, 0, 64>"                                              # fc1: 256 workgroups of 256 x 288, 128-byte ring
     ops.linear(A[:, :D].contiguous(), W[:136, :D].contiguous(), b[:136])
     assert name().startswith("gemm_kernel<1, 0, 32, 2, 2, 2, 2, 0>")                           # final layer
     ops.linear(A[:2, :D].contiguous(), W[:, :D].contiguous(), b)
@@ -296,15 +296,15 @@ def test_reported_kernel_names_of_the_headline_shapes(ops):
         tag = ops.PROFILE[0][0]
     finally:
         ops.PROFILE = None
-    assert tag == "gemm288p_dma_kernel<1, false> 4096x4608x1152", tag
+    assert tag == "gemm288q_dma_kernel<1, 0, 64> 4096x4608x1152", tag
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,K", [(4096, 64), (4096, 128), (3900, 192), (3600, 1152)])
-def test_two_pass_big_tile_edges(ops, dtype, M, K):
-    """gemm288p_dma_kernel (the Linear epilogue's 256 x 288 tile as two 256 x 144 passes with loader waves; one-round launches:
-    224 <= workgroups <= 256): one and two k-tiles per pass (fewer than ring stages: the ring then holds both passes at once), a
-    ragged last M tile, 15 instead of 16 row tiles, with / without bias, GELU (tanh and erf) and an output scale."""
+def test_one_round_big_tile_edges(ops, dtype, M, K):
+    """The Linear epilogue's one-round launches of the 256 x 288 tile (224 <= workgroups <= 256; the two-pass kernel's until round 6,
+    gemm288q_dma_kernel on its 128-byte ring since): one, two and three 64-wide k-tiles (fewer than, as many as and more than ring
+    stages), a ragged last M tile, 15 instead of 16 row tiles, with / without bias, GELU (tanh and erf) and an output scale."""
     from topia_xl_amd import _lib
     N = 4608
     assert 224 <= ((M + 255) // 256) * (N // 288) <= 256
@@ -312,7 +312,7 @@ def test_two_pass_big_tile_edges(ops, dtype, M, K):
     r = lambda t: t.to(dtype).double()
     got = ops.linear(A.to(DEV), W.to(DEV), b.to(DEV))
     if _default_dispatch():
-        assert _lib.load().primx_last_gemm_kernel().decode().startswith("gemm288p_dma_kernel")
+        assert _lib.load().primx_last_gemm_kernel().decode() == f"gemm288q_dma_kernel<{1 if dtype == torch.float16 else 2}, 0, 64>"
     assert rel_l2(got, ref) < TOL[dtype], rel_l2(got, ref)
     assert rel_l2(ops.linear(A.to(DEV), W.to(DEV), None), ref - b.double()) < TOL[dtype]
     got = ops.linear(A.to(DEV), W.to(DEV), b.to(DEV), act=1)                              # tanh GELU

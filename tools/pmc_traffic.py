@@ -15,13 +15,15 @@ CYCLES = {  # kernel name prefix -> shape tags in launch order within one block 
     "gemm144l_dma_kernel<1, 1>": ["4096x1152x1152", "4096x1152x1152", "4096x1152x4608"],
     "gemm144l_dma_kernel<1, 2>": ["4096x1152x1152"],
     "gemm288q_dma_kernel<1, 0>": ["4096x4608x1152"],
-    "gemm288p_dma_kernel<1, false>": ["4096x4608x1152"],
+    "gemm288q_dma_kernel<1, 0, 64>": ["4096x4608x1152"],
+    "gemm288p_dma_kernel<1, false>": ["4096x4608x1152"],     # (rounds 3 - 5 traces)
     # with the LayerNorm fold (DiT.fold_ln, the default in planned loops): producers <1, 6> = cproj, proj, fc2 of every block but the
-    # last one's fc2, which stays <1, 1>; consumers <1, 7> (to_q from block 1 on; qkv on the 256 x 288 tile), fc1 on <1, true>
+    # last one's fc2, which stays <1, 1>; consumers <1, 7> (to_q from block 1 on; qkv on the 256 x 288 tile), fc1 on gemm288q<1, 8, 64>
     "gemm144l_dma_kernel<1, 6>": ["4096x1152x1152", "4096x1152x1152", "4096x1152x4608"] * 27 + ["4096x1152x1152"] * 2,
     "gemm144l_dma_kernel<1, 7>": ["4096x1152x1152"],
     "gemm288q_dma_kernel<1, 7>": ["4096x3456x1152"],
-    "gemm288p_dma_kernel<1, true>": ["4096x4608x1152"],
+    "gemm288q_dma_kernel<1, 8, 64>": ["4096x4608x1152"],
+    "gemm288p_dma_kernel<1, true>": ["4096x4608x1152"],      # (rounds 4 - 5 traces)
     "attn_kernel<1, 5, 3, 0, 0>": ["32x2048x1370x72", "32x2048x2048x72"],
     # --config decode (2048 primitives): one shape per kernel
     "conv3_s4c256_kernel<1, 0>": ["256->256 @4^3 x2048"],
