@@ -94,8 +94,19 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_kernel(const typename T16<DT>
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave / HW, rw = wave % HW;                                  // wave-uniform
     const int l31 = lane & 31, hi = lane >> 5;
-    const int bh = blockIdx.x;  // (batch, head) fastest: with B*H % 8 == 0 all query tiles of a head share an XCD's L2
-    const int q0 = blockIdx.y * BQ;
+    // Workgroup id -> (batch-head, query tile).  Ids go round-robin over the 8 XCDs, so with B*H % 8 == 0 all query tiles of a head share
+    // an XCD's L2 whatever the order - but the ORDER decides whether its K / V^T (0.7 MB at 2048 keys) are still there for the next query
+    // tile: with (batch, head) fastest an XCD's 32 CUs hold 32 different heads at a time (22 MB of operands through a 4 MB L2) and every
+    // query tile re-fetches its head's keys from the fabric - 1577 MB per launch at batch 8 against 180 MB of operands
+    // (profiles/r6_largeM_diagnosis.txt section 5).  Query tiles fastest INSIDE an XCD (round 6): the XCD's l-th workgroup is query
+    // tile l % nqt of its head l / nqt - 32 CUs hold 32 / nqt heads.
+    int bh = blockIdx.x, qt = blockIdx.y;
+    if ((gridDim.x & 7) == 0) {
+        const int id = blockIdx.x + gridDim.x * blockIdx.y, l = id >> 3, j = l / (int)gridDim.y;
+        qt = l - j * (int)gridDim.y;
+        bh = (id & 7) + 8 * j;
+    }
+    const int q0 = qt * BQ;
     // Batch entries >= b_from attend to nkv COPIES OF ONE key / value row (primx_attention_bcast: the unconditional half of
     // classifier-free guidance, whose conditioning tokens are one embedding expanded to the sequence length).  Their operands
     // hold that sequence once - tile 0 = 64 copies, tile 1 = the ragged last tile (nkv % 64 keys, the rest masked like any

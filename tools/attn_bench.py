@@ -9,7 +9,8 @@ from topia_xl_amd._lib import HEADS_KROWS, HEADS_ROWS, HEADS_VT
 
 dev, dt, reps = "cuda:0", torch.float16, int(os.environ.get("REPS", "20"))
 for name, B, H, nq, nkv, dh in [("self_b1", 2, 16, 2048, 2048, 72), ("cross_b1", 2, 16, 2048, 1370, 72),
-                                ("self_b8", 16, 16, 2048, 2048, 72), ("self_n4096", 2, 16, 4096, 4096, 72)]:
+                                ("self_b8", 16, 16, 2048, 2048, 72), ("cross_b8", 16, 16, 2048, 1370, 72),
+                                ("self_n4096", 2, 16, 4096, 4096, 72), ("self_n4096_b4", 8, 16, 4096, 4096, 72)]:
     q = torch.randn(B, nq, H, dh, device=dev).to(dt)
     k = torch.randn(B, nkv, H, dh, device=dev).to(dt)
     v = torch.randn(B, nkv, H, dh, device=dev).to(dt)

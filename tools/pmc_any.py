@@ -1,7 +1,7 @@
 """Average of arbitrary rocprofv3 --pmc counters per (kernel, shape) tag, per launch.
 
     rocprofv3 --kernel-trace --pmc <counters...> --output-format csv -d DIR -o NAME -- <command>
-    python tools/pmc_any.py DIR/**/NAME_counter_collection.csv [substring filter of the kernel tag ...]
+    python tools/pmc_any.py DIR/**/NAME_counter_collection.csv [--mode=b8] [substring filter of the kernel tag ...]
 
 The tags are those of tools/pmc_traffic.py (kernel name as rocprofv3 prints it + the shape, split by launch order inside one DiT
 block); kernels without an entry there keep their bare name."""
@@ -11,13 +11,19 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from pmc_traffic import CYCLES, short  # noqa: E402
+import pmc_traffic  # noqa: E402
+from pmc_traffic import short, tag_of  # noqa: E402
 
 
 def main():
     cfile, filt = sys.argv[1], sys.argv[2:]
+    MODE = "ddim"
+    if filt and filt[0].startswith("--mode="):
+        MODE, filt = filt[0][7:], filt[1:]
+    rows_all = list(csv.DictReader(open(cfile)))
+    pmc_traffic.FOLDED = any(short(r["Kernel_Name"]).startswith("gemm144l_dma_kernel<1, 6>") for r in rows_all)
     rows, meta = collections.defaultdict(dict), {}
-    for r in csv.DictReader(open(cfile)):
+    for r in rows_all:
         d = int(r["Dispatch_Id"])
         rows[d][r["Counter_Name"]] = float(r["Counter_Value"])
         meta[d] = (r["Kernel_Name"], int(r.get("Grid_Size", 0) or 0))
@@ -26,15 +32,7 @@ def main():
     seen = collections.Counter()
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in sorted(rows):
-        k = short(meta[d][0])
-        cyc = CYCLES.get(k)
-        if k.startswith("gemm288q_dma_kernel<1, 2>"):
-            tag = k + (" 1536x64512x768" if meta[d][1] > 512 * 400 else " 4096x3456x1152")
-        elif cyc:
-            tag = f"{k} {cyc[seen[k] % len(cyc)]}"
-            seen[k] += 1
-        else:
-            tag = k
+        tag = tag_of(meta[d][0], meta[d][1], seen, MODE)
         for c, v in rows[d].items():
             agg[tag][c].append(v)
     names = sorted({c for t in agg.values() for c in t if c != "us"})

@@ -17,25 +17,22 @@ import sys
 
 sys.argv += [None] * 5
 cfile, tfile, out, mode = sys.argv[1], sys.argv[2], sys.argv[3], (sys.argv[4] or "ddim")
-from pmc_traffic import CYCLES, short   # the launch-order -> shape tables  # noqa: E402
+import pmc_traffic  # noqa: E402
+from pmc_traffic import short, tag_of   # the launch-order -> shape tables  # noqa: E402
+
+def gemm_flops(shape):      # "MxNxK" -> 2 M N K; "PxNqxNkvxdh" -> 4 P Nq Nkv dh
+    try:
+        d = [int(x) for x in shape.split("x")]
+    except ValueError:
+        return None
+    return 2 * d[0] * d[1] * d[2] if len(d) == 3 else 4 * d[0] * d[1] * d[2] * d[3] if len(d) == 4 else None
+
 
 FLOPS = {"4096x1152x1152": 2 * 4096 * 1152 * 1152, "4096x1152x4608": 2 * 4096 * 1152 * 4608, "4096x4608x1152": 2 * 4096 * 4608 * 1152,
          "4096x3456x1152": 2 * 4096 * 3456 * 1152, "1536x64512x768": 2 * 1370 * 64512 * 768,
          "32x2048x2048x72": 4 * 32 * 2048 * 2048 * 72, "32x2048x1370x72": 4 * 32 * 2048 * 1370 * 72,
          "256->256 @4^3 x2048": 2 * 2048 * 64 * 256 * 27 * 256, "gn+256->32+sc @8^3 x2048": 2 * 2048 * 512 * 32 * 28 * 256,
          "256->32 @8^3 x2048": 2 * 2048 * 512 * 32 * 27 * 256}
-
-
-def tag_of(kname, grid, seen):
-    k = short(kname)
-    cyc = CYCLES.get(k)
-    if k.startswith("gemm288q_dma_kernel<1, 2>"):
-        return k + (" 1536x64512x768" if grid > 512 * 400 else " 4096x3456x1152")
-    if cyc:
-        t = f"{k} {cyc[seen[k] % len(cyc)]}"
-        seen[k] += 1
-        return t
-    return k
 
 
 dur = {}
@@ -50,10 +47,11 @@ for r in csv.DictReader(open(cfile)):
     meta[d] = (r["Kernel_Name"], int(r.get("Grid_Size", 0)))
     if d not in dur and r.get("End_Timestamp"):      # the counter csv carries the dispatch's own timestamps too
         dur[d] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+pmc_traffic.FOLDED = any(short(m[0]).startswith("gemm144l_dma_kernel<1, 6>") for m in meta.values())
 seen = collections.Counter()
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sorted(rows):
-    tag = tag_of(meta[d][0], meta[d][1], seen)
+    tag = tag_of(meta[d][0], meta[d][1], seen, mode)
     for c, v in rows[d].items():
         agg[tag][c].append(v)
     if d in dur:
@@ -72,7 +70,7 @@ for tag in sorted(agg, key=lambda t: -sum(agg[t]["us"])):
     clk /= div
     util = busy / (1024.0 * gui) if gui else float("nan")
     shape = tag.split("> ")[-1] if "> " in tag else ""
-    fl = FLOPS.get(shape)
+    fl = FLOPS.get(shape) or gemm_flops(shape)
     if "convt_" in tag:                      # the k2s2 upsample shares the convolution's shape tag: 8 taps, not 27
         fl = 2 * 2048 * 64 * 8 * 256 * 256
     tf = fl / us / 1e6 if fl and us else float("nan")

@@ -2,7 +2,7 @@
 launch, keyed like bench.py's per-shape kernel tags ("<kernel name as rocprofv3 prints it> <shape>").  gfx950 correction
 (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes of wide coalesced reads -> doubled; both counters are in KiB.
 
-    python tools/pmc_traffic.py <fetch_csv> <write_csv> <out.json> [ddim|decode]
+    python tools/pmc_traffic.py <fetch_csv> <write_csv> <out.json> [ddim|decode|b8]
 
 Kernels launched with several shapes are split by their position in the (fixed) launch sequence of one DiT block:
 gemm144l_dma_kernel<dt, 1> runs cproj, proj (K = 1152) and fc2 (K = 4608) in that order; attn_kernel alternates
@@ -33,6 +33,41 @@ CYCLES = {  # kernel name prefix -> shape tags in launch order within one block 
 }
 
 
+# BASELINE configs[2] / [3] per-GPU shape (batch 8, T = 32768 token rows, fp16): every GEMM on the 256 x 288 tile.  The kernels that run several
+# shapes are split by launch order (producers <1, 6, 64>: cproj, proj, fc2 per block) or by grid size (heads consumers <1, 7, 32>: qkv 3072
+# workgroups, to_q 1024; <1, 2, 32>: the batched K / V projection, block 0's to_q)
+CYCLES_B8 = {
+    "gemm288q_dma_kernel<1, 6, 64>": ["32768x1152x1152", "32768x1152x1152", "32768x1152x4608"] * 27 + ["32768x1152x1152"] * 2,
+    "gemm288q_dma_kernel<1, 1, 64>": ["32768x1152x4608"],
+    "gemm288q_dma_kernel<1, 8, 64>": ["32768x4608x1152"],
+    "attn_kernel<1, 5, 3, 0, 0>": ["256x2048x1370x72", "256x2048x2048x72"],
+}
+GRID_B8 = {   # kernel -> {workgroups: shape}
+    "gemm288q_dma_kernel<1, 7, 32>": {3072: "32768x3456x1152", 1024: "32768x1152x1152"},
+    "gemm288q_dma_kernel<1, 2, 32>": {1024: "32768x1152x1152", 43008: "12288x64512x768", 21504: "6144x64512x768"},
+}
+
+
+def tag_of(kname, grid, seen, mode="ddim"):
+    """(kernel, shape) tag of one dispatch: `grid` = Grid_Size (threads), `seen` = a Counter of the kernel's earlier dispatches."""
+    k = short(kname)
+    if mode == "b8":
+        if k in GRID_B8:
+            return f"{k} {GRID_B8[k].get(grid // 512, str(grid // 512) + ' workgroups')}"
+        cyc = CYCLES_B8.get(k)
+    else:
+        if k.startswith("gemm288q_dma_kernel<1, 2>") or k.startswith("gemm288q_dma_kernel<1, 2, 32>"):
+            return k + (" 1536x64512x768" if grid > 512 * 400 else " 4096x3456x1152")
+        cyc = CYCLES.get(k)
+        if cyc and k == "gemm144l_dma_kernel<1, 1>" and FOLDED:
+            cyc = ["4096x1152x4608"]                       # only the last block's fc2 is left on the plain gate-residual kernel
+    if cyc:
+        t = f"{k} {cyc[seen[k] % len(cyc)]}"
+        seen[k] += 1
+        return t
+    return k
+
+
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
@@ -40,6 +75,7 @@ def short(name):
 
 
 FOLDED = False   # set by load(): the trace contains fold kernels
+MODE = "ddim"    # "b8": the batch-8 shapes (argv[4])
 
 
 def load(path, counter):
@@ -50,22 +86,13 @@ def load(path, counter):
     FOLDED = any(short(r["Kernel_Name"]).startswith("gemm144l_dma_kernel<1, 6>") for r in rows)
     rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
     for r in rows:
-        k = short(r["Kernel_Name"])
-        cyc = CYCLES.get(k)
-        if k.startswith("gemm288q_dma_kernel<1, 2>"):   # qkv per block + ONE batched K/V projection per forward: split by grid
-            tag = k + (" 1536x64512x768" if int(r.get("Grid_Size", 0)) > 512 * 400 else " 4096x3456x1152")
-        elif cyc:
-            if k == "gemm144l_dma_kernel<1, 1>" and FOLDED:
-                cyc = ["4096x1152x4608"]                   # only the last block's fc2 is left on the plain gate-residual kernel
-            tag = f"{k} {cyc[seen[k] % len(cyc)]}"
-            seen[k] += 1
-        else:
-            tag = k
-        acc[tag].append(float(r["Counter_Value"]))
+        acc[tag_of(r["Kernel_Name"], int(r.get("Grid_Size", 0) or 0), seen, MODE)].append(float(r["Counter_Value"]))
     return acc
 
 
 def main():
+    global MODE
+    MODE = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] else "ddim"
     f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     out = {}
     for k in sorted(set(f) | set(w)):
