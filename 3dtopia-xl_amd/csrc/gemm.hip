@@ -2419,6 +2419,19 @@ void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
                 srt[0], srt[nw / 2], srt[nw * 9 / 10], srt[nw - 1]);
         for (int x = 0; x < 8; ++x) if (xn[x]) fprintf(stderr, "  [%d] %.1f / %.0f / %.1f", x, xs[x] / xn[x], xe[x] / xn[x], xend[x]);
         fprintf(stderr, "\n");
+        if (nw > 256) {   // rounds of 256 workgroups in start order: when does a CU's next workgroup begin after the previous one ended?
+            static int ord[4096];
+            for (int i = 0; i < nw; ++i) ord[i] = i;
+            for (int i = 1; i < nw; ++i) { const int v = ord[i]; int j = i; while (j > 0 && wg[ord[j - 1]][0] > wg[v][0]) { ord[j] = ord[j - 1]; --j; } ord[j] = v; }
+            fprintf(stderr, "   rounds of 256 in start order (us from the first start): mean start / mean end:");
+            for (int r0 = 0; r0 < nw && r0 < 256 * 10; r0 += 256) {
+                double ms_ = 0, me_ = 0;
+                const int n_ = nw - r0 < 256 ? nw - r0 : 256;
+                for (int i = r0; i < r0 + n_; ++i) { ms_ += (wg[ord[i]][0] - r[0]) * 0.01; me_ += (wg[ord[i]][0] + wg[ord[i]][1] - r[0]) * 0.01; }
+                fprintf(stderr, "  %.1f / %.1f", ms_ / n_, me_ / n_);
+            }
+            fprintf(stderr, "\n");
+        }
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 }

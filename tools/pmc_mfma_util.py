@@ -9,7 +9,8 @@ Columns: `busy/SIMD` = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs (cycles the matrix 
 not hold 2.4 GHz under these kernels (the GEMM timelines, PRIMX_GEMM_PROF=1, measure 1.8 - 2.0 GHz as core cycles per 100 MHz
 tick inside the workgroups); `util@GUI` = busy/SIMD / GRBM_GUI_ACTIVE - GUI_ACTIVE also counts the dispatch overhead of a
 profiled launch, so it is only meaningful for kernels of >= 40 us.  "of 2.5PF" = algorithmic FLOPs / duration of THIS
-(profiled) pass / the 2.5 PFLOP/s dense peak."""
+(profiled) pass / the 2.5 PFLOP/s dense peak.  `GHz` = GRBM_GUI_ACTIVE / duration: the shader clock while the kernel ran (same caveat).
+A fourth argument selects the shape tables: ddim (default), b8 (batch 8: T = 32768), c5 (configs[4] per GPU: bf16, N_prim = 4096, batch 4)."""
 import collections
 import csv
 import re
@@ -58,7 +59,7 @@ for d in sorted(rows):
         agg[tag]["us"].append(dur[d])
 mean = lambda v: sum(v) / len(v) if v else float("nan")
 lines = ["# per (kernel, shape): means over the launches of one profiled bench pass (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE)",
-         f"{'launches':>8} {'us':>8} {'busy/SIMD':>10} {'util@2.4':>8} {'util@GUI':>8} {'MFMA insts':>11} {'VALU act/wave-cyc':>17} {'TF/s':>7} {'of 2.5PF':>8}  kernel"]
+         f"{'launches':>8} {'us':>8} {'busy/SIMD':>10} {'util@2.4':>8} {'util@GUI':>8} {'GHz':>5} {'MFMA insts':>11} {'VALU act/wave-cyc':>17} {'TF/s':>7} {'of 2.5PF':>8}  kernel"]
 for tag in sorted(agg, key=lambda t: -sum(agg[t]["us"])):
     a = agg[tag]
     if not any(s in tag for s in ("gemm", "attn", "conv", "ln_modulate", "gemv", "groupnorm")):
@@ -76,6 +77,6 @@ for tag in sorted(agg, key=lambda t: -sum(agg[t]["us"])):
     tf = fl / us / 1e6 if fl and us else float("nan")
     valu = mean(a["SQ_ACTIVE_INST_VALU"]) / mean(a["SQ_WAVE_CYCLES"]) if a["SQ_WAVE_CYCLES"] else float("nan")
     u24 = busy / 1024.0 / (us * 2400.0) if us else float("nan")
-    lines.append(f"{len(a['us']):8d} {us:8.2f} {busy / 1024.0:10.0f} {u24:8.3f} {util:8.3f} {mean(a['SQ_INSTS_MFMA']):11.4g} {valu:17.3f} {tf:7.0f} {tf / 2500.0:8.3f}  {tag}")
+    lines.append(f"{len(a['us']):8d} {us:8.2f} {busy / 1024.0:10.0f} {u24:8.3f} {util:8.3f} {clk:5.2f} {mean(a['SQ_INSTS_MFMA']):11.4g} {valu:17.3f} {tf:7.0f} {tf / 2500.0:8.3f}  {tag}")
 open(out, "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

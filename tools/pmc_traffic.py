@@ -22,6 +22,7 @@ CYCLES = {  # kernel name prefix -> shape tags in launch order within one block 
     "gemm144l_dma_kernel<1, 6>": ["4096x1152x1152", "4096x1152x1152", "4096x1152x4608"] * 27 + ["4096x1152x1152"] * 2,
     "gemm144l_dma_kernel<1, 7>": ["4096x1152x1152"],
     "gemm288q_dma_kernel<1, 7>": ["4096x3456x1152"],
+    "gemm288q_dma_kernel<1, 7, 32>": ["4096x3456x1152"],     # (rocprofv3 prints the ring's template argument since round 6)
     "gemm288q_dma_kernel<1, 8, 64>": ["4096x4608x1152"],
     "gemm288p_dma_kernel<1, true>": ["4096x4608x1152"],      # (rounds 4 - 5 traces)
     "attn_kernel<1, 5, 3, 0, 0>": ["32x2048x1370x72", "32x2048x2048x72"],
@@ -51,6 +52,12 @@ GRID_B8 = {   # kernel -> {workgroups: shape}
 def tag_of(kname, grid, seen, mode="ddim"):
     """(kernel, shape) tag of one dispatch: `grid` = Grid_Size (threads), `seen` = a Counter of the kernel's earlier dispatches."""
     k = short(kname)
+    if mode == "c5":   # configs[4] per GPU: bf16, N_prim = 4096, batch 4 (effective 8): only the attention launches are tagged
+        if k.startswith("attn_kernel<2,"):
+            t = f"{k} {['128x4096x1370x72', '128x4096x4096x72'][seen[k] % 2]}"
+            seen[k] += 1
+            return t
+        return k
     if mode == "b8":
         if k in GRID_B8:
             return f"{k} {GRID_B8[k].get(grid // 512, str(grid // 512) + ' workgroups')}"
