@@ -2302,7 +2302,7 @@ static void launch288q(const GemmArgs<DT>& x, dim3 grid, hipStream_t st) {
         }
     }
     {
-        PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d>", DT, EPI);
+        PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d, 32>", DT, EPI);
         hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI, 32>), grid, dim3(512), 0, st, PRIMX_GEMM_PASS(x));
     }
 }

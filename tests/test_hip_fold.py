@@ -202,7 +202,7 @@ def test_fold_consumer_to_q(ops, dtype, B, n):
     print(f"to_q {dtype} B={B} n={n}: folded {err:.2e}, unfolded {err_unfolded:.2e}")
     assert err < 2 * TOL[dtype] and err < 1.5 * err_unfolded + 1e-4
     if _default_dispatch():
-        assert names[0].startswith("gemm288q_dma_kernel<" if B * n >= 10240 else "gemm144l_dma_kernel<") and names[0].endswith(", 7>"), names
+        assert names[0].startswith("gemm288q_dma_kernel<" if B * n >= 10240 else "gemm144l_dma_kernel<") and names[0].endswith((", 7>", ", 7, 32>")), names
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -233,7 +233,7 @@ def test_fold_consumer_qkv(ops, dtype):
     # the operand-level mask / denominator markers of the layouts survive (include/primx_hip.h)
     assert float(bufs[2][:, :, dh].float().sum()) == B * H * n
     if _default_dispatch():
-        assert names[0].startswith("gemm288q_dma_kernel<") and names[0].endswith(", 7>")
+        assert names[0].startswith("gemm288q_dma_kernel<") and names[0].endswith(", 7, 32>")
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

@@ -246,7 +246,7 @@ def test_large_batch_dense_epilogues_take_the_128_byte_ring(ops):
     code = ("import sys, torch; sys.path.insert(0, %r); import topia_xl_amd; from topia_xl_amd import ops, _lib\n"
             "g = torch.Generator(device='cpu').manual_seed(5); T, D = 8192, 1152\n"
             "A = torch.randn(T, D, generator=g).cuda().half(); W = (torch.randn(4 * D, D, generator=g) * D ** -0.5).cuda().half(); b = torch.randn(4 * D, generator=g).cuda().half()\n"
-            "o = ops.linear(A, W, b, act=1); assert _lib.load().primx_last_gemm_kernel().decode() == 'gemm288q_dma_kernel<1, 0>'\n"
+            "o = ops.linear(A, W, b, act=1); assert _lib.load().primx_last_gemm_kernel().decode() == 'gemm288q_dma_kernel<1, 0, 32>'\n"
             "torch.save(o.cpu(), sys.argv[1])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import tempfile
     with tempfile.TemporaryDirectory() as d:
@@ -288,7 +288,7 @@ def test_reported_kernel_names_of_the_headline_shapes(ops):
     v = ops.alloc_heads(2, H, 2048, dh, _lib.HEADS_VT, f16, DEV, 256)
     ops.linear_heads(A[:, :D].contiguous(), W[:3 * D, :D].contiguous(), b[:3 * D], 2048, H, dh,
                      [_lib.HEADS_ROWS, _lib.HEADS_KROWS, _lib.HEADS_VT], [q, k, v], q.shape[2])
-    assert name() == "gemm288q_dma_kernel<1, 2>"                                           # qkv
+    assert name() == "gemm288q_dma_kernel<1, 2, 32>"                                         # qkv
     # the timing hook tags a launch with exactly that name + the shape
     ops.PROFILE = []
     try:

@@ -35,8 +35,8 @@ CYCLES = {  # kernel name prefix -> shape tags in launch order within one block 
 
 
 # BASELINE configs[2] / [3] per-GPU shape (batch 8, T = 32768 token rows, fp16): every GEMM on the 256 x 288 tile.  The kernels that run several
-# shapes are split by launch order (producers <1, 6, 64>: cproj, proj, fc2 per block) or by grid size (heads consumers <1, 7, 32>: qkv 3072
-# workgroups, to_q 1024; <1, 2, 32>: the batched K / V projection, block 0's to_q)
+# shapes are split by launch order (producers <1, 6, 64>: cproj, proj, fc2 per block) or by grid size (heads consumers <1, 7, 32>: qkv 1536
+# workgroups, to_q 512; <1, 2, 32>: the batched K / V projection, block 0's to_q)
 CYCLES_B8 = {
     "gemm288q_dma_kernel<1, 6, 64>": ["32768x1152x1152", "32768x1152x1152", "32768x1152x4608"] * 27 + ["32768x1152x1152"] * 2,
     "gemm288q_dma_kernel<1, 1, 64>": ["32768x1152x4608"],
@@ -44,8 +44,8 @@ CYCLES_B8 = {
     "attn_kernel<1, 5, 3, 0, 0>": ["256x2048x1370x72", "256x2048x2048x72"],
 }
 GRID_B8 = {   # kernel -> {workgroups: shape}
-    "gemm288q_dma_kernel<1, 7, 32>": {3072: "32768x3456x1152", 1024: "32768x1152x1152"},
-    "gemm288q_dma_kernel<1, 2, 32>": {1024: "32768x1152x1152", 43008: "12288x64512x768", 21504: "6144x64512x768"},
+    "gemm288q_dma_kernel<1, 7, 32>": {1536: "32768x3456x1152", 512: "32768x1152x1152"},
+    "gemm288q_dma_kernel<1, 2, 32>": {512: "32768x1152x1152", 10752: "12288x64512x768", 21504: "24576x64512x768"},
 }
 
 
