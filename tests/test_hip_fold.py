@@ -117,7 +117,7 @@ def test_fold_producer(ops, dtype, B, n, K):
     ops.linear_gate_residual_fold(A.to(DEV), W.to(DEV), b.to(DEV), modd[:, :D], x_fold, n, modd[:, D:2 * D], c.to(DEV), a16, part)
     if _default_dispatch():
         want_kernel = "gemm288q_dma_kernel<" if M >= 14336 else "gemm144l_dma_kernel<"
-        assert _last_kernel(ops).startswith(want_kernel) and _last_kernel(ops).endswith(", 6>"), _last_kernel(ops)
+        assert _last_kernel(ops).startswith(want_kernel) and _last_kernel(ops).endswith((", 6>", ", 6, 32>", ", 6, 64>")), _last_kernel(ops)
         assert torch.equal(x_fold, x_plain)
     else:
         assert rel_l2(x_fold, x_plain) < 1e-5
@@ -378,8 +378,9 @@ def test_dit_with_the_fold_against_the_unfolded_path_and_the_oracle(ops, dtype, 
                            and os.environ.get("PRIMX_DIT_LN_TAIL") != "1")               # the final layer's LayerNorm runs inside the last GEMM
     if launch_list_applies:
         assert len(ln_calls) == 2 * 4, len(ln_calls)                       # the first LayerNorm and the final layer's, per forward
-        assert sum(1 for nm in names if ", 6> " in nm) == 4 * (3 * 3 - 1), names   # producers: every gated add but the last
-        assert sum(1 for nm in names if ", 7> " in nm) == 4 * (2 * 3 - 1)          # to_q (blocks 1, 2) + qkv
+        epi = lambda nm: nm.split("<")[1].split(">")[0].split(", ")[1] if "<" in nm else ""      # the epilogue template argument of a GEMM tag
+        assert sum(1 for nm in names if epi(nm) == "6") == 4 * (3 * 3 - 1), names   # producers: every gated add but the last
+        assert sum(1 for nm in names if epi(nm) == "7") == 4 * (2 * 3 - 1)          # to_q (blocks 1, 2) + qkv
         assert sum(1 for nm in names if nm.startswith("gemm288q_dma_kernel") and ", 8, 64>" in nm) == 4 * 3
     # one planned forward against the fp32 oracle
     t = torch.tensor([520])
