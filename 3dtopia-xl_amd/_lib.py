@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PRIMX_LIB") or os.path.join(_HERE, "csrc", "libprimx_
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
 HEADS_ROWS, HEADS_VT, HEADS_KROWS = 0, 1, 2
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -34,7 +34,8 @@ class DitForwardFold(C.Structure):
     _fields_ = [(n, _i) for n in ("dtype", "Be", "N", "D", "H", "dh", "hidden", "depth", "L", "nq_pad", "nkv_pad_c", "nkv_pad_b",
                                   "b_from", "step", "n_steps")] + \
                [("ln_eps", _f), ("scale", _f)] + \
-               [(n, _p) for n in ("h", "xn", "att", "hid", "Qc", "Qs", "Ks", "Vs", "mod", "center0", "center1", "part")]
+               [(n, _p) for n in ("h", "xn", "att", "hid", "Qc", "Qs", "Ks", "Vs", "mod", "center0", "center1", "part")] + \
+               [(n, _p) for n in ("kv_A", "kv_W", "kv_bias")] + [(n, _i) for n in ("kv_rows", "kv_rows_per_batch", "kv_K")]   # ABI 25
 
 
 # name -> argument ctypes (return type is always int unless listed in _RESTYPES)
@@ -64,6 +65,8 @@ SIGNATURES = {
     "primx_linear_gate_residual_fold": [_p, _p, _p, _p, _l, _p, _i, _i, _i, _i, _p, _l, _p, _p, _p, _i, _p, _l, _p],
     "primx_linear_heads_fold": [_p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _f, _p, _p, _p, _p, _p, _f,
                                 _i, _p, _l, _p],
+    "primx_linear_heads_fold_pair": [_p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _f, _p, _p, _p, _p, _p, _f,
+                                     _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _f, _i, _p],
     "primx_linear_fold": [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _i, _p, _l, _p],
     "primx_linear_heads": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _i, _i, _f, _i, _p, _l, _p],
     "primx_attention": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
@@ -98,12 +101,14 @@ _RESTYPES = {"primx_last_error": C.c_char_p, "primx_last_gemm_kernel": C.c_char_
 # versions 22 / 23 only added / re-typed the LayerNorm-fold entry points, so a version-21 or -22 build can stand in as long as
 # nothing folds: the fold prototypes are not bound to such a build and `fold_available()` is False (ops.fold_shapes_ok asks);
 # version 24 added primx_dit_blocks_fold (one foreign call for a forward's blocks): a version-23 build lacks only that one, and the
-# host then issues the launches itself (`blocks_call_available()`)
+# host then issues the launches itself (`blocks_call_available()`); version 25 added primx_linear_heads_fold_pair and the kv_* tail of
+# PrimxDitForwardFold (a version-24 build ignores the tail: the host then projects K / V itself, `kv_ride_available()`)
 _FOLD_ENTRY_POINTS: set = {"primx_linear_f32out", "primx_row_stats", "primx_linear_gate_residual_fold", "primx_linear_heads_fold",
                            "primx_linear_fold"}
-_AB_ABI_VERSIONS: tuple = (21, 22, 23)
+_AB_ABI_VERSIONS: tuple = (21, 22, 23, 24)
 _fold_available: dict = {}
 _blocks_call: dict = {}
+_kv_ride: dict = {}
 
 _lib: Optional[C.CDLL] = None
 
@@ -149,11 +154,14 @@ def load(path: Optional[str] = None) -> C.CDLL:
             continue                # an older A/B build: its fold entry points (if any) have other argument lists
         if got < 24 and name == "primx_dit_blocks_fold":
             continue
+        if got < 25 and name == "primx_linear_heads_fold_pair":
+            continue
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     _fold_available[path] = got >= 23
     _blocks_call[path] = got >= 24
+    _kv_ride[path] = got >= 25
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -169,6 +177,12 @@ def blocks_call_available() -> bool:
     """Does the loaded library carry primx_dit_blocks_fold (ABI 24)?"""
     load()
     return _blocks_call.get(LIB_PATH, False)
+
+
+def kv_ride_available() -> bool:
+    """Does the loaded library's primx_dit_blocks_fold project the conditioning K / V itself (ABI 25: riders on the qkv launches)?"""
+    load()
+    return _kv_ride.get(LIB_PATH, False)
 
 
 def check(status: int, name: str) -> None:

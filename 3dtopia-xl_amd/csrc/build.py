@@ -21,7 +21,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["rowops.hip", "gemm.hip", "attention.hip", "vae.hip", "primsdf.hip", "raymarch.hip", "fp32.hip", "conv3.hip", "conv3s8.hip", "conv3s8c32.hip", "convt.hip", "dit_host.hip"]
-HEADERS = ["common.h", "ln_row.h", os.path.join("..", "..", "include", "primx_hip.h")]
+HEADERS = ["common.h", "ln_row.h", "gemm288q_body.inc", os.path.join("..", "..", "include", "primx_hip.h")]
 LIB = os.path.join(HERE, "libprimx_hip.so")
 MANIFEST = os.path.join(HERE, "build_manifest.json")
 # -amdgpu-kernarg-preload-count: the leading scalar kernel arguments arrive in SGPRs at wave launch instead of through an s_load of

@@ -1,4 +1,4 @@
-// primx_dit_blocks_fold (ABI 24): the DiT blocks of one planned, folded forward issued from ONE foreign call.  Host code only: it
+// primx_dit_blocks_fold (ABI 24; the K / V projection riding on the qkv launches: ABI 25): the DiT blocks of one planned, folded forward issued from ONE foreign call.  Host code only: it
 // calls the library's own entry points in the order and with the arguments DiT._forward16 (3dtopia-xl_amd/dit.py) issues them, so
 // the kernels, their launch shapes and the results are the same - what changes is the host's cost per DDIM step (231 Python +
 // ctypes calls of ~21 us -> ~10: DESIGN.md section 8, tools/host_bound_check.py).
@@ -41,6 +41,25 @@ extern "C" int primx_dit_blocks_fold(const PrimxDitForwardFold* f, const PrimxDi
         rc = (x);                  \
         if (rc != PRIMX_OK) return rc; \
     } while (0)
+    // ABI 25: the to_k / to_v projection of the conditioning tokens (attention.py:106-107) issued from here - block 0's as a launch of its
+    // own, block i + 1's on the CUs block i's qkv launch leaves idle (primx_linear_heads_fold_pair)
+    const int kkv[2] = {PRIMX_HEADS_KROWS, PRIMX_HEADS_VT};
+    if (f->kv_A) {
+        if (!f->kv_W || f->kv_rows <= 0 || f->kv_rows_per_batch <= 0 || f->kv_rows % f->kv_rows_per_batch || f->kv_K <= 0)
+            PRIMX_FAIL("primx_dit_blocks_fold: bad K / V projection (rows %d, rows per batch entry %d, K %d)", f->kv_rows, f->kv_rows_per_batch, f->kv_K);
+        for (int i = 0; i < f->depth; ++i)
+            if (!blocks[i].Kc || !blocks[i].Vc) PRIMX_FAIL("primx_dit_blocks_fold: block %d: null K / V destination", i);
+    }
+    const char* const kvW = static_cast<const char*>(f->kv_W);
+    const char* const kvB = static_cast<const char*>(f->kv_bias);
+#define PRIMX_DIT_KV(i)                                                                                                                      \
+    f->kv_A, kvW + (int64_t)(i) * 2 * D * f->kv_K * 2, kvB ? kvB + (int64_t)(i) * 2 * D * 2 : nullptr, f->kv_rows, 2 * D, f->kv_K,         \
+        f->kv_rows_per_batch, H, dh, 2, kkv, kvdst, f->nkv_pad_c, 1.0f
+    if (f->kv_A) {
+        void* const kvdst[2] = {const_cast<void*>(blocks[0].Kc), const_cast<void*>(blocks[0].Vc)};
+        PRIMX_DIT_CALL(primx_linear_heads_fold_pair(nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr, nullptr,
+                                                    nullptr, 0.f, PRIMX_DIT_KV(0), dt, stream));
+    }
     for (int i = 0; i < f->depth; ++i) {
         const PrimxDitBlockFold& b = blocks[i];
         if (!b.w_q || !b.w_cproj || !b.w_qkv || !b.w_proj || !b.w_fc1 || !b.w_fc2 || !b.uv_qkv || !b.uv_fc1 || (i > 0 && !b.uv_q))
@@ -74,8 +93,14 @@ extern "C" int primx_dit_blocks_fold(const PrimxDitForwardFold* f, const PrimxDi
                                                        f->part, dt, b.carry_cproj, b.carry_cproj_bytes, stream));
         // ---- self-attention over the primitive tokens (dit_crossattn.py:56, attention.py:48-59)
         uv(b.uv_qkv, 3 * D, u, v);
-        PRIMX_DIT_CALL(primx_linear_heads_fold(f->xn, b.w_qkv, T, 3 * D, D, N, H, dh, 3, kqkv, dqkv, f->nq_pad, 1.0f, f->part, u, v, center[side],
-                                               center[side ^ 1], f->ln_eps, dt, nullptr, 0, stream));
+        if (f->kv_A && i + 1 < f->depth) {
+            void* const kvdst[2] = {const_cast<void*>(blocks[i + 1].Kc), const_cast<void*>(blocks[i + 1].Vc)};
+            PRIMX_DIT_CALL(primx_linear_heads_fold_pair(f->xn, b.w_qkv, T, 3 * D, D, N, H, dh, 3, kqkv, dqkv, f->nq_pad, 1.0f, f->part, u, v,
+                                                        center[side], center[side ^ 1], f->ln_eps, PRIMX_DIT_KV(i + 1), dt, stream));
+        } else {
+            PRIMX_DIT_CALL(primx_linear_heads_fold(f->xn, b.w_qkv, T, 3 * D, D, N, H, dh, 3, kqkv, dqkv, f->nq_pad, 1.0f, f->part, u, v, center[side],
+                                                   center[side ^ 1], f->ln_eps, dt, nullptr, 0, stream));
+        }
         side ^= 1;
         PRIMX_DIT_CALL(primx_attention(f->Qs, f->Ks, f->Vs, f->att, Be, H, N, f->nq_pad, N, f->nq_pad, dh, f->scale, dt, stream));
         PRIMX_DIT_CALL(primx_linear_gate_residual_fold(f->att, b.w_proj, b.b_proj, ch(i, 5), 0, f->h, T, D, D, N, ch(i, 7), 0, center[side], f->xn,
@@ -93,6 +118,7 @@ extern "C" int primx_dit_blocks_fold(const PrimxDitForwardFold* f, const PrimxDi
                                                          ch(f->depth, 1), 0, f->xn, f->ln_eps, nullptr, 0, dt, nullptr, 0, stream));
         }
     }
+#undef PRIMX_DIT_KV
 #undef PRIMX_DIT_CALL
     return PRIMX_OK;
 }

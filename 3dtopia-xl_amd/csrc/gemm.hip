@@ -1565,599 +1565,43 @@ __global__ __launch_bounds__(640) void gemm144l_dma_kernel(PRIMX_GEMM_PARAMS(DT)
 // rows of 64 halves with the 128 x 144 kernels' chunk swizzle on the source address), ONE barrier per tile, placed two MFMA groups into
 // the tile's second half - "everybody has read tile t, tile t + 1 has landed" - behind which tile t + 2 is requested into tile t's stage
 // between the remaining MFMA groups; the first half of every tile runs without any barrier.
+// LDS halves of one body (ring / heads staging area + the fold consumer's statistics): the __global__ wrappers own the block
+template <int EPI, int KT>
+constexpr int gemm288q_lds_halves() {
+    constexpr int BM = 256, BN = 288, NST = KT == 64 ? 2 : 4, STAGE = (BM + BN) * KT, RS_ROWS = BN + 16, RS_VT = BM + 16;
+    constexpr bool HEADS = EPI == EPI_HEADS || EPI == EPI_HEADS_FOLD, FOLD_C = EPI == EPI_HEADS_FOLD || EPI == EPI_LINEAR_FOLD;
+    constexpr int STG = HEADS ? ((BM * RS_ROWS > BN * RS_VT) ? BM * RS_ROWS : BN * RS_VT) : 0;
+    return ((NST * STAGE > STG) ? NST * STAGE : STG) + (FOLD_C ? BM * 4 + 2 * BN * 2 : 0);
+}
+// The kernel's body lives in gemm288q_body.inc (textual include: the pair kernel below instantiates it twice in one kernel)
 template <int DT, int EPI, int KT = 32>
 __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(DT)) {
     PRIMX_GEMM_ARGS(DT);
-    unsigned long long pr0 = 0, pc0 = 0, pc1 = 0, pc2 = 0;   // PRIMX_GEMM_PROF=1 timeline (see g_gemm_prof)
-    if (pl_prof) { pr0 = __builtin_amdgcn_s_memrealtime(); pc0 = __builtin_readcyclecounter(); }
-    using S = typename T16<DT>::S;
-    using V8 = typename T16<DT>::V8;
-    typedef __attribute__((address_space(1))) const void GV;
-    typedef __attribute__((address_space(3))) void LV;
-    static_assert(KT == 32 || KT == 64, "k-tile");
-    constexpr int BM = 256, BN = 288, MI = 4, NI = 9, KS = KT, NST = KT == 64 ? 2 : 4;
-    constexpr int ROWS = BM + BN;            // 544 rows of 64 (KT = 32) / 128 bytes per stage
-    constexpr int STAGE = ROWS * KS;         // halves per stage
-    constexpr int RPI = 512 / KS;            // rows per 1 KiB wave-instruction: 16 / 8
-    constexpr int NINST = ROWS / RPI;        // 34 / 68 wave-instructions per stage
-    constexpr int NSLOT = (NINST + 7) / 8;   // 5 (waves 0,1) / 4;  KT = 64: 9 (waves 0..3) / 8
-    // EPI_HEADS stages the rounded 16-bit tile in LDS after the main loop (row-major [256][304] for the token-major
-    // layouts, transposed [288][272] for PRIMX_HEADS_VT); the strides put the 16 fragment rows of a wave 8 banks apart
-    constexpr int RS_ROWS = BN + 16, RS_VT = BM + 16;
-    constexpr bool HEADS = EPI == EPI_HEADS || EPI == EPI_HEADS_FOLD;
-    constexpr bool FOLD_C = EPI == EPI_HEADS_FOLD || EPI == EPI_LINEAR_FOLD;   // consumer of a folded LayerNorm site (see fold_stats_load)
-    constexpr bool FOLD_P = EPI == EPI_GATE_RESIDUAL_FOLD;         // producer
-    constexpr int STG = HEADS ? ((BM * RS_ROWS > BN * RS_VT) ? BM * RS_ROWS : BN * RS_VT) : 0;
-    constexpr int LDS_HALVES = (NST * STAGE > STG) ? NST * STAGE : STG;
-    constexpr int STAT_HALVES = FOLD_C ? BM * 4 + 2 * BN * 2 : 0;  // behind the staging area: (mu', rho) of the tile's rows, u and v of its columns
-    static_assert((LDS_HALVES + STAT_HALVES) * 2 <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) S smem[LDS_HALVES + STAT_HALVES];
+    __shared__ __attribute__((aligned(16))) typename T16<DT>::S smem[gemm288q_lds_halves<EPI, KT>()];
+    const int bid = blockIdx.x;
+#include "gemm288q_body.inc"
+}
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 15, lg = lane >> 4;
-
-    const int nt = pl_N / BN, mt = (pl_M + BM - 1) / BM;
-    int mi_t, ni_t;
-    if (pl_xcd_gm > 0) {   // packed gm | sr << 8 | sc << 16 (xcd_pack)
-        xcd_tile2d(blockIdx.x, mt, nt, pl_xcd_gm, mi_t, ni_t);
+// Two problems in one launch (round 6): workgroups [0, n0) are the fold-consumer heads GEMM of the leading arguments (qkv of a DiT block:
+// 192 workgroups at T = 4096 = 75 % of the CUs), workgroups [n0, grid) a plain heads GEMM `r` (the to_k / to_v projection of the NEXT
+// block's conditioning tokens, 48 tiles) on CUs the first problem leaves idle.  Same bodies, same tiles, same bits as the two launches.
+// n0 % 8 == 0, so that a rider's id keeps its XCD (id mod 8) for the tile walk.
+template <int DT>
+__global__ __launch_bounds__(512, 2) void gemm288q_pair_kernel(PRIMX_GEMM_PARAMS(DT), int n0, const GemmArgs<DT> r) {
+    constexpr int H0 = gemm288q_lds_halves<EPI_HEADS_FOLD, 32>(), H1 = gemm288q_lds_halves<EPI_HEADS, 32>();
+    __shared__ __attribute__((aligned(16))) typename T16<DT>::S smem[H0 > H1 ? H0 : H1];
+    if ((int)blockIdx.x < n0) {
+        constexpr int EPI = EPI_HEADS_FOLD, KT = 32;
+        PRIMX_GEMM_ARGS(DT);
+        const int bid = blockIdx.x;
+#include "gemm288q_body.inc"
     } else {
-        const int id = xcd_remap(blockIdx.x, nt * mt);
-        mi_t = id / nt;
-        ni_t = id - mi_t * nt;
+        constexpr int EPI = EPI_HEADS, KT = 32;
+        const GemmArgs<DT>& p = r;
+        const typename T16<DT>::S *const pl_A = r.A, *const pl_W = r.W;
+        const int pl_M = r.M, pl_N = r.N, pl_K = r.K, pl_xcd_gm = r.xcd_gm, pl_prof = 0, bid = (int)blockIdx.x - n0;
+#include "gemm288q_body.inc"
     }
-    const int m0 = mi_t * BM, n0 = ni_t * BN;
-
-    // KT = 64: nine requests per tile and wave - 32-bit byte offsets against the (uniform) operand bases instead of 64-bit pointers (the
-    // launcher checks that both operands are smaller than 4 GB); slots 0 .. 3 are A rows for every wave, 4 .. 8 W rows (256 / 8 / 8 = 4)
-    const S* gp[KT == 64 ? 1 : NSLOT];
-    unsigned go[KT == 64 ? NSLOT : 1];
-    constexpr int NA_SLOTS = BM / RPI / 8;
-    if constexpr (KT == 64) {
-#pragma unroll
-        for (int i = 0; i < NSLOT; ++i) {
-            const int t = min(wave + 8 * i, NINST - 1);
-            const int row = RPI * t + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> 1) & 7);   // LDS position (row, 16-byte slot lane & 7) holds chunk slot ^ ((row >> 1) & 7) (lds_off)
-            go[i] = (unsigned)(((i < NA_SLOTS ? (int64_t)min(m0 + row, pl_M - 1) : (int64_t)(n0 + row - BM)) * pl_K + c * 8) * 2);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < NSLOT; ++i) {
-            const int t = min(wave + 8 * i, NINST - 1);
-            const int row = 16 * t + (lane >> 2);
-            const int c = (lane & 3) ^ (((row >> 3) & 1) << 1);
-            gp[i] = (row < BM) ? pl_A + (int64_t)min(m0 + row, pl_M - 1) * pl_K + c * 8
-                               : pl_W + (int64_t)(n0 + row - BM) * pl_K + c * 8;
-        }
-    }
-    const bool last_slot = wave + 8 * (NSLOT - 1) < NINST;  // wave-uniform (waves 0,1; KT = 64: waves 0..3)
-    auto issue_one = [&](int ks, int stage, int i) {        // slot i of this wave for k-slice ks
-        // (non-temporal policy on the weight rows - do the streamed weights flush the Infinity Cache? - measured in round 3: every
-        // GEMM slower, the step 9.05 -> 10.16 ms; the 16 - 32 workgroups of an XCD that share a weight panel then miss in L2)
-        if (i < NSLOT - 1 || last_slot) {
-            if constexpr (KT == 64)
-                __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(reinterpret_cast<const char*>((i < NA_SLOTS ? pl_A : pl_W) + ks * KS) + go[i]),
-                                                 (LV*)(smem + stage * STAGE + (wave + 8 * i) * 512), 16, 0, 0);
-            else
-                __builtin_amdgcn_global_load_lds((GV*)(uintptr_t)(gp[i] + ks * KS),
-                                                 (LV*)(smem + stage * STAGE + (wave + 8 * i) * 512), 16, 0, 0);
-        }
-    };
-
-    f32x4 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int sw2 = ((lr >> 3) & 1) << 1;
-    // KT = 64: chunk lg of the tile's first half (k 0 .. 31); the second half's chunk 4 + lg sits at `^ 32` halves (the swizzle is an XOR
-    // of the 16-byte slot index, and the fragment rows are 16 apart, so (row >> 1) & 7 depends on lr alone)
-    const int a_off = KT == 64 ? (wm * 64 + lr) * 64 + ((lg ^ ((lr >> 1) & 7)) << 3) : (wm * 64 + lr) * KS + ((lg ^ sw2) << 3);            // + i * 16 rows
-    const int w_off = KT == 64 ? (BM + wn * 144 + lr) * 64 + ((lg ^ ((lr >> 1) & 7)) << 3) : (BM + wn * 144 + lr) * KS + ((lg ^ sw2) << 3);      // + j * 16 rows
-
-    const int nks = pl_K / KS;
-    // fold consumer: the partial sums are requested in front of the first DMAs (vmcnt is in-order) and used behind their issue
-    f32x2* const fstat = reinterpret_cast<f32x2*>(smem + LDS_HALVES);
-    float* const fu = reinterpret_cast<float*>(smem + LDS_HALVES + BM * 4);              // u[288], then v[288]
-    FoldPartials fpart;
-    f32x2 fu2 = {0.f, 0.f}, fv2 = {0.f, 0.f};
-    const int tuv = tid - BM;                                                            // threads 256 .. 399: two columns each
-    if constexpr (FOLD_C) {
-        if (wave < BM / 64) fpart = fold_stats_load<DT>(p, pl_M, m0, tid);
-        else if (tuv < BN / 2) {
-            fu2 = *reinterpret_cast<const f32x2*>(p.fold_u + n0 + 2 * tuv);
-            fv2 = *reinterpret_cast<const f32x2*>(p.fold_v + n0 + 2 * tuv);
-        }
-    }
-#pragma unroll
-    for (int pre = 0; pre < (KT == 64 ? 2 : NST - 1); ++pre)
-#pragma unroll
-        for (int i = 0; i < NSLOT; ++i)
-            if (KT == 32 || pre < nks) issue_one(min(pre, nks - 1), pre, i);
-    if constexpr (FOLD_C) {
-        if (wave < BM / 64) fold_stats_finish<DT>(p, fpart, pl_M, pl_K, m0, tid, ni_t == 0, fstat);
-        else if (tuv < BN / 2) {
-            *reinterpret_cast<f32x2*>(fu + 2 * tuv) = fu2;
-            *reinterpret_cast<f32x2*>(fu + BN + 2 * tuv) = fv2;
-        }
-    }
-    // Fragment prefetch: the A fragments and the first NPF W fragments of slice ks+1 are read while the MFMAs of slice ks
-    // run (they need slice ks+1 to have landed one barrier earlier: "vmcnt(4)" = only slice ks+2 still in flight).
-    constexpr int NPF = 3;
-    V8 a_n[MI], b_n[NPF];
-    if (KT == 64 && nks < 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");     // slice 0 landed (KT = 64: tile 0; tile 1's 8 - 9 requests may be out)
-    if (pl_prof) pc1 = __builtin_readcyclecounter();
-    {
-        const S* base0 = smem;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a_n[i] = *reinterpret_cast<const V8*>(base0 + a_off + i * 16 * KS);
-#pragma unroll
-        for (int j = 0; j < NPF; ++j) b_n[j] = *reinterpret_cast<const V8*>(base0 + w_off + j * 16 * KS);
-    }
-    // Tile-uniform epilogue form of EPI_HEADS: a column tile of a PRIMX_HEADS_VT segment wants 4 consecutive TOKENS per
-    // lane, i.e. the plain operand order (accumulator = C); everything else swaps the operands (accumulator = C^T, 4
-    // consecutive columns per lane).  The main loop exists once per order; the choice is made once per workgroup.
-    bool vt_tile = false;
-    if (HEADS) {
-        const int seg = (n0 / (p.heads * p.dh)) % p.n_seg;
-        vt_tile = (seg == 0 ? p.kind[0] : seg == 1 ? p.kind[1] : p.kind[2]) == PRIMX_HEADS_VT;
-    }
-    auto main_loop = [&](auto swapped) {
-    constexpr bool SW = decltype(swapped)::value;
-    if constexpr (KT == 64) {
-        for (int t = 0; t < nks; ++t) {
-            const S* base = smem + (t & 1) * STAGE;
-            const S* base_n = smem + ((t + 1) & 1) * STAGE;
-            const bool more = t + 2 < nks;                               // (uniform) tile t + 2 exists: it goes into tile t's stage
-            const bool late = t >= 1 && t + 1 < nks;                     // tile t + 1's last four requests (tiles 0 and 1: the prologue)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                V8 a[MI], b[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) a[i] = a_n[i];
-#pragma unroll
-                for (int j = 0; j < NPF; ++j) b[j] = b_n[j];
-#pragma unroll
-                for (int j = NPF; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(base + ((w_off + j * 16 * 64) ^ (h << 5)));
-                // the next half's first fragments: tile t's second half, or tile t + 1's first (other stage: behind the barrier below)
-                const S* nb = h == 0 ? base : base_n;
-                const int nx = h == 0 ? 32 : 0;
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    if (h == 1 && j == 2) {
-                        // every read of tile t has been issued; when this wave's have returned and its requests of tile t + 1 have landed
-                        // it may say so.  Behind the barrier: tile t + 1 is readable, tile t's stage is free.
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    }
-                    // tile t + 2 goes into tile t's stage: five of a wave's nine requests behind the barrier, four more between the first
-                    // MFMA groups of tile t + 1 - the request queue takes 68 x ~29 cycles of a 2304-cycle tile, so the issue is spread over
-                    // the whole period (a wave waits in the queue for every request it issues; bunched behind the barrier the requests cost
-                    // the loop 850 cycles per tile: 3150 measured)
-                    if (h == 1 && more) {
-                        if (j == 2) issue_one(t + 2, t & 1, 0);
-                        else if (j == 3) issue_one(t + 2, t & 1, 1);
-                        else if (j == 5) issue_one(t + 2, t & 1, 2);
-                        else if (j == 6) issue_one(t + 2, t & 1, 3);
-                        else if (j == 8) issue_one(t + 2, t & 1, 4);
-                    }
-                    if (h == 0 && late && j < 4) issue_one(t + 1, (t + 1) & 1, 5 + j);
-#pragma unroll
-                    for (int i = 0; i < MI; ++i)
-                        acc[i][j] = SW ? T16<DT>::mfma16(b[j], a[i], acc[i][j]) : T16<DT>::mfma16(a[i], b[j], acc[i][j]);
-                    if (j == NPF) {
-#pragma unroll
-                        for (int i = 0; i < MI; ++i) a_n[i] = *reinterpret_cast<const V8*>(nb + ((a_off + i * 16 * 64) ^ nx));
-#pragma unroll
-                        for (int jj = 0; jj < NPF; ++jj) b_n[jj] = *reinterpret_cast<const V8*>(nb + ((w_off + jj * 16 * 64) ^ nx));
-                    }
-                }
-            }
-        }
-        return;
-    }
-    int st = 0;
-    for (int ks = 0; ks < nks; ++ks) {
-        // slice ks+2 may stay in flight (4..5 DMAs per wave): <= 4 outstanding means slices ks and ks+1 have landed;
-        // lgkmcnt(0): this wave's reads of slice ks-1 (and its prefetch of slice ks) are done
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const S* base = smem + st * STAGE;
-        const int st_next = (st == NST - 1) ? 0 : st + 1;
-        const S* base_n = smem + st_next * STAGE;
-        const int st_fill = (st == 0) ? NST - 1 : st - 1;                // stage of slice ks-1
-        const int ks_fill = min(ks + NST - 1, nks - 1);
-        V8 a[MI], b[NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a[i] = a_n[i];
-#pragma unroll
-        for (int j = 0; j < NPF; ++j) b[j] = b_n[j];
-#pragma unroll
-        for (int j = NPF; j < NI; ++j) b[j] = *reinterpret_cast<const V8*>(base + w_off + j * 16 * KS);
-        // operands swapped: accumulator = C^T (see the epilogue); the DMAs of slice ks+3 go out between the MFMA groups
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            if (j < NSLOT) issue_one(ks_fill, st_fill, j);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                acc[i][j] = SW ? T16<DT>::mfma16(b[j], a[i], acc[i][j]) : T16<DT>::mfma16(a[i], b[j], acc[i][j]);
-            if (j == NPF) {   // the prefetched registers are free now: fetch slice ks+1's (clamped reads past the end are unused)
-#pragma unroll
-                for (int i = 0; i < MI; ++i) a_n[i] = *reinterpret_cast<const V8*>(base_n + a_off + i * 16 * KS);
-#pragma unroll
-                for (int jj = 0; jj < NPF; ++jj) b_n[jj] = *reinterpret_cast<const V8*>(base_n + w_off + jj * 16 * KS);
-            }
-        }
-        st = st_next;
-    }
-    };
-    if (HEADS && vt_tile) main_loop(std::false_type{});
-    else main_loop(std::true_type{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (clamped tail DMAs)
-    if (pl_prof) pc2 = __builtin_readcyclecounter();
-    // the launch's carried weight prefetch (gemm_prefetch_lines_tail): the epilogues that load nothing from global memory
-    // (vmcnt is one in-order queue: whatever an epilogue loads must be requested BEFORE these lines, or its wait includes their trip from
-    //  HBM - the fold consumers load nothing, EPI_LINEAR asks behind its bias vector; the other epilogues ignore the range)
-    constexpr bool PF_TAIL = EPI == EPI_HEADS_FOLD || EPI == EPI_LINEAR || EPI == EPI_LINEAR_FOLD;
-    pf_u32x2 pf_v = {0u, 0u};
-    if constexpr (EPI == EPI_HEADS_FOLD || EPI == EPI_LINEAR_FOLD) pf_v = gemm_prefetch_lines_tail<DT>(p, wave, lane);
-    auto prof_end = [&]() {
-        if constexpr (PF_TAIL) asm volatile("" ::"v"(pf_v[0]), "v"(pf_v[1]));   // (the requests have returned)
-        if (pl_prof) {
-            __builtin_amdgcn_s_waitcnt(0);   // the epilogue's stores have been issued AND acknowledged
-            const unsigned long long pc3 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
-            if (tid == 0) {
-                atomicMin(&g_gemm_prof[0], pr0); atomicMax(&g_gemm_prof[1], pr1);
-                atomicAdd(&g_gemm_prof[2], pc1 - pc0); atomicAdd(&g_gemm_prof[3], pc2 - pc1);
-                atomicAdd(&g_gemm_prof[4], pc3 - pc2); atomicAdd(&g_gemm_prof[5], 1ull); atomicAdd(&g_gemm_prof[6], pr0);
-                atomicAdd(&g_gemm_prof[8], pr1 - pr0); atomicAdd(&g_gemm_prof[9], pc3 - pc0);   // -> the shader clock while this kernel runs
-                if (blockIdx.x < 4096) {
-                    unsigned xcc;
-                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                    g_gemm_wg[blockIdx.x][0] = pr0; g_gemm_wg[blockIdx.x][1] = pr1 - pr0; g_gemm_wg[blockIdx.x][2] = pc3 - pc0;
-                    g_gemm_wg[blockIdx.x][3] = ((unsigned long long)(xcc & 15) << 32) | (unsigned)(pc3 - pc2);
-                }
-            }
-        }
-    };
-
-    using V4e = typename T16<DT>::V4;
-    if (HEADS) {
-        // ---- heads epilogue through LDS (host guarantees: per % 288 == 0, 288 % dh == 0, dh % 8 == 0,
-        // rows_per_batch % 256 == 0 - hence M % 256 == 0, no ragged tile - so the tile lies in ONE (repetition, segment,
-        // batch entry) and covers whole heads).
-        // Phase 1 parks bias + rounding (+ scale0) results as 16-bit values; phase 2 walks the tile in DESTINATION order
-        // with 16-byte accesses and almost no live registers (the register-resident scatter spilled at this tile size).
-        const int per = p.heads * p.dh;
-        const int seg_all = n0 / per, rep_i = seg_all / p.n_seg, seg = seg_all - rep_i * p.n_seg;
-        const int hh0 = (n0 - seg_all * per) / p.dh;
-        const int bb = m0 / p.rows_per_batch, tok0 = m0 - bb * p.rows_per_batch;
-        const int kind = seg == 0 ? p.kind[0] : seg == 1 ? p.kind[1] : p.kind[2];
-        S* dst = (seg == 0 ? p.dst[0] : seg == 1 ? p.dst[1] : p.dst[2]) +
-                 rep_i * (seg == 0 ? p.rep_stride[0] : seg == 1 ? p.rep_stride[1] : p.rep_stride[2]);
-        const float sc = (seg == 0) ? p.scale0 : 1.0f;
-        __syncthreads();   // every wave is done with the operand stages
-        if (!vt_tile) {
-            // acc[i][j][r] = C[wm*64 + i*16 + lr][wn*144 + j*16 + 4*lg + r]
-            // (`scaled` is a compile-time flag under a uniform branch: if-converted, the q scale cost every element of
-            // every segment a multiply, two conversions and a select)
-            auto park = [&](auto scaled_t) {
-            constexpr bool scaled = decltype(scaled_t)::value;
-            f32x2 st[FOLD_C ? MI : 1];                   // fold: (mu', rho) of this lane's four rows
-            if constexpr (FOLD_C) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) st[i] = fstat[wm * 64 + i * 16 + lr];
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                V4e bv = V4e{};
-                f32x4 u4 = {0.f, 0.f, 0.f, 0.f}, v4 = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (FOLD_C) {
-                    u4 = *reinterpret_cast<const f32x4*>(fu + wn * 144 + j * 16 + 4 * lg);          // (LDS)
-                    v4 = *reinterpret_cast<const f32x4*>(fu + BN + wn * 144 + j * 16 + 4 * lg);
-                } else if (p.bias) {
-                    bv = *reinterpret_cast<const V4e*>(p.bias + n0 + wn * 144 + j * 16 + 4 * lg);
-                }
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    V4e o;
-                    f32x4 yv;
-                    if constexpr (FOLD_C) {
-                        yv = fold_apply(acc[i][j], st[i], u4, v4);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) yv[r] = acc[i][j][r] + (float)bv[r];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = scaled ? (S)(sc * rnd16<DT>(yv[r])) : (S)yv[r];
-                    *reinterpret_cast<V4e*>(smem + (wm * 64 + i * 16 + lr) * RS_ROWS + wn * 144 + j * 16 + 4 * lg) = o;
-                }
-            }
-            };
-            if (sc != 1.0f) { asm volatile("" ::: "memory"); park(std::true_type{}); }
-            else park(std::false_type{});
-            __syncthreads();
-            const int rs = heads_row_stride(kind, p.DP);
-#pragma unroll 6
-            for (int it = 0; it < (BM * (BN / 8)) / 512; ++it) {      // 9216 (row, 8-column) units / 512 threads = 18
-                const int u = tid + 512 * it;
-                const int row = u / (BN / 8), c = u - row * (BN / 8);
-                int d = 8 * c, hl = 0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (d >= p.dh) { d -= p.dh; ++hl; }
-                const V8 v = *reinterpret_cast<const V8*>(smem + row * RS_ROWS + 8 * c);
-                out_store(reinterpret_cast<V8*>(dst + (((int64_t)bb * p.heads + hh0 + hl) * p.n_pad + tok0 + row) * rs + d), v);
-            }
-        } else {
-            // acc[i][j][r] = C[wm*64 + i*16 + 4*lg + r][wn*144 + j*16 + lr]  ->  staged transposed [column][token]
-            auto park = [&](auto scaled_t) {
-            constexpr bool scaled = decltype(scaled_t)::value;
-            f32x2 st[FOLD_C ? MI : 1][4];                // fold: (mu', rho) of this lane's sixteen rows
-            if constexpr (FOLD_C) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) st[i][r] = fstat[wm * 64 + i * 16 + 4 * lg + r];
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                float bj = 0.f, uj = 0.f;
-                if constexpr (FOLD_C) {
-                    uj = fu[wn * 144 + j * 16 + lr];                                                 // (LDS)
-                    bj = fu[BN + wn * 144 + j * 16 + lr];
-                } else if (p.bias) {
-                    bj = (float)p.bias[n0 + wn * 144 + j * 16 + lr];
-                }
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    V4e o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float y;
-                        if constexpr (FOLD_C) y = st[i][r][1] * (acc[i][j][r] - st[i][r][0] * uj) + bj;
-                        else y = acc[i][j][r] + bj;
-                        o[r] = scaled ? (S)(sc * rnd16<DT>(y)) : (S)y;
-                    }
-                    *reinterpret_cast<V4e*>(smem + (wn * 144 + j * 16 + lr) * RS_VT + wm * 64 + i * 16 + 4 * lg) = o;
-                }
-            }
-            };
-            if (sc != 1.0f) { asm volatile("" ::: "memory"); park(std::true_type{}); }
-            else park(std::false_type{});
-            __syncthreads();
-#pragma unroll 3
-            for (int it = 0; it < (BN * (BM / 16)) / 512; ++it) {     // 4608 (column, 16-token) units / 512 threads = 9
-                const int u = tid + 512 * it;
-                const int col = u >> 4, g = u & 15;
-                int d = col, hl = 0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (d >= p.dh) { d -= p.dh; ++hl; }
-                const V8 lo = *reinterpret_cast<const V8*>(smem + col * RS_VT + 16 * g);
-                const V8 hi = *reinterpret_cast<const V8*>(smem + col * RS_VT + 16 * g + 8);
-                // vt_key_pos: the 4-key quads of a group of 16 are stored in the order {0, 2, 1, 3}
-                const V8 o0 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                const V8 o1 = {lo[4], lo[5], lo[6], lo[7], hi[4], hi[5], hi[6], hi[7]};
-                S* rowp = dst + (((int64_t)bb * p.heads + hh0 + hl) * p.DP + d) * p.n_pad + tok0 + 16 * g;
-                out_store(reinterpret_cast<V8*>(rowp), o0);
-                out_store(reinterpret_cast<V8*>(rowp + 8), o1);
-            }
-        }
-        prof_end();
-        return;
-    }
-
-    // (EPI_LINEAR through the same LDS staging as EPI_HEADS - 16-byte stores, 576 contiguous bytes per row - measured
-    // WORSE than the register form below at fc1: epilogue 33.4k -> 40.1k cycles per tile.  The 33k are the 37.7 MB write
-    // burst of 256 workgroups finishing together (2.1 TB/s), not store issue.)
-    // ---- epilogue from registers: acc[i][j][r] = C[m0 + wm*64 + i*16 + lr][n0 + wn*144 + j*16 + 4*lg + r]
-    const int nb = n0 + wn * 144 + 4 * lg;
-    const bool gelu_fast = p.act == PRIMX_ACT_GELU_TANH && p.out_scale == 1.0f;   // (uniform: one branch per row group, see linear_out4)
-    V4e bpre[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        bpre[j] = V4e{};
-        if (p.bias && EPI != EPI_CONVT && EPI != EPI_LINEAR_FOLD) bpre[j] = *reinterpret_cast<const V4e*>(p.bias + nb + j * 16);
-    }
-    if constexpr (EPI == EPI_LINEAR) pf_v = gemm_prefetch_lines_tail<DT>(p, wave, lane);
-#ifndef PRIMX_PROBE_SKIPSTORE
-    if constexpr (EPI == EPI_GATE_RESIDUAL && KT == 64) {
-        // Round 6: the fp32 read-modify-write of the residual rows as a pipeline.  The epilogue below asks for a row group's 36 + 18
-        // registers of x and gate, waits a full memory round trip, updates, stores, and only then asks for the next group: four exposed
-        // round trips, 30 - 37k cycles per tile.  Here two row groups are always on their way: the accumulators are rounded to their
-        // 16-bit values rnd16(acc + bias) - the reference's Linear output: what the gate multiplies is a 16-bit number - which halves
-        // their registers and pays for the second buffer, and group i + 2 is requested the moment group i has been stored: 26 - 28k
-        // cycles (profiles/r6_kt64_experiments.txt).  Full tiles inside one batch entry only (one gate row, no row clamp): the launcher
-        // sends only M % 256 == 0 && rows_per_batch % 256 == 0 to this instantiation (launch288q).  Same arithmetic, same order:
-        // bit-identical results.  The ORDER of the requests below is the one that fits 256 registers: every other one tried (group 0
-        // requested before the first rounding; both buffers before the second; gate row in LDS) spilled 10 - 40 dwords, and a reload
-        // from scratch waits in the in-order vmcnt queue behind the row group requested in front of it - 71k cycles measured.
-        // The LayerNorm-fold producer (EPI_GATE_RESIDUAL_FOLD: + operand store + partial sums) does not fit two buffers; it keeps the loop.
-        {
-            const S* grow = p.gate + (int64_t)(m0 / p.rows_per_batch) * p.gate_stride + nb;
-            float* xrow0 = p.x + (int64_t)(m0 + wm * 64 + lr) * pl_N + nb;
-            const int64_t gstep = (int64_t)16 * pl_N;          // floats between the row groups of a lane
-            f32x4 xa[NI], xb[NI];
-            auto load_x = [&](f32x4 (&xv)[NI], int i) {
-#pragma unroll
-                for (int j = 0; j < NI; ++j) xv[j] = *reinterpret_cast<const f32x4*>(xrow0 + i * gstep + j * 16);
-            };
-            V4e pk[MI][NI];                                     // rnd16(acc + bias)
-            auto pack = [&](int i) {
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pk[i][j][r] = (S)(acc[i][j][r] + (p.bias ? (float)bpre[j][r] : 0.f));
-            };
-            pack(2);                                            // (first: 72 accumulator registers become 36 before the loads need theirs)
-            pack(3);
-            { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-            load_x(xa, 0);
-            { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-            pack(0);
-            pack(1);
-            { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-            load_x(xb, 1);
-            V4e gv[NI];                                         // (behind the last use of the bias registers)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) gv[j] = *reinterpret_cast<const V4e*>(grow + j * 16);
-            auto update = [&](f32x4 (&xv)[NI], int i) {
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xv[j][r] += rnd16<DT>((float)gv[j][r] * (float)pk[i][j][r]);
-                    out_store(reinterpret_cast<f32x4*>(xrow0 + i * gstep + j * 16), xv[j]);
-                }
-            };
-            update(xa, 0);
-            { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-            load_x(xa, 2);
-            { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-            update(xb, 1);
-            { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-            load_x(xb, 3);
-            { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-            update(xa, 2);
-            update(xb, 3);
-            prof_end();
-            return;
-        }
-    }
-#endif
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + lr;
-#ifdef PRIMX_PROBE_SKIPSTORE   // measurement builds only: 1 = odd tile columns store nothing, 2 = nobody stores (results invalid)
-        const bool ok = m < pl_M && !(PRIMX_PROBE_SKIPSTORE == 2 || (PRIMX_PROBE_SKIPSTORE == 1 && (ni_t & 1)));
-#else
-        const bool ok = m < pl_M;
-#endif
-#if defined(PRIMX_PROBE_SKIPSTORE) && PRIMX_PROBE_SKIPSTORE == 3   // every tile stores (and updates) rows 0 .. 255: the epilogue's instructions without its HBM traffic
-        const int mc = m & 255;
-#else
-        const int mc = ok ? m : pl_M - 1;
-#endif
-        if (EPI == EPI_GATE_RESIDUAL || FOLD_P) {
-            const S* grow = p.gate + (int64_t)(mc / p.rows_per_batch) * p.gate_stride + nb;
-            float* xrow = p.x + (int64_t)mc * pl_N + nb;
-            V4e gv[NI];
-            f32x4 xv[NI];
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                gv[j] = *reinterpret_cast<const V4e*>(grow + j * 16);
-                xv[j] = *reinterpret_cast<const f32x4*>(xrow + j * 16);
-            }
-            if constexpr (FOLD_P) {
-                // the producer of the LayerNorm site behind this GEMM (see fold_stats_load): a lane owns 36 of its row's columns in
-                // this wave's 144-column half; the four lanes of a row meet by shuffle, so the half IS one 144-column partial sum
-                const f32x2 cr = reinterpret_cast<const f32x2*>(p.fold_c)[mc];
-                const S* srow = p.ln_scale + (int64_t)(mc / p.rows_per_batch) * p.ln_mod_stride + nb;
-                S* arow = p.ln_out + (int64_t)mc * pl_N + n0 + wn * 144;
-                float s1 = 0.f, s2 = 0.f;
-                auto unit = [&](int j) -> V4e {            // residual update of four columns (stored), their operand values (returned)
-                    const V4e sv = *reinterpret_cast<const V4e*>(srow + j * 16);
-                    V4e o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        xv[j][r] += rnd16<DT>((float)gv[j][r] * rnd16<DT>(acc[i][j][r] + (p.bias ? (float)bpre[j][r] : 0.f)));
-                        const float d = xv[j][r] - cr[0];
-                        s1 += d;
-                        s2 = __builtin_fmaf(d, d, s2);
-                        o[r] = (S)((d * cr[1]) * rnd16<DT>(1.0f + (float)sv[r]));
-                    }
-                    if (ok) out_store(reinterpret_cast<f32x4*>(xrow + j * 16), xv[j]);
-                    return o;
-                };
-                // 16-bit operand: 16-byte stores - the lane groups of a row trade halves of neighbouring tiles (see EPI_LINEAR below);
-                // 8-byte stores of 32-byte row pieces left the batch-8 step where it was (61.1 vs 61.3 ms unfolded)
-                typedef unsigned int u32;
-#pragma unroll
-                for (int j = 0; j + 1 < NI; j += 2) {
-                    const u32x2 a = __builtin_bit_cast(u32x2, unit(j));
-                    const u32x2 b = __builtin_bit_cast(u32x2, unit(j + 1));
-                    const auto t0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-                    const auto t1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-                    const u32x4 o = {(u32)t0[0], (u32)t1[0], (u32)t0[1], (u32)t1[1]};
-                    if (ok) out_store(reinterpret_cast<u32x4*>(arow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
-                }
-                {
-                    const V4e o = unit(NI - 1);
-                    if (ok) out_store(reinterpret_cast<V4e*>(arow + (NI - 1) * 16 + 4 * lg), o);
-                }
-                s1 += __shfl_xor(s1, 16);                 // lanes lr + 16 lg: (lg0 + lg1) + (lg2 + lg3), the same in all four
-                s2 += __shfl_xor(s2, 16);
-                s1 += __shfl_xor(s1, 32);
-                s2 += __shfl_xor(s2, 32);
-                if (ok && lg == 0)
-                    *reinterpret_cast<f32x2*>(p.fold_part + ((int64_t)m * (pl_N / 144) + ni_t * 2 + wn) * 2) = f32x2{s1, s2};
-            } else {
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    xv[j][r] += rnd16<DT>((float)gv[j][r] * rnd16<DT>(acc[i][j][r] + (p.bias ? (float)bpre[j][r] : 0.f)));
-                if (ok) out_store(reinterpret_cast<f32x4*>(xrow + j * 16), xv[j]);
-            }
-            }
-        } else if (EPI == EPI_LINEAR_FOLD) {
-            // (statistics and u / v from LDS, 16-byte stores by permlane swap)
-            typedef unsigned int u32;
-            S* orow = p.out + (int64_t)mc * pl_N + n0 + wn * 144;
-            const f32x2 fst = fstat[wm * 64 + i * 16 + lr];
-            const float* up = fu + wn * 144 + 4 * lg;
-            const float* vp = fu + BN + wn * 144 + 4 * lg;
-            auto rows = [&](auto gelu) {
-                auto out4 = [&](int j) -> V4e {
-                    return fold_out4<DT, decltype(gelu)::value>(p, fold_apply(acc[i][j], fst, *reinterpret_cast<const f32x4*>(up + j * 16),
-                                                                              *reinterpret_cast<const f32x4*>(vp + j * 16)));
-                };
-#pragma unroll
-                for (int j = 0; j + 1 < NI; j += 2) {
-                    const u32x2 a = __builtin_bit_cast(u32x2, out4(j));
-                    const u32x2 b = __builtin_bit_cast(u32x2, out4(j + 1));
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-                    const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
-                    if (ok) out_store(reinterpret_cast<u32x4*>(orow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
-                }
-                if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), out4(NI - 1));
-            };
-            if (gelu_fast) rows(BoolC<true>{}); else rows(BoolC<false>{});
-        } else if (EPI == EPI_LINEAR) {
-            // 16-bit outputs.  Stored straight from the accumulator layout a lane writes 8 bytes and an instruction touches 16 rows
-            // x 32 bytes; the store path of a CU then needs ~21k cycles for the tile's 147 KB (tools/probe/write_burst.hip: "fc1
-            // regs 8B") - MORE than the GELU arithmetic, so the fc1 epilogue was bound by its store REQUESTS.  One
-            // v_permlane16_swap per dword makes the lane groups of a row trade halves of two neighbouring 16-column tiles: lane
-            // group g then owns 8 consecutive columns of tile j + (g & 1) - 16 bytes per lane, 64 bytes per row and instruction,
-            // half the instructions (probe "fc1 regs 16B": 12k cycles).  The ninth tile has no partner and keeps the 8-byte form.
-            typedef unsigned int u32;
-            S* orow = p.out + (int64_t)mc * pl_N + n0 + wn * 144;
-            auto rows = [&](auto gelu) {
-                constexpr bool G = decltype(gelu)::value;
-#pragma unroll
-                for (int j = 0; j + 1 < NI; j += 2) {
-                    const u32x2 a = __builtin_bit_cast(u32x2, linear_out4<DT, G>(p, acc[i][j], bpre[j]));
-                    const u32x2 b = __builtin_bit_cast(u32x2, linear_out4<DT, G>(p, acc[i][j + 1], bpre[j + 1]));
-                    // odd 16-lane rows of the first operand <-> even rows of the second: (g1, g3)'s tile-j halves go to (g0, g2), their
-                    // tile-(j+1) halves come back
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-                    const u32x4 o = {(u32)s0[0], (u32)s1[0], (u32)s0[1], (u32)s1[1]};
-                    if (ok) out_store(reinterpret_cast<u32x4*>(orow + (j + (lg & 1)) * 16 + 8 * (lg >> 1)), o);
-                }
-                if (ok) out_store(reinterpret_cast<V4e*>(orow + (NI - 1) * 16 + 4 * lg), linear_out4<DT, G>(p, acc[i][NI - 1], bpre[NI - 1]));
-            };
-            if (gelu_fast) rows(BoolC<true>{}); else rows(BoolC<false>{});
-        } else {
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-                if (ok) epilogue_row4<DT, EPI>(p, m, nb + j * 16, acc[i][j], bpre[j]);
-        }
-    }
-    prof_end();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2307,26 +1751,32 @@ static void launch288q(const GemmArgs<DT>& x, dim3 grid, hipStream_t st) {
     }
 }
 
+// XCD block shape of a 256 x 288 launch (packed for xcd_tile2d; 0 = whole tile rows per XCD): minimise (A bytes x column groups + W bytes
+// x row groups) over the splits the tile grid allows
+template <int DT>
+static int big_xcd_gm(const GemmArgs<DT>& a, bool heads) {
+    if (!g_xcd2d) return a.xcd_gm;
+    const int mtb = (a.M + 255) / 256, ntb = a.N / 288;
+    double best = 1e300;
+    int g = a.xcd_gm;
+    for (int gm = 1; gm <= 8; gm *= 2) {
+        const int gn = 8 / gm;
+        if (mtb % gm || ntb % gn) continue;
+        const double cost = (double)a.M * gn + (double)a.N * gm;      // x K x 2 bytes each
+        if (cost < best) { best = cost; g = gm; }
+    }
+    // (the heads epilogue keeps the row-major walk: the batched K / V projection measured 210 vs 217 us with sub-blocks - its rounds
+    // are bound by the two-layout scatter of the tile, not by operand traffic - while the dense-output GEMMs of a large batch
+    // gain: fc1 at T = 32768 440 -> 410 us, the batch-8 step 61.25 -> 60.86 ms)
+    return g > 0 ? xcd_pack(g, mtb, ntb, heads) : g;
+}
+
 template <int DT, int EPI, int BIG = 0>
 void launch144_dma(const GemmArgs<DT>& a, int mt, hipStream_t st) {
     const dim3 grid(BIG ? ((a.M + 255) / 256) * (a.N / 288) : mt * (a.N / 144));
     GemmArgs<DT> a2 = a;
     a2.ln_light = g_ln_mode;
-    if (BIG && g_xcd2d) {
-        // XCD block shape: minimise (A bytes x column groups + W bytes x row groups) over the splits the tile grid allows
-        const int mtb = (a.M + 255) / 256, ntb = a.N / 288;
-        double best = 1e300;
-        for (int gm = 1; gm <= 8; gm *= 2) {
-            const int gn = 8 / gm;
-            if (mtb % gm || ntb % gn) continue;
-            const double cost = (double)a.M * gn + (double)a.N * gm;      // x K x 2 bytes each
-            if (cost < best) { best = cost; a2.xcd_gm = gm; }
-        }
-        // (the heads epilogue keeps the row-major walk: the batched K / V projection measured 210 vs 217 us with sub-blocks - its rounds
-        // are bound by the two-layout scatter of the tile, not by operand traffic - while the dense-output GEMMs of a large batch
-        // gain: fc1 at T = 32768 440 -> 410 us, the batch-8 step 61.25 -> 60.86 ms)
-        if (a2.xcd_gm > 0) a2.xcd_gm = xcd_pack(a2.xcd_gm, mtb, ntb, EPI == EPI_HEADS || EPI == EPI_HEADS_FOLD);
-    }
+    if (BIG) a2.xcd_gm = big_xcd_gm<DT>(a, EPI == EPI_HEADS || EPI == EPI_HEADS_FOLD);
     constexpr bool FOLD_EPI = EPI == EPI_GATE_RESIDUAL_FOLD || EPI == EPI_HEADS_FOLD || EPI == EPI_LINEAR_FOLD;
     // loader-wave kernel: the row-major epilogues (heads: token-major segments whose tiles stay inside one segment)
     bool loader_ok = !BIG && (EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_GATE_RESIDUAL_FOLD || EPI == EPI_LINEAR_FOLD);
@@ -2809,6 +2259,96 @@ extern "C" int primx_linear_heads_fold(const void* A, const void* W, int M, int 
         a.fold_part = const_cast<float*>(part); a.fold_parts = K / 144; a.fold_u = u; a.fold_v = v; a.fold_c = center; a.fold_c_out = center_out; a.fold_eps = eps;
         if (int rc = set_prefetch<DT>(a, prefetch, prefetch_bytes, name)) return rc;
         return launch_fold<DT, EPI_HEADS_FOLD>(a, (hipStream_t)stream, name);
+    });
+    return PRIMX_OK;
+}
+
+// Does a heads problem map onto the 256 x 288 tile's LDS-staged scatter epilogue (the shape rule of launch<> / launch_fold, without their
+// workgroup-count thresholds)?
+template <int DT>
+static bool big_heads_shape(const GemmArgs<DT>& a) {
+    const int per = a.heads * a.dh;
+    return !g_no_big && g_big_heads_min > 0 && a.heads > 0 && a.N % 288 == 0 && per % 288 == 0 && 288 % a.dh == 0 && a.dh % 8 == 0 &&
+           a.dh >= 32 && a.rows_per_batch % 256 == 0 && a.M % 256 == 0 && a.K % BK == 0;
+}
+
+// primx_linear_heads_fold (problem 0, no carried prefetch) and primx_linear_heads (problem 1: n_rep = 1, no carried prefetch) from ONE
+// launch: problem 1's tiles run on the CUs problem 0's single round of 256 x 288 tiles leaves idle (gemm288q_pair_kernel).  A == NULL:
+// problem 1 alone, on the same tile kernel - so that its bits never depend on whether it rode.  Where the pairing rule does not hold
+// the two launches are made one after the other: same results.
+extern "C" int primx_linear_heads_fold_pair(const void* A, const void* W, int M, int N, int K, int rows_per_batch, int heads, int dh,
+                                            int n_seg, const int* kind, void* const* dst, int n_pad, float scale0, const float* part,
+                                            const float* u, const float* v, const float* center, float* center_out, float eps,
+                                            const void* A2, const void* W2, const void* bias2, int M2, int N2, int K2,
+                                            int rows_per_batch2, int heads2, int dh2, int n_seg2, const int* kind2, void* const* dst2,
+                                            int n_pad2, float scale0_2, int dtype, void* stream) {
+    const char* name = "primx_linear_heads_fold_pair";
+    PRIMX_REQUIRE(A2 && W2 && kind2 && dst2 && n_seg2 >= 1 && n_seg2 <= 3, "%s: problem 1: null operand, or n_seg outside 1..3", name);
+    PRIMX_REQUIRE(heads2 > 0 && dh2 > 0 && N2 == n_seg2 * heads2 * dh2 && M2 > 0 && K2 > 0, "%s: problem 1: N must equal n_seg*heads*dh", name);
+    PRIMX_REQUIRE(rows_per_batch2 > 0 && M2 % rows_per_batch2 == 0 && n_pad2 >= rows_per_batch2 && n_pad2 % 16 == 0,
+                  "%s: problem 1: need M %% rows_per_batch == 0, n_pad >= rows_per_batch, n_pad %% 16 == 0", name);
+    for (int s = 0; s < n_seg2; ++s)
+        PRIMX_REQUIRE(dst2[s] != nullptr && (kind2[s] == PRIMX_HEADS_ROWS || kind2[s] == PRIMX_HEADS_VT || kind2[s] == PRIMX_HEADS_KROWS),
+                      "%s: problem 1: null destination or bad kind", name);
+    bool paired = false;
+    if (A) {
+        PRIMX_REQUIRE(W && kind && dst && n_seg >= 1 && n_seg <= 3 && heads > 0 && dh > 0 && N == n_seg * heads * dh && M > 0 && K > 0 &&
+                          rows_per_batch > 0 && M % rows_per_batch == 0 && n_pad >= rows_per_batch && n_pad % 16 == 0 && part && u && v &&
+                          center && center_out && center != center_out,
+                      "%s: problem 0: the argument rules of primx_linear_heads_fold", name);
+        for (int s = 0; s < n_seg; ++s) PRIMX_REQUIRE(dst[s] != nullptr, "%s: problem 0: null destination", name);
+    }
+    PRIMX_DISPATCH_16(dtype, name, {
+        using S = typename T16<DT>::S;
+        GemmArgs<DT> r = {};
+        r.A = (const S*)A2; r.W = (const S*)W2; r.bias = (const S*)bias2;
+        r.M = M2; r.N = N2; r.K = K2;
+        r.rows_per_batch = rows_per_batch2; r.heads = heads2; r.dh = dh2; r.DP = primx_padded_head_dim(dh2);
+        r.n_pad = n_pad2; r.n_seg = n_seg2; r.scale0 = scale0_2;
+        for (int s = 0; s < 3; ++s) {
+            r.kind[s] = s < n_seg2 ? kind2[s] : 0;
+            r.rep_stride[s] = 0;
+            r.dst[s] = s < n_seg2 ? (S*)dst2[s] : nullptr;
+        }
+        const bool big1 = big_heads_shape<DT>(r);
+        const int g1 = big1 ? (r.M / 256) * (r.N / 288) : 0;
+        if (big1) r.xcd_gm = big_xcd_gm<DT>(r, true);
+        if (A) {
+            GemmArgs<DT> a = {};
+            a.A = (const S*)A; a.W = (const S*)W;
+            a.M = M; a.N = N; a.K = K;
+            a.rows_per_batch = rows_per_batch; a.heads = heads; a.dh = dh; a.DP = primx_padded_head_dim(dh);
+            a.n_pad = n_pad; a.n_seg = n_seg; a.scale0 = scale0;
+            for (int s = 0; s < 3; ++s) {
+                a.kind[s] = s < n_seg ? kind[s] : 0;
+                a.rep_stride[s] = 0;
+                a.dst[s] = s < n_seg ? (S*)dst[s] : nullptr;
+            }
+            a.fold_part = const_cast<float*>(part); a.fold_parts = K / 144; a.fold_u = u; a.fold_v = v; a.fold_c = center; a.fold_c_out = center_out;
+            a.fold_eps = eps;
+            const int g0 = big_heads_shape<DT>(a) ? (a.M / 256) * (a.N / 288) : 0;
+            // one round: both problems' tiles at once on the 256 CUs; problem 0 at the size launch_fold gives the big tile; the fold rules
+            if (big1 && g0 >= g_big_heads_min && g0 % 8 == 0 && g0 + g1 <= 256 && !g_gemm_prof_on && K % 144 == 0 && a.fold_parts <= 8 &&
+                (((uintptr_t)u | (uintptr_t)v) & 15) == 0 && (((uintptr_t)part | (uintptr_t)center | (uintptr_t)center_out) & 7) == 0) {
+                a.xcd_gm = big_xcd_gm<DT>(a, true);
+                a.ln_light = g_ln_mode;
+                PRIMX_NOTE_KERNEL("gemm288q_pair_kernel<%d>", DT);
+                hipLaunchKernelGGL((gemm288q_pair_kernel<DT>), dim3(g0 + g1), dim3(512), 0, (hipStream_t)stream, PRIMX_GEMM_PASS(a), g0, r);
+                PRIMX_CHECK_LAUNCH(name);
+                paired = true;
+            } else if (int rc = launch_fold<DT, EPI_HEADS_FOLD>(a, (hipStream_t)stream, name)) {
+                return rc;
+            }
+        }
+        if (!paired) {
+            if (big1) {   // problem 1 alone: the tile kernel it would have ridden
+                PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d, 32>", DT, EPI_HEADS);
+                hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI_HEADS, 32>), dim3(g1), dim3(512), 0, (hipStream_t)stream, PRIMX_GEMM_PASS(r));
+                PRIMX_CHECK_LAUNCH(name);
+            } else {
+                return launch<DT, EPI_HEADS>(r, (hipStream_t)stream, name);
+            }
+        }
     });
     return PRIMX_OK;
 }

@@ -195,6 +195,11 @@ class DiT(nn.Module):
         # foreign call (primx_dit_blocks_fold, ABI 24: the same entry points with the same arguments, issued from C) instead of 8
         # Python + ctypes calls per block.  Bit-identical; what changes is the host's time per step (tools/host_bound_check.py).
         self.blocks_call = os.environ.get("PRIMX_DIT_BLOCKS_CALL", "1") != "0"
+        # `kv_ride` (round 6, ABI 25; PRIMX_DIT_KV_RIDE=0 turns it off): on the one-call route the to_k / to_v projection of the conditioning
+        # tokens (attention.py:106-107) is issued by the library - block i + 1's 48 tiles ride on block i's qkv launch, whose 192 tiles leave
+        # a quarter of the chip idle at T = 4096 (primx_linear_heads_fold_pair) - instead of one batched launch per forward from here.
+        # Same tile kernel, bit-identical operands.
+        self.kv_ride = os.environ.get("PRIMX_DIT_KV_RIDE", "1") != "0"
         # Dynamic range (fp16): the folded operand cast16((x - c) rho_p (1 + scale)) is normalised with the PREVIOUS site's (mean, rstd)
         # of the row (ABI 23) - the LayerNorm output up to the factor rho_p / rho by which one gated branch changes the row's spread.
         # Magnitude and spread of the residual stream do not enter (tests/test_hip_fold.py: spreads 3e4 and 1e-5, magnitude 1e4); the
@@ -701,9 +706,20 @@ class DiT(nn.Module):
             Kn = self._heads("Kn", self.depth, Ln, HEADS_KROWS, dt, dev, ops.BKV)
             Vn = self._heads("Vn", self.depth, Ln, HEADS_VT, dt, dev, ops.BKV)
             Kn_blk, Vn_blk = Kn.view(self.depth, 1, *Kn.shape[1:]), Vn.view(self.depth, 1, *Vn.shape[1:])
-        if self.depth and not (self.reuse_cond_kv and cs["kv_valid"] and cs.get("kv_id") == (Kc.data_ptr(), Vc.data_ptr())):
-            ops.linear_heads(y16[:Bkv * Lk], pk["w_kv_all"], pk["b_kv_all"], Lk, H, dh, [HEADS_KROWS, HEADS_VT], [Kc, Vc],
-                             Kc.shape[2], n_rep=self.depth, rep_batches=Bkv, real_rows=Bkv * L)
+        need_kv = bool(self.depth) and not (self.reuse_cond_kv and cs["kv_valid"] and cs.get("kv_id") == (Kc.data_ptr(), Vc.data_ptr()))
+
+        ride_state = {"on": False}
+
+        def kv_problem(i: int):
+            # block i's [to_k; to_v] projection of the conditional entries as the heads GEMM primx_linear_heads_fold_pair carries
+            wkv, bkv = pk["w_kv_all"][i * 2 * D:(i + 1) * 2 * D], pk["b_kv_all"][i * 2 * D:(i + 1) * 2 * D]
+            return (y16[:Bkv * Lk], wkv, bkv, Lk, H, dh, [HEADS_KROWS, HEADS_VT], [Kc_blk[i], Vc_blk[i]], Kc.shape[2], 1.0, Bkv * L)
+
+        def project_kv(cond_rows: bool) -> None:
+            # (cond_rows False: the one-call route projects the conditional entries itself - `kv_ride`)
+            if cond_rows:
+                ops.linear_heads(y16[:Bkv * Lk], pk["w_kv_all"], pk["b_kv_all"], Lk, H, dh, [HEADS_KROWS, HEADS_VT], [Kc, Vc],
+                                 Kc.shape[2], n_rep=self.depth, rep_batches=Bkv, real_rows=Bkv * L)
             if dedup:
                 ops.linear_heads(cs["null16"], pk["w_kv_all"], pk["b_kv_all"], Ln, H, dh, [HEADS_KROWS, HEADS_VT], [Kn, Vn],
                                  Kn.shape[2], n_rep=self.depth, rep_batches=1)
@@ -826,7 +842,13 @@ class DiT(nn.Module):
             # ---- self-attention over the primitive tokens (dit_crossattn.py:56, attention.py:48-59)
             if not fuse:
                 ops.layernorm_modulate(hh, ch[3], ch[4], N, xh, self.LN_EPS, prefetch=warm(w["w_proj"]))
-            if folded:
+            if folded and ride_state["on"] and i + 1 < len(blocks):
+                # (`kv_ride`: the next block's to_k / to_v projection rides on this launch - what primx_dit_blocks_fold issues)
+                u1, v1 = uv(1)
+                ops.linear_heads_fold_pair(dict(A=xh, W=w["w_qkv"], rows_per_batch=N, heads=H, dh=dh, kinds=[HEADS_ROWS, HEADS_KROWS, HEADS_VT],
+                                                dsts=[Qs[b0:b1], Ks[b0:b1], Vs[b0:b1]], n_pad=nq_pad, part=fp, u=u1, v=v1, center=fc_in(),
+                                                center_out=fc_flip(), eps=self.LN_EPS), *kv_problem(i + 1))
+            elif folded:
                 ops.linear_heads_fold(xh, w["w_qkv"], N, H, dh, [HEADS_ROWS, HEADS_KROWS, HEADS_VT],
                                       [Qs[b0:b1], Ks[b0:b1], Vs[b0:b1]], nq_pad, fp, *uv(1), fc_in(), fc_flip(), self.LN_EPS)
             else:
@@ -855,6 +877,19 @@ class DiT(nn.Module):
                 ops.linear_gate_residual(hid[r0:r1], w["w_fc2"], w["b_fc2"], ch[8], hh, N,
                                          carry=None if last else carry(blocks[i + 1]["w_q"]), ln=ln_of(*nxt))
 
+        two_streams = bool(self.cfg_streams and null_half and self.depth and ops.PROFILE is None)
+        one_call = (not two_streams and fold_uv is not None and self.blocks_call and sync is None and ops.PROFILE is None
+                    and self.block_probe is None and _lib.blocks_call_available())
+        # `kv_ride`: every folded single-stream forward - the library issues the riders on the one-call route, the block loop below otherwise
+        # - where the riders fit the qkv launch's round (T = 4096: 192 + 48 tiles; a large batch fills the chip by itself and keeps the
+        # batched projection)
+        ride = (need_kv and self.kv_ride and fold_uv is not None and not two_streams and _lib.kv_ride_available()
+                and ops.fold_pair_fits(T, N, D, H, Bkv * Lk, Lk, Dc))
+        ride_state["on"] = ride and not one_call
+        if need_kv:
+            project_kv(not ride)
+            if ride_state["on"]:
+                ops.linear_heads_fold_pair(None, *kv_problem(0))     # block 0's projection: a launch of its own, on the riders' tile kernel
         if self.cfg_streams and null_half and self.depth and ops.PROFILE is None:
             # Two HIP streams, one per CFG half (the conditional and the unconditional rows are independent chains of
             # kernels): every GEMM of this path ends with a write burst that nothing of ITS OWN kernel can overlap
@@ -871,8 +906,7 @@ class DiT(nn.Module):
                         side.wait_event(lag)             # the side chain starts when the main one is three kernels in
                     block(i, w, B, Be)
             main.wait_stream(side)
-        elif (fold_uv is not None and self.blocks_call and sync is None and ops.PROFILE is None and self.block_probe is None
-              and _lib.blocks_call_available()):
+        elif one_call:
             # ONE foreign call for the forward's blocks (primx_dit_blocks_fold, ABI 24): the C side issues the launches block() below
             # would - same entry points, same arguments, same order, bit-identical results - at ~1 us of host time each instead of
             # ~21 us of Python + ctypes (tools/host_bound_check.py).  The per-block descriptors are built once per planned loop.
@@ -901,6 +935,9 @@ class DiT(nn.Module):
                 n_steps=plan["t"].numel(), ln_eps=self.LN_EPS, scale=scale, h=h.data_ptr(), xn=xn.data_ptr(), att=att.data_ptr(),
                 hid=hid.data_ptr(), Qc=Qc.data_ptr(), Qs=Qs.data_ptr(), Ks=Ks.data_ptr(), Vs=Vs.data_ptr(), mod=mod.data_ptr(),
                 center0=fcent[0].data_ptr(), center1=fcent[1].data_ptr(), part=fpart.data_ptr())
+            if ride:
+                f.kv_A, f.kv_W, f.kv_bias = y16.data_ptr(), pk["w_kv_all"].data_ptr(), pk["b_kv_all"].data_ptr()
+                f.kv_rows, f.kv_rows_per_batch, f.kv_K = Bkv * Lk, Lk, Dc
             ops._dev(h, "h", torch.float32)                 # (the launch-device check of every op: ops._stream)
             _lib.check(_lib.load().primx_dit_blocks_fold(C.byref(f), fd["desc"], ops._stream()), "primx_dit_blocks_fold")
         else:

@@ -411,6 +411,49 @@ def linear_heads_fold(A: torch.Tensor, W: torch.Tensor, rows_per_batch: int, hea
         fa[0], fa[1], fa[2], fa[3], fa[4], eps, dtype_code(A.dtype), cp, cn, _stream()), "primx_linear_heads_fold"))
 
 
+def fold_pair_fits(T: int, rows_per_batch: int, D: int, heads: int, kv_rows: int, kv_rows_per_batch: int, kv_K: int) -> bool:
+    """Will primx_linear_heads_fold_pair run a DiT block's qkv projection (T token rows) and the next block's to_k / to_v projection
+    (kv_rows conditioning rows) as ONE launch?  The rule of csrc/gemm.hip: both on the 256 x 288 heads tile, the first problem one
+    round of at least PRIMX_GEMM_BIGHEADS_MIN workgroups (a multiple of 8), both together at most 256."""
+    if not fold_shapes_ok(T, rows_per_batch, D, heads) or os.environ.get("PRIMX_GEMM_PROF"):
+        return False
+    dh = D // heads
+    if (2 * D) % 288 or (heads * dh) % 288 or kv_rows_per_batch % 256 or kv_rows % kv_rows_per_batch or kv_K % 64:
+        return False
+    g0, g1 = (T // 256) * (3 * D // 288), (kv_rows // 256) * (2 * D // 288)
+    return g0 % 8 == 0 and g0 + g1 <= 256
+
+
+def linear_heads_fold_pair(fold: Optional[dict], A2: torch.Tensor, W2: torch.Tensor, bias2: Optional[torch.Tensor], rows_per_batch2: int,
+                           heads2: int, dh2: int, kinds2: Sequence[int], dsts2: Sequence[torch.Tensor], n_pad2: int,
+                           scale0_2: float = 1.0, real_rows2: Optional[int] = None) -> None:
+    """primx_linear_heads_fold_pair (ABI 25): `fold` = the keyword arguments of linear_heads_fold (without `carry`) for problem 0 - or None:
+    problem 1 alone on the 256 x 288 tile kernel - and a plain heads GEMM (linear_heads with n_rep = 1) as problem 1, from ONE launch where
+    the pairing rule of the header holds (problem 1's tiles on the CUs problem 0 leaves idle), otherwise from two.  Results = the two calls'."""
+    M2, K2 = A2.shape
+    N2 = W2.shape[0]
+    fl2 = 2.0 * (real_rows2 if real_rows2 is not None else M2) * N2 * K2     # (bench.py's FLOP credit: rows that are not zero padding)
+    k2 = (C.c_int * len(kinds2))(*kinds2)
+    d2 = (C.c_void_p * len(kinds2))(*[_dev(d, "dst", A2.dtype) for d in dsts2])
+    tail = (_dev(A2, "A2"), _dev(W2, "W2", A2.dtype), _dev(bias2, "bias2", A2.dtype) if bias2 is not None else None, M2, N2, K2,
+            rows_per_batch2, heads2, dh2, len(kinds2), k2, d2, n_pad2, scale0_2, dtype_code(A2.dtype), _stream())
+    if fold is None:
+        head = (None, None, 0, 0, 0, 0, 0, 0, 0, None, None, 0, 0.0, None, None, None, None, None, 0.0)
+        flops, tag = fl2, f"None {M2}x{N2}x{K2}"
+    else:
+        A, W = fold["A"], fold["W"]
+        M, K = A.shape
+        N = W.shape[0]
+        kinds, dsts = fold["kinds"], fold["dsts"]
+        k = (C.c_int * len(kinds))(*kinds)
+        d = (C.c_void_p * len(kinds))(*[_dev(t, "dst", A.dtype) for t in dsts])
+        fa = _fold_args(fold["part"], fold["u"], fold["v"], fold["center"], fold["center_out"], M, N, K)
+        head = (_dev(A, "A"), _dev(W, "W", A.dtype), M, N, K, fold["rows_per_batch"], fold["heads"], fold["dh"], len(kinds), k, d,
+                fold["n_pad"], fold.get("scale0", 1.0), fa[0], fa[1], fa[2], fa[3], fa[4], fold["eps"])
+        flops, tag = 2.0 * M * N * K + fl2, f"None {M}x{N}x{K}+{M2}x{N2}x{K2}"
+    _timed(tag, flops, lambda: check(_lib.load().primx_linear_heads_fold_pair(*head, *tail), "primx_linear_heads_fold_pair"))
+
+
 def linear_fold(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, part: torch.Tensor, u: torch.Tensor, v: torch.Tensor,
                 center: torch.Tensor, center_out: torch.Tensor, eps: float, act: int = ACT_NONE,
                 carry: Optional[torch.Tensor] = None) -> torch.Tensor:

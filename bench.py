@@ -509,6 +509,22 @@ def main() -> None:
                     "note": "DiT.fold_ln=False (PRIMX_DIT_FOLD=0): every LayerNorm + modulate as a launch of its own between the "
                             "gate-residual GEMM and the Linear it feeds (the round-3 / early round-4 path)"}
 
+    # The same K steps with the conditioning K / V projection as ONE batched launch per forward (DiT.kv_ride = False) instead of riding on
+    # the qkv launches' idle CUs (round 6, ABI 25): what the riders save, for the record (bit-identical samples).
+    batched_kv = None
+    if (args.config == "ddim" and rank == 0 and world == 1 and not args.no_side_legs and not args.reuse_cond_kv
+            and getattr(model, "kv_ride", False) and getattr(model, "fold_ln", False) and model._fold_ok(2 * B * N, N)):
+        model.kv_ride = False
+        run_steps(args.warmup)
+        el, _ = timed_repeats(run_steps, args.steps, max(1, args.repeats), 1, dist, dev)
+        model.kv_ride = True
+        run_steps(1)
+        e = statistics.median(el)
+        batched_kv = {"ms_per_step": 1e3 * e / args.steps, "value": B * args.steps / e, "unit": "denoise-steps/s",
+                      "note": "DiT.kv_ride=False (PRIMX_DIT_KV_RIDE=0): to_k / to_v of the conditioning tokens of all blocks as one GEMM per "
+                              "forward; the headline runs block i + 1's projection on the CUs block i's qkv launch (192 of 256 tiles) leaves "
+                              "idle (primx_linear_heads_fold_pair); same tile kernel, bit-identical samples (tests/test_hip_fold.py)"}
+
     # Two more shapes of the same loop, reported NEXT TO the headline (outside its timed region, like `decode`): the configs[2] /
     # configs[3] per-GPU batch of 8 (T = 32768 tokens per launch: every GEMM on the 256 x 288 tile) and configs[1] in bf16 - the
     # north star's target dtype.  Same model, same kernels, K steps between synchronisations, median of R.
@@ -677,6 +693,8 @@ def main() -> None:
             res["with_expanded_null_kv"] = expanded
         if unfolded:
             res["with_layernorm_launches"] = unfolded
+        if batched_kv:
+            res["with_batched_kv_projection"] = batched_kv
         if args.config in ("ddim", "c4"):
             res["ln_fold"] = {"enabled": bool(getattr(model, "fold_ln", False) and model._fold_ok(2 * B * N, N)),
                               "what": "LayerNorm + modulate folded into the gate-residual GEMM in front of it (operand + partial row sums) "

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 24
+#define PRIMX_ABI_VERSION 25
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -209,6 +209,20 @@ int primx_linear_heads_fold(const void* A, const void* W, int M, int N, int K, i
                             const float* v, const float* center, float* center_out, float eps, int dtype, const void* prefetch,
                             int64_t prefetch_bytes, void* stream);
 
+/* ABI 25.  primx_linear_heads_fold (problem 0: the arguments above without the prefetch range) and primx_linear_heads (problem 1:
+ * A2 ... scale0_2, n_rep = 1, no prefetch range) from ONE launch where both map onto the 256 x 288 tile's heads epilogue and fit
+ * one round of the chip together (problem 0's workgroups a multiple of 8, at least PRIMX_GEMM_BIGHEADS_MIN; problem 0 + problem 1
+ * <= 256): problem 1's tiles run on the CUs problem 0 leaves idle - the self-attention qkv projection of a DiT block at T = 4096
+ * (attention.py:48-54: 192 tiles) carries the to_k / to_v projection of the NEXT block's conditioning tokens (attention.py:106-107:
+ * 48 tiles).  Results are those of the two calls, bit for bit; outside the rule the two launches are made one after the other.
+ * A == NULL: problem 1 alone, on the tile kernel it would have ridden (its bits do not depend on whether it rode). */
+int primx_linear_heads_fold_pair(const void* A, const void* W, int M, int N, int K, int rows_per_batch, int heads, int dh, int n_seg,
+                                 const int* kind, void* const* dst, int n_pad, float scale0, const float* part, const float* u,
+                                 const float* v, const float* center, float* center_out, float eps,
+                                 const void* A2, const void* W2, const void* bias2, int M2, int N2, int K2, int rows_per_batch2,
+                                 int heads2, int dh2, int n_seg2, const int* kind2, void* const* dst2, int n_pad2, float scale0_2,
+                                 int dtype, void* stream);
+
 /* primx_linear (out_scale = 1) as the CONSUMER of a folded site (fc1 + GELU):
  * out = act(cast16((rho / rho_p) a16 W^T - rho mu' u + v)); center / center_out as above. */
 int primx_linear_fold(const void* A, const void* W, void* out, int M, int N, int K, int act, const float* part, const float* u,
@@ -298,13 +312,21 @@ typedef struct PrimxDitForwardFold {
     void *xn, *att, *hid, *Qc, *Qs, *Ks, *Vs;
     const void* mod;
     float *center0, *center1, *part;
+    /* ABI 25: the cross-attention K / V projection of the conditioning tokens done by this call (kv_A != NULL): kv_A = 16-bit
+     * [kv_rows, kv_K] conditioning rows (kv_rows_per_batch per batch entry, a multiple of 256), kv_W / kv_bias = [depth * 2 D, kv_K] /
+     * [depth * 2 D]: per block [to_k; to_v] (attention.py:106-107); block i's result goes to its Kc / Vc (KROWS / VT, nkv_pad_c keys).
+     * Block 0's projection is a launch of its own in front of the blocks, block i + 1's rides on block i's qkv launch
+     * (primx_linear_heads_fold_pair).  kv_A == NULL: the caller has filled Kc / Vc. */
+    const void *kv_A, *kv_W, *kv_bias;
+    int kv_rows, kv_rows_per_batch, kv_K;
 } PrimxDitForwardFold;
 
 /* The `depth` DiT blocks of a forward whose LayerNorms are folded (every call below is one of this header's entry points, issued
  * in the order and with the arguments `DiT._forward16` of the Python host issues them - same kernels, bit-identical results; the
  * host makes ONE foreign call per forward instead of 8 per block: 231 -> 10 per DDIM step at depth 28).  Per block:
  *   block 0 only: primx_layernorm_modulate + primx_row_stats + primx_linear_heads (to_q);  other blocks: primx_linear_heads_fold (to_q)
- *   primx_attention[_bcast] (cross)  ->  primx_linear_gate_residual_fold (cross proj)  ->  primx_linear_heads_fold (qkv)
+ *   primx_attention[_bcast] (cross)  ->  primx_linear_gate_residual_fold (cross proj)  ->  primx_linear_heads_fold (qkv; with
+ *   kv_A: primx_linear_heads_fold_pair carrying the next block's to_k / to_v)
  *   ->  primx_attention (self)  ->  primx_linear_gate_residual_fold (proj)  ->  primx_linear_fold (fc1 + GELU-tanh)
  *   ->  primx_linear_gate_residual_fold (fc2; last block: primx_linear_gate_residual_ln with the final layer's shift / scale).
  * Replaces the loop `for block in self.blocks: x = block(x, y, c)` (models/dit_crossattn.py:198-199) of a planned sampling loop. */

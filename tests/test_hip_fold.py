@@ -237,6 +237,75 @@ def test_fold_consumer_qkv(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,n,paired", [(2, 2048, True), (4, 2048, False)])
+def test_fold_consumer_qkv_with_a_rider(ops, dtype, B, n, paired):
+    """primx_linear_heads_fold_pair (ABI 25): the qkv consumer + the to_k / to_v projection of 1536 conditioning rows (K = 768, KROWS / V^T)
+    from one launch - every output the same BITS as the two calls (same tile kernel, same tiles); the problem-1-alone form (A = NULL) too.
+    T = 4096: 192 + 48 workgroups in one round (the pair kernel); T = 8192 (384 tiles: more than a round): two launches."""
+    from topia_xl_amd._lib import HEADS_KROWS, HEADS_ROWS, HEADS_VT
+    if not _fold_kernels_selectable(ops):
+        pytest.skip("a kernel-selection switch removes the 256 x 288 heads tile")
+    D, H, dh, Lk, L, Dc = 1152, 16, 72, 1536, 1370, 768
+    dt = 1 if dtype == torch.float16 else 2
+    Wc = synth.tensor(34, "Wqkv", (3 * D, D), D ** -0.5).to(dtype)
+    bc = synth.tensor(34, "bqkv", (3 * D,), 0.3).to(dtype)
+    y16 = torch.zeros(Lk, Dc, dtype=dtype)
+    y16[:L] = synth.tensor(34, "y", (L, Dc)).to(dtype)
+    Wkv = synth.tensor(34, "Wkv", (2 * D, Dc), Dc ** -0.5).to(dtype).to(DEV)
+    bkv = synth.tensor(34, "bkv", (2 * D,), 0.3).to(dtype).to(DEV)
+    y16 = y16.to(DEV)
+    kinds = [HEADS_ROWS, HEADS_KROWS, HEADS_VT]
+    mk = lambda: [ops.alloc_heads(B, H, n, dh, k, dtype, DEV, 128) for k in kinds]
+    mkkv = lambda: [ops.alloc_heads(1, H, L, dh, k, dtype, DEV, 256) for k in (HEADS_KROWS, HEADS_VT)]
+    got, ref, kv_got, kv_ref, kv_alone = mk(), mk(), mkkv(), mkkv(), mkkv()
+    cn_ref = []
+    names = []
+
+    def consumer(a16, part, u, v, c, cn):
+        ops.linear_heads_fold(a16, Wc.to(DEV), n, H, dh, kinds, ref, ref[0].shape[2], part, u, v, c, cn, EPS)
+        cn_ref.append(cn.clone())
+        cn.fill_(float("nan"))
+        ops.linear_heads_fold_pair(dict(A=a16, W=Wc.to(DEV), rows_per_batch=n, heads=H, dh=dh, kinds=kinds, dsts=got, n_pad=got[0].shape[2],
+                                        part=part, u=u, v=v, center=c, center_out=cn, eps=EPS),
+                                   y16, Wkv, bkv, Lk, H, dh, [HEADS_KROWS, HEADS_VT], kv_got, kv_got[0].shape[2])
+        names.append(_last_kernel(ops))
+        assert torch.equal(cn, cn_ref[0])
+    _chain(ops, dtype, B, n, Wc, bc, 34, consumer)
+    ops.linear_heads_fold_pair(None, y16, Wkv, bkv, Lk, H, dh, [HEADS_KROWS, HEADS_VT], kv_alone, kv_alone[0].shape[2])
+    names.append(_last_kernel(ops))
+    # the batched projection of DiT._forward16 (n_rep = 2 repetitions of the same weights: 96 tiles; the rule of launch<> gives it the
+    # same tile kernel only from PRIMX_GEMM_BIGHEADS_MIN = 160 workgroups on, so the reference here is the explicit big-tile form above)
+    ops.linear_heads(y16, Wkv, bkv, Lk, H, dh, [HEADS_KROWS, HEADS_VT], kv_ref, kv_ref[0].shape[2])
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    for a, b in zip(kv_got, kv_alone):
+        assert torch.equal(a, b)
+    want = (y16.double().cpu() @ Wkv.double().cpu().t() + bkv.double().cpu()).to(dtype).view(1, Lk, 2, H, dh)[:, :L]
+    for s, unpack in ((0, unpack_rows), (1, unpack_vt)):
+        assert rel_l2(unpack(kv_got[s], L, dh), want[:, :, s]) < TOL[dtype]
+        assert rel_l2(unpack(kv_ref[s], L, dh), want[:, :, s]) < TOL[dtype]
+    if _default_dispatch():
+        assert names[0] == (f"gemm288q_pair_kernel<{dt}>" if paired else f"gemm288q_dma_kernel<{dt}, 2, 32>"), names
+        assert names[1] == f"gemm288q_dma_kernel<{dt}, 2, 32>", names
+
+
+def test_fold_pair_rejects_bad_arguments(ops):
+    """Argument validation of primx_linear_heads_fold_pair happens before anything is launched."""
+    import ctypes as C
+    from topia_xl_amd import _lib
+    lib = _lib.load()
+    k2, d2 = (C.c_int * 2)(2, 1), (C.c_void_p * 2)(16, 16)
+    nul = (None, None, 0, 0, 0, 0, 0, 0, 0, None, None, 0, 0.0, None, None, None, None, None, 0.0)
+    assert lib.primx_linear_heads_fold_pair(*nul, None, 16, None, 1536, 2304, 768, 1536, 16, 72, 2, k2, d2, 1536, 1.0, 1, None) == -1
+    assert b"problem 1" in lib.primx_last_error()
+    assert lib.primx_linear_heads_fold_pair(*nul, 16, 16, None, 1536, 2300, 768, 1536, 16, 72, 2, k2, d2, 1536, 1.0, 1, None) == -1
+    assert b"n_seg*heads*dh" in lib.primx_last_error()
+    bad0 = (16, 16, 4096, 3456, 1152, 2048, 16, 72, 3, None, None, 2048, 1.0, None, None, None, None, None, 1e-6)
+    assert lib.primx_linear_heads_fold_pair(*bad0, 16, 16, None, 1536, 2304, 768, 1536, 16, 72, 2, k2, d2, 1536, 1.0, 1, None) == -1
+    assert b"problem 0" in lib.primx_last_error()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("B,n,kernel", [(2, 2048, "gemm288q_dma_kernel"), (2, 1950, "gemm288q_dma_kernel"), (1, 1024, "gemm144l_dma_kernel"),
                                         (1, 333, "gemm144l_dma_kernel"), (4, 2048, "gemm288q_dma_kernel"), (3, 1500, "gemm288q_dma_kernel")])
 def test_fold_consumer_fc1(ops, dtype, B, n, kernel):
@@ -378,9 +447,13 @@ def test_dit_with_the_fold_against_the_unfolded_path_and_the_oracle(ops, dtype, 
                            and os.environ.get("PRIMX_DIT_LN_TAIL") != "1")               # the final layer's LayerNorm runs inside the last GEMM
     if launch_list_applies:
         assert len(ln_calls) == 2 * 4, len(ln_calls)                       # the first LayerNorm and the final layer's, per forward
-        epi = lambda nm: nm.split("<")[1].split(">")[0].split(", ")[1] if "<" in nm else ""      # the epilogue template argument of a GEMM tag
+        def epi(nm):                                                               # the epilogue template argument of a GEMM tag
+            args = nm.split("<")[1].split(">")[0].split(", ") if "<" in nm else []
+            return args[1] if len(args) > 1 else ""
+        riders = 2 if os.environ.get("PRIMX_DIT_KV_RIDE", "1") != "0" else 0       # qkv of blocks 0, 1 carries the next block's to_k / to_v
         assert sum(1 for nm in names if epi(nm) == "6") == 4 * (3 * 3 - 1), names   # producers: every gated add but the last
-        assert sum(1 for nm in names if epi(nm) == "7") == 4 * (2 * 3 - 1)          # to_q (blocks 1, 2) + qkv
+        assert sum(1 for nm in names if epi(nm) == "7") == 4 * (2 * 3 - 1 - riders), names      # to_q (blocks 1, 2) + qkv
+        assert sum(1 for nm in names if nm.startswith("gemm288q_pair_kernel<")) == 4 * riders, names
         assert sum(1 for nm in names if nm.startswith("gemm288q_dma_kernel") and ", 8, 64>" in nm) == 4 * 3
     # one planned forward against the fp32 oracle
     t = torch.tensor([520])
@@ -465,7 +538,9 @@ def test_blocks_call_is_bit_identical_to_the_python_block_loop(ops, dtype, batch
     from topia_xl_amd import _lib
     if not _lib.blocks_call_available():
         pytest.skip("the loaded library has no primx_dit_blocks_fold")
-    sd, m = _fold_model(pkg, 3, 83)
+    # (depth 4: the Python loop's batched K / V projection - 6 x 8 x depth tiles at batch 1 - takes the 256 x 288 tile from 160 tiles on, the tile
+    #  the one-call route's riders always use; below that it runs on the 128 x 144 kernel and the operands differ at rounding level)
+    sd, m = _fold_model(pkg, 4, 83)
     m.dedup_null_kv = dedup
     x, y = synth.tensor(83, "x", (batch, 2048, 68)), synth.tensor(83, "y", (batch, 1370, 768))
     d = pkg.create_diffusion("ddim4", noise_schedule="squaredcos_cap_v2", parameterization="v")
@@ -496,6 +571,34 @@ def test_blocks_call_is_bit_identical_to_the_python_block_loop(ops, dtype, batch
     assert len(calls) == (4 if folds else 0), len(calls)
     for a, b in zip(got, base):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype,batch,dedup", [(torch.float16, 1, True), (torch.bfloat16, 1, False)])
+def test_kv_ride_is_bit_identical_to_the_batched_projection(ops, dtype, batch, dedup):
+    """`DiT.kv_ride` (ABI 25): on the one-call route the library projects the conditioning K / V itself - block 0's as a launch of its own,
+    block i + 1's riding on block i's qkv launch - instead of one batched GEMM per forward from Python: every sample of a planned loop is
+    the same to the last bit, with `reuse_cond_kv` (nothing to project after the first forward) as well."""
+    import topia_xl_amd as pkg
+    from topia_xl_amd import _lib
+    if not (_lib.blocks_call_available() and _lib.kv_ride_available()):
+        pytest.skip("the loaded library has no K / V riders")
+    sd, m = _fold_model(pkg, 4, 87)        # (depth 4: the batched projection on the riders' tile kernel - see the test above)
+    m.dedup_null_kv = dedup
+    x, y = synth.tensor(87, "x", (batch, 2048, 68)), synth.tensor(87, "y", (batch, 1370, 768))
+    d = pkg.create_diffusion("ddim3", noise_schedule="squaredcos_cap_v2", parameterization="v")
+    kw = dict(y=y.to(DEV), cfg_scale=6.0, precision_dtype=dtype, enable_amp=True)
+    loop = lambda: [o["sample"].clone() for o in d.ddim_sample_loop_progressive(m.forward_with_cfg, tuple(x.shape), noise=x.to(DEV),
+                                                                                clip_denoised=False, model_kwargs=kw)]
+    m.kv_ride = False
+    base = loop()
+    m.kv_ride = True
+    got = loop()
+    m.reuse_cond_kv = True
+    m._cond = None
+    again = loop()
+    m.reuse_cond_kv = False
+    for a, b, c in zip(got, base, again):
+        assert torch.equal(a, b) and torch.equal(c, b)
 
 
 def test_blocks_call_rejects_bad_descriptors(ops):

@@ -31,6 +31,7 @@ def gemm_flops(shape):      # "MxNxK" -> 2 M N K; "PxNqxNkvxdh" -> 4 P Nq Nkv dh
 
 FLOPS = {"4096x1152x1152": 2 * 4096 * 1152 * 1152, "4096x1152x4608": 2 * 4096 * 1152 * 4608, "4096x4608x1152": 2 * 4096 * 4608 * 1152,
          "4096x3456x1152": 2 * 4096 * 3456 * 1152, "1536x64512x768": 2 * 1370 * 64512 * 768,
+         "4096x3456x1152+1536x2304x768": 2 * 4096 * 3456 * 1152 + 2 * 1370 * 2304 * 768, "1536x2304x768": 2 * 1370 * 2304 * 768,
          "32x2048x2048x72": 4 * 32 * 2048 * 2048 * 72, "32x2048x1370x72": 4 * 32 * 2048 * 1370 * 72,
          "256->256 @4^3 x2048": 2 * 2048 * 64 * 256 * 27 * 256, "gn+256->32+sc @8^3 x2048": 2 * 2048 * 512 * 32 * 28 * 256,
          "256->32 @8^3 x2048": 2 * 2048 * 512 * 32 * 27 * 256}
