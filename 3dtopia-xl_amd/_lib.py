@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PRIMX_LIB") or os.path.join(_HERE, "csrc", "libprimx_
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
 HEADS_ROWS, HEADS_VT, HEADS_KROWS = 0, 1, 2
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -27,6 +27,11 @@ class DitBlockFold(C.Structure):
                                   "Kc", "Vc", "Kb", "Vb", "uv_q", "uv_qkv", "uv_fc1",
                                   "carry_q", "carry_cproj", "carry_fc1", "carry_fc2")] + \
                [(n, _l) for n in ("carry_q_bytes", "carry_cproj_bytes", "carry_fc1_bytes", "carry_fc2_bytes")]
+
+
+class F32outProblem(C.Structure):
+    """PrimxF32outProblem (include/primx_hip.h, ABI 26): one problem of primx_linear_f32out_group; the array lives in DEVICE memory (40 bytes each)."""
+    _fields_ = [("A", _p), ("W", _p), ("bias", _p), ("out", _p), ("N", _i), ("first_wg", _i)]
 
 
 class DitForwardFold(C.Structure):
@@ -67,6 +72,7 @@ SIGNATURES = {
                                 _i, _p, _l, _p],
     "primx_linear_heads_fold_pair": [_p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _f, _p, _p, _p, _p, _p, _f,
                                      _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _f, _i, _p],
+    "primx_linear_f32out_group": [_p, _i, _i, _i, _i, _i, _i, _p],
     "primx_linear_fold": [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _i, _p, _l, _p],
     "primx_linear_heads": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_p), _i, _i, _i, _f, _i, _p, _l, _p],
     "primx_attention": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
@@ -102,13 +108,15 @@ _RESTYPES = {"primx_last_error": C.c_char_p, "primx_last_gemm_kernel": C.c_char_
 # nothing folds: the fold prototypes are not bound to such a build and `fold_available()` is False (ops.fold_shapes_ok asks);
 # version 24 added primx_dit_blocks_fold (one foreign call for a forward's blocks): a version-23 build lacks only that one, and the
 # host then issues the launches itself (`blocks_call_available()`); version 25 added primx_linear_heads_fold_pair and the kv_* tail of
-# PrimxDitForwardFold (a version-24 build ignores the tail: the host then projects K / V itself, `kv_ride_available()`)
+# PrimxDitForwardFold (a version-24 build ignores the tail: the host then projects K / V itself, `kv_ride_available()`); version 26 added
+# primx_linear_f32out_group (`f32out_group_available()`: without it the fold's u / v rows are one launch per site)
 _FOLD_ENTRY_POINTS: set = {"primx_linear_f32out", "primx_row_stats", "primx_linear_gate_residual_fold", "primx_linear_heads_fold",
                            "primx_linear_fold"}
-_AB_ABI_VERSIONS: tuple = (21, 22, 23, 24)
+_AB_ABI_VERSIONS: tuple = (21, 22, 23, 24, 25)
 _fold_available: dict = {}
 _blocks_call: dict = {}
 _kv_ride: dict = {}
+_f32out_group: dict = {}
 
 _lib: Optional[C.CDLL] = None
 
@@ -156,12 +164,15 @@ def load(path: Optional[str] = None) -> C.CDLL:
             continue
         if got < 25 and name == "primx_linear_heads_fold_pair":
             continue
+        if got < 26 and name == "primx_linear_f32out_group":
+            continue
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     _fold_available[path] = got >= 23
     _blocks_call[path] = got >= 24
     _kv_ride[path] = got >= 25
+    _f32out_group[path] = got >= 26
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -183,6 +194,12 @@ def kv_ride_available() -> bool:
     """Does the loaded library's primx_dit_blocks_fold project the conditioning K / V itself (ABI 25: riders on the qkv launches)?"""
     load()
     return _kv_ride.get(LIB_PATH, False)
+
+
+def f32out_group_available() -> bool:
+    """Does the loaded library carry primx_linear_f32out_group (ABI 26)?"""
+    load()
+    return _f32out_group.get(LIB_PATH, False)
 
 
 def check(status: int, name: str) -> None:

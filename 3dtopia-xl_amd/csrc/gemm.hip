@@ -2180,6 +2180,112 @@ extern "C" int primx_linear_heads(const void* A, const void* W, const void* bias
     return PRIMX_OK;
 }
 
+// ---- Grouped few-row fp32-out Linear (ABI 26): the fold's u / v rows of EVERY site of a planned loop from one launch.  Each problem is
+// out_i[M, N_i] = A_i[M, K] W_i[N_i, K]^T (+ bias_i for the rows >= bias_from_row) with the same M (2 x timesteps of the loop: 50 rows at
+// 25 steps) and K: 83 problems at DiT-XL, 592 MB of weights read once - a weight stream, where 83 separate launches of 8 - 32 workgroups
+// were latency-bound (~18 us each: 1.5 ms per 25-step loop).  A workgroup = 4 waves x 32 columns of ONE problem and 64 rows (grid.y walks
+// the row blocks of a longer loop); a wave streams its 32 weight rows straight into the MFMA's first operand (accumulator = C^T: a lane
+// owns one A row and four consecutive columns, 16-byte fp32 stores) and reads the A fragments through L1 / L2 (64 x K halves per problem,
+// shared by its workgroups).  k runs in order in one fp32 accumulator per output: same products, same order for every (M, problem count).
+template <int DT>
+__global__ __launch_bounds__(256) void f32out_group_kernel(const PrimxF32outProblem* __restrict__ probs, int n_probs, int M, int K,
+                                                            int bias_from_row) {
+    using S = typename T16<DT>::S;
+    using V8 = typename T16<DT>::V8;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the problem of this workgroup: the last one whose first workgroup is <= blockIdx.x (uniform binary search over <= a few hundred entries)
+    int lo = 0, hi = n_probs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (probs[mid].first_wg <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PrimxF32outProblem pr = probs[lo];
+    const int n0 = ((int)blockIdx.x - pr.first_wg) * 128 + wave * 32;
+    if (n0 >= pr.N) return;                                      // (N % 32 == 0: a wave's 32 columns are all inside or all outside)
+    const int m0 = blockIdx.y * 64;
+    const S* A = static_cast<const S*>(pr.A);
+    const S* W = static_cast<const S*>(pr.W);
+    const S* arow[4];
+    const S* wrow[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) arow[i] = A + (int64_t)min(m0 + i * 16 + lr, M - 1) * K + lg * 8;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wrow[j] = W + (int64_t)(n0 + j * 16 + lr) * K + lg * 8;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int UN = 4;                                        // k-steps of 32 in flight: 4 x (2 + 4) 16-byte loads per lane
+    int k = 0;
+    for (; k + 32 * UN <= K; k += 32 * UN) {
+        V8 a[UN][4], b[UN][2];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[u][j] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(wrow[j] + k + 32 * u));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[u][i] = *reinterpret_cast<const V8*>(arow[i] + k + 32 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = T16<DT>::mfma16(b[u][j], a[u][i], acc[i][j]);
+    }
+    for (; k < K; k += 32) {
+        V8 a[4], b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(wrow[j] + k));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const V8*>(arow[i] + k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = T16<DT>::mfma16(b[j], a[i], acc[i][j]);
+    }
+    // acc[i][j][r] = C[m0 + 16 i + lr][n0 + 16 j + 4 lg + r]
+    const S* bias = static_cast<const S*>(pr.bias);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + j * 16 + 4 * lg;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = (float)bias[n + r];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + i * 16 + lr;
+            if (m >= M) continue;
+            f32x4 o = acc[i][j];
+            if (m >= bias_from_row) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] += bv[r];
+            }
+            *reinterpret_cast<f32x4*>(pr.out + (int64_t)m * pr.N + n) = o;
+        }
+    }
+}
+
+// `probs`: n_probs descriptors in DEVICE memory, first_wg ascending from 0 with first_wg[i + 1] - first_wg[i] = ceil(N_i / 128); total_wg =
+// their sum.  (The descriptors are data the kernel reads: the host cannot validate them here - the caller builds them, cf. ops.F32outGroup.)
+extern "C" int primx_linear_f32out_group(const PrimxF32outProblem* probs, int n_probs, int total_wg, int M, int K, int bias_from_row,
+                                         int dtype, void* stream) {
+    const char* name = "primx_linear_f32out_group";
+    PRIMX_REQUIRE(probs && n_probs > 0 && total_wg >= n_probs, "%s: null or empty problem list", name);
+    PRIMX_REQUIRE(M > 0 && K > 0 && K % 32 == 0 && bias_from_row >= 0, "%s: need M > 0, K %% 32 == 0 (M=%d K=%d)", name, M, K);
+    PRIMX_DISPATCH_16(dtype, name, {
+        PRIMX_NOTE_KERNEL("f32out_group_kernel<%d>", DT);
+        hipLaunchKernelGGL((f32out_group_kernel<DT>), dim3(total_wg, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, probs, n_probs, M, K,
+                           bias_from_row);
+    });
+    PRIMX_CHECK_LAUNCH(name);
+    return PRIMX_OK;
+}
+
 // ---- LayerNorm fold (see fold_stats_load)
 extern "C" int primx_linear_f32out(const void* A, const void* W, const void* bias, float* out, int M, int N, int K,
                                    int bias_from_row, int dtype, void* stream) {

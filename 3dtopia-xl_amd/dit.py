@@ -617,20 +617,30 @@ class DiT(nn.Module):
         tab = self._modulation_table(plan, dt, pk)
         n, D = tab.shape[0], self.hidden_size
         A = self._fold_rows(tab, self.depth, D)
-        # (3 x depth - 1 independent few-row GEMMs, 9 - 36 workgroups and ~20 us each: 0.07 ms per step of a 25-step loop.  Issued
-        # round-robin on four side streams they overlap - and every LATER launch of the loop got slower: the step 8.83 vs 8.63 ms on
-        # the same box, against 8.97 unfolded (profiles/r4_experiments.txt section 6).  They stay on the calling stream.)
-        uv = []
+        # (3 x depth - 1 independent few-row GEMMs.  As launches of their own: 9 - 36 workgroups and ~20 us each, 0.07 ms per step of a
+        # 25-step loop; issued round-robin on four side streams they overlapped - and every LATER launch of the loop got slower: the step
+        # 8.83 vs 8.63 ms on the same box (profiles/r4_experiments.txt section 6).  Round 6: one grouped launch on the calling stream.)
+        # ONE grouped launch for the 3 x depth - 1 sites (primx_linear_f32out_group, ABI 26: 592 MB of weights streamed once; the per-site
+        # launches were 8 - 32 workgroups and ~18 us each = 1.5 ms per loop); per-site launches where the grouped kernel does not apply
+        sites, uv = [], []
+        total = sum(2 * n * w["w_" + name].shape[0] for i, w in enumerate(pk["blocks"]) for s, name in enumerate(("q", "qkv", "fc1"))
+                    if not (i == 0 and s == 0))
+        flat, off = torch.empty(total, dtype=torch.float32, device=tab.device), 0
         for i, w in enumerate(pk["blocks"]):
             row = []
             for s, name in enumerate(("q", "qkv", "fc1")):
                 if i == 0 and s == 0:                                     # (the first LayerNorm of a forward stays a launch)
                     row.append(None)
                     continue
-                out = torch.empty(2, n, w["w_" + name].shape[0], dtype=torch.float32, device=tab.device)
-                ops.linear_f32out(A[i, s].view(2 * n, D), w["w_" + name], w["b_" + name], out.view(2 * n, -1), bias_from_row=n)
+                Ns = w["w_" + name].shape[0]
+                out = flat[off:off + 2 * n * Ns].view(2, n, Ns)
+                off += 2 * n * Ns
+                sites.append((A[i, s].view(2 * n, D), w["w_" + name], w["b_" + name], out.view(2 * n, Ns)))
                 row.append(out)
             uv.append(row)
+        if not ops.linear_f32out_group(sites, bias_from_row=n):
+            for a_s, w_s, b_s, o_s in sites:
+                ops.linear_f32out(a_s, w_s, b_s, o_s, bias_from_row=n)
         ft = plan["fold"] = {"key": key, "uv": uv}
         return ft
 

@@ -357,6 +357,31 @@ def linear_f32out(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
     return out
 
 
+def linear_f32out_group(problems: Sequence[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], torch.Tensor]], bias_from_row: int) -> bool:
+    """primx_linear_f32out_group (ABI 26): every (A [M, K], W [N, K], bias [N] or None, out [M, N] fp32) of `problems` - same M, K and dtype -
+    from ONE launch (the fold's u / v rows of a whole planned loop).  Returns False, having launched nothing, where the grouped kernel does
+    not apply (an older PRIMX_LIB build, PRIMX_UV_GROUP=0, N % 32 or K % 32 != 0): the caller then makes one linear_f32out call per problem."""
+    if not problems or not _lib.f32out_group_available() or os.environ.get("PRIMX_UV_GROUP") == "0":
+        return False
+    M, K = problems[0][0].shape
+    dt = problems[0][0].dtype
+    rows, first = [], 0
+    flops = 0.0
+    for A, W, b, out in problems:
+        N = W.shape[0]
+        if (tuple(A.shape) != (M, K) or A.dtype != dt or W.shape[1] != K or tuple(out.shape) != (M, N) or N % 32 or K % 32
+                or not (A.is_contiguous() and W.is_contiguous() and out.is_contiguous()) or out.data_ptr() % 16):
+            return False
+        rows.append([_dev(A, "A"), _dev(W, "W", dt), _dev(b, "bias", dt) if b is not None else 0, _dev(out, "out", torch.float32),
+                     N | (first << 32)])                          # (N, first_wg: two little-endian ints in the struct's last 8 bytes)
+        first += (N + 127) // 128
+        flops += 2.0 * M * N * K
+    table = torch.tensor(rows, dtype=torch.int64).to(problems[0][0].device, non_blocking=False)
+    _timed(f"None {len(problems)} problems x {M} rows, K = {K}", flops, lambda: check(_lib.load().primx_linear_f32out_group(
+        table.data_ptr(), len(problems), first, M, K, bias_from_row, dtype_code(dt), _stream()), "primx_linear_f32out_group"))
+    return True
+
+
 def _fold_args(part: torch.Tensor, u: torch.Tensor, v: torch.Tensor, center: torch.Tensor, center_out: torch.Tensor, M: int, N: int,
                K: int):
     if K % FOLD_TILE or tuple(part.shape) != (M, K // FOLD_TILE, 2) or tuple(center.shape) != (M, 2) or tuple(center_out.shape) != (M, 2):

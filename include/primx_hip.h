@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PRIMX_ABI_VERSION 25
+#define PRIMX_ABI_VERSION 26
 
 /* dtype codes */
 #define PRIMX_F32 0
@@ -186,6 +186,22 @@ int primx_ln_sync_timeouts(void);
  * u rows (A = cast16(1 + scale) of each planned timestep, no bias) and v rows (A = shift, bias = the Linear's) in one launch. */
 int primx_linear_f32out(const void* A, const void* W, const void* bias, float* out, int M, int N, int K, int bias_from_row,
                         int dtype, void* stream);
+
+/* ABI 26.  Many primx_linear_f32out problems with the same M, K, bias_from_row and dtype from ONE launch: the fold's u / v rows of every
+ * (block, site) of a planned sampling loop (83 problems at DiT-XL: 592 MB of weights streamed once instead of 83 latency-bound launches).
+ * `probs` lives in DEVICE memory: problem i = out[M, N] (fp32, 16-byte aligned rows: N % 32 == 0) = A[M, K] W[N, K]^T (+ bias, may be NULL,
+ * for the rows >= bias_from_row); first_wg = the sum of ceil(N / 128) over the problems in front of it (ascending from 0), total_wg the sum
+ * over all.  Same products in the same order for every output whatever M and the problem count. */
+typedef struct PrimxF32outProblem {
+    const void* A;
+    const void* W;
+    const void* bias;
+    float* out;
+    int N;
+    int first_wg;
+} PrimxF32outProblem;
+int primx_linear_f32out_group(const PrimxF32outProblem* probs, int n_probs, int total_wg, int M, int K, int bias_from_row, int dtype,
+                              void* stream);
 
 /* stats[r] = (mean(x[r, :]), 1 / sqrt(var(x[r, :]) + eps)) in fp32, [rows][2]: the (c, rho_p) pair of the first folded site of a
  * forward - the statistics primx_layernorm_modulate uses for the same rows (D % 4 == 0).  ABI 23 (replaces primx_row_mean). */

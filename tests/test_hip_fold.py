@@ -77,6 +77,40 @@ def test_linear_f32out(ops, dtype, M, N, K, frm):
     assert rel_l2(out2, A.double() @ W.double().t()) < 2e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,frm", [(50, 25), (8, 4), (130, 65), (64, 0)])
+def test_linear_f32out_group(ops, dtype, M, frm):
+    """primx_linear_f32out_group (ABI 26): many few-row fp32-out problems from one launch - every problem against float64 and against its own
+    primx_linear_f32out call; ragged last column group (N = 160: a workgroup with idle waves), a problem without a bias, more than 64 rows
+    (two or three row blocks); the same problem alone or inside a group gives the same bits."""
+    from topia_xl_amd import _lib
+    if not _lib.f32out_group_available() or os.environ.get("PRIMX_UV_GROUP") == "0":
+        pytest.skip("no grouped f32out kernel in this library / switched off")
+    K = 1152
+    probs, refs = [], []
+    for i, N in enumerate((1152, 3456, 160, 4608, 32)):
+        A = synth.tensor(40 + i, "A", (M, K)).to(dtype)
+        W = synth.tensor(40 + i, "W", (N, K), K ** -0.5).to(dtype)
+        b = None if i == 2 else synth.tensor(40 + i, "b", (N,), 0.3).to(dtype)
+        out = torch.full((M, N), float("nan"), device=DEV)
+        probs.append((A.to(DEV), W.to(DEV), None if b is None else b.to(DEV), out))
+        ref = A.double() @ W.double().t()
+        if b is not None:
+            ref[frm:] += b.double()
+        refs.append(ref)
+    assert ops.linear_f32out_group(probs, frm)
+    assert _last_kernel(ops) == f"f32out_group_kernel<{1 if dtype == torch.float16 else 2}>"
+    for (A, W, b, out), ref in zip(probs, refs):
+        assert rel_l2(out, ref) < 2e-6 and max_abs(out, ref) < 2e-5 * float(ref.abs().max())
+        one = torch.empty_like(out)
+        ops.linear_f32out(A, W, b, one, frm)
+        assert rel_l2(one, out.double().cpu()) < 1e-6
+    alone = torch.full_like(probs[1][3], float("nan"))
+    assert ops.linear_f32out_group([probs[1][:3] + (alone,)], frm)
+    assert torch.equal(alone, probs[1][3])
+    assert not ops.linear_f32out_group([(probs[0][0], probs[0][1][:40], None, torch.empty(M, 40, device=DEV))], frm)   # N % 32 != 0: the caller's loop
+
+
 def _site(seed, B, n, D, K, dtype, mean_ratio=0.3, spread=2.0, offset=0.0, branch=1.0):
     """Inputs of one folded LayerNorm site: the branch operand A [B n, K] and weights of the PRODUCER (N = D), the residual
     stream x - row spread `spread`, a per-row mean of `mean_ratio` x the spread (+ `offset` with a per-row sign), gate (scaled
