@@ -197,8 +197,9 @@ def traffic_file() -> str:
     """The newest committed PMC traffic table (profiles/r<round>_traffic.json)."""
     import glob
     import re
-    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")),
-                key=lambda f: int(re.search(r"r(\d+)_traffic", f).group(1)))
+    pat = re.compile(r"^r(\d+)_traffic\.json$")       # (r6_traffic.json; not r6_traffic_b8.json, not an archived r6a_traffic.json)
+    fs = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")) if pat.match(os.path.basename(f))),
+                key=lambda f: int(pat.match(os.path.basename(f)).group(1)))
     return fs[-1] if fs else os.path.join(ROOT, "profiles", "none")
 
 
