@@ -1586,17 +1586,17 @@ __global__ __launch_bounds__(512, 2) void gemm288q_dma_kernel(PRIMX_GEMM_PARAMS(
 // 192 workgroups at T = 4096 = 75 % of the CUs), workgroups [n0, grid) a plain heads GEMM `r` (the to_k / to_v projection of the NEXT
 // block's conditioning tokens, 48 tiles) on CUs the first problem leaves idle.  Same bodies, same tiles, same bits as the two launches.
 // n0 % 8 == 0, so that a rider's id keeps its XCD (id mod 8) for the tile walk.
-template <int DT>
+template <int DT, int KT>
 __global__ __launch_bounds__(512, 2) void gemm288q_pair_kernel(PRIMX_GEMM_PARAMS(DT), int n0, const GemmArgs<DT> r) {
-    constexpr int H0 = gemm288q_lds_halves<EPI_HEADS_FOLD, 32>(), H1 = gemm288q_lds_halves<EPI_HEADS, 32>();
+    constexpr int H0 = gemm288q_lds_halves<EPI_HEADS_FOLD, KT>(), H1 = gemm288q_lds_halves<EPI_HEADS, KT>();
     __shared__ __attribute__((aligned(16))) typename T16<DT>::S smem[H0 > H1 ? H0 : H1];
     if ((int)blockIdx.x < n0) {
-        constexpr int EPI = EPI_HEADS_FOLD, KT = 32;
+        constexpr int EPI = EPI_HEADS_FOLD;
         PRIMX_GEMM_ARGS(DT);
         const int bid = blockIdx.x;
 #include "gemm288q_body.inc"
     } else {
-        constexpr int EPI = EPI_HEADS, KT = 32;
+        constexpr int EPI = EPI_HEADS;
         const GemmArgs<DT>& p = r;
         const typename T16<DT>::S *const pl_A = r.A, *const pl_W = r.W;
         const int pl_M = r.M, pl_N = r.N, pl_K = r.K, pl_xcd_gm = r.xcd_gm, pl_prof = 0, bid = (int)blockIdx.x - n0;
@@ -1730,6 +1730,18 @@ static const int g_kt64_min = [] {   // PRIMX_GEMM_KT64_MIN: fewest 256x288 work
 // ONE round (qkv at T = 4096: 192 workgroups) the two-stage ring's longer first wait costs more than the request rate gives (44.5 ->
 // 46.5 us), and the heads epilogues neither gain (T = 16384 qkv 137 vs 137 us) nor fit the registers (the compiler spills 7 - 29
 // dwords next to their two main loops): both keep the 32-wide ring.  (KT = 64 addresses its operands by 32-bit byte offsets.)
+static const bool g_heads_kt64 = [] {   // PRIMX_GEMM_HEADS_KT32=1: the heads epilogues of the 256x288 kernel on the ring of 32-wide slices (rounds 1 - 6a)
+    const char* e = getenv("PRIMX_GEMM_HEADS_KT32");
+    return !(e && atoi(e) != 0);
+}();
+
+// The heads epilogues on the 128-byte ring (end of round 6): with the rolling fragment window of gemm288q_body.inc they fit the registers
+// (no scratch), and their k-loop leaves the request-bound regime like the dense epilogues' did.
+template <int DT>
+static bool heads_kt64(const GemmArgs<DT>& x) {
+    return g_heads_kt64 && !g_kt32 && x.K % 64 == 0 && x.K >= 128 && (int64_t)x.M * x.K < (1ll << 31) && (int64_t)x.N * x.K < (1ll << 31);
+}
+
 template <int DT, int EPI>
 static void launch288q(const GemmArgs<DT>& x, dim3 grid, hipStream_t st) {
     constexpr bool DENSE = EPI == EPI_LINEAR || EPI == EPI_GATE_RESIDUAL || EPI == EPI_GATE_RESIDUAL_FOLD || EPI == EPI_LINEAR_FOLD ||
@@ -1740,6 +1752,13 @@ static void launch288q(const GemmArgs<DT>& x, dim3 grid, hipStream_t st) {
         //  two-pass kernel once this kernel carries the weight prefetch; the read-modify-write epilogues from two rounds on)
         const int kt64_min = g_kt64_min >= 0 ? g_kt64_min : (EPI == EPI_LINEAR || EPI == EPI_LINEAR_FOLD) ? 1 : 257;
         if (x.K % 64 == 0 && !g_kt32 && full && (int)grid.x >= kt64_min && (int64_t)x.M * x.K < (1ll << 31) && (int64_t)x.N * x.K < (1ll << 31)) {
+            PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d, 64>", DT, EPI);
+            hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI, 64>), grid, dim3(512), 0, st, PRIMX_GEMM_PASS(x));
+            return;
+        }
+    }
+    if constexpr (EPI == EPI_HEADS || EPI == EPI_HEADS_FOLD) {
+        if (heads_kt64<DT>(x)) {
             PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d, 64>", DT, EPI);
             hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI, 64>), grid, dim3(512), 0, st, PRIMX_GEMM_PASS(x));
             return;
@@ -2438,8 +2457,13 @@ extern "C" int primx_linear_heads_fold_pair(const void* A, const void* W, int M,
                 (((uintptr_t)u | (uintptr_t)v) & 15) == 0 && (((uintptr_t)part | (uintptr_t)center | (uintptr_t)center_out) & 7) == 0) {
                 a.xcd_gm = big_xcd_gm<DT>(a, true);
                 a.ln_light = g_ln_mode;
-                PRIMX_NOTE_KERNEL("gemm288q_pair_kernel<%d>", DT);
-                hipLaunchKernelGGL((gemm288q_pair_kernel<DT>), dim3(g0 + g1), dim3(512), 0, (hipStream_t)stream, PRIMX_GEMM_PASS(a), g0, r);
+                if (heads_kt64<DT>(a) && heads_kt64<DT>(r)) {
+                    PRIMX_NOTE_KERNEL("gemm288q_pair_kernel<%d, 64>", DT);
+                    hipLaunchKernelGGL((gemm288q_pair_kernel<DT, 64>), dim3(g0 + g1), dim3(512), 0, (hipStream_t)stream, PRIMX_GEMM_PASS(a), g0, r);
+                } else {
+                    PRIMX_NOTE_KERNEL("gemm288q_pair_kernel<%d, 32>", DT);
+                    hipLaunchKernelGGL((gemm288q_pair_kernel<DT, 32>), dim3(g0 + g1), dim3(512), 0, (hipStream_t)stream, PRIMX_GEMM_PASS(a), g0, r);
+                }
                 PRIMX_CHECK_LAUNCH(name);
                 paired = true;
             } else if (int rc = launch_fold<DT, EPI_HEADS_FOLD>(a, (hipStream_t)stream, name)) {
@@ -2448,8 +2472,7 @@ extern "C" int primx_linear_heads_fold_pair(const void* A, const void* W, int M,
         }
         if (!paired) {
             if (big1) {   // problem 1 alone: the tile kernel it would have ridden
-                PRIMX_NOTE_KERNEL("gemm288q_dma_kernel<%d, %d, 32>", DT, EPI_HEADS);
-                hipLaunchKernelGGL((gemm288q_dma_kernel<DT, EPI_HEADS, 32>), dim3(g1), dim3(512), 0, (hipStream_t)stream, PRIMX_GEMM_PASS(r));
+                launch288q<DT, EPI_HEADS>(r, dim3(g1), (hipStream_t)stream);
                 PRIMX_CHECK_LAUNCH(name);
             } else {
                 return launch<DT, EPI_HEADS>(r, (hipStream_t)stream, name);

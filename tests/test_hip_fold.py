@@ -42,6 +42,10 @@ def _fold_kernels_selectable(ops) -> bool:
     return ops.fold_shapes_ok(4096, 2048, 1152, 16)
 
 
+# the ring the 256 x 288 kernel's heads epilogues run on: 128-byte row segments (two stages of 64-wide k-tiles) unless switched back
+_HEADS_RING = ", 32>" if (os.environ.get("PRIMX_GEMM_HEADS_KT32", "0") not in ("", "0") or os.environ.get("PRIMX_GEMM_KT32", "0") not in ("", "0")) else ", 64>"
+
+
 def _last_kernel(ops):
     from topia_xl_amd import _lib
     return _lib.load().primx_last_gemm_kernel().decode()
@@ -236,7 +240,7 @@ def test_fold_consumer_to_q(ops, dtype, B, n):
     print(f"to_q {dtype} B={B} n={n}: folded {err:.2e}, unfolded {err_unfolded:.2e}")
     assert err < 2 * TOL[dtype] and err < 1.5 * err_unfolded + 1e-4
     if _default_dispatch():
-        assert names[0].startswith("gemm288q_dma_kernel<" if B * n >= 10240 else "gemm144l_dma_kernel<") and names[0].endswith((", 7>", ", 7, 32>")), names
+        assert names[0].startswith("gemm288q_dma_kernel<" if B * n >= 10240 else "gemm144l_dma_kernel<") and names[0].endswith((", 7>", ", 7, 32>", ", 7, 64>")), names
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -267,7 +271,7 @@ def test_fold_consumer_qkv(ops, dtype):
     # the operand-level mask / denominator markers of the layouts survive (include/primx_hip.h)
     assert float(bufs[2][:, :, dh].float().sum()) == B * H * n
     if _default_dispatch():
-        assert names[0].startswith("gemm288q_dma_kernel<") and names[0].endswith(", 7, 32>")
+        assert names[0].startswith("gemm288q_dma_kernel<") and names[0].endswith(_HEADS_RING)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -319,8 +323,8 @@ def test_fold_consumer_qkv_with_a_rider(ops, dtype, B, n, paired):
         assert rel_l2(unpack(kv_got[s], L, dh), want[:, :, s]) < TOL[dtype]
         assert rel_l2(unpack(kv_ref[s], L, dh), want[:, :, s]) < TOL[dtype]
     if _default_dispatch():
-        assert names[0] == (f"gemm288q_pair_kernel<{dt}>" if paired else f"gemm288q_dma_kernel<{dt}, 2, 32>"), names
-        assert names[1] == f"gemm288q_dma_kernel<{dt}, 2, 32>", names
+        assert names[0] == (f"gemm288q_pair_kernel<{dt}{_HEADS_RING}" if paired else f"gemm288q_dma_kernel<{dt}, 2{_HEADS_RING}"), names
+        assert names[1] == f"gemm288q_dma_kernel<{dt}, 2{_HEADS_RING}", names
 
 
 def test_fold_pair_rejects_bad_arguments(ops):

@@ -23,8 +23,11 @@ CYCLES = {  # kernel name prefix -> shape tags in launch order within one block 
     "gemm144l_dma_kernel<1, 7>": ["4096x1152x1152"],
     "gemm288q_dma_kernel<1, 7>": ["4096x3456x1152"],
     "gemm288q_dma_kernel<1, 7, 32>": ["4096x3456x1152"],     # (rocprofv3 prints the ring's template argument since round 6)
+    "gemm288q_dma_kernel<1, 7, 64>": ["4096x3456x1152"],     # (the heads epilogues on the 128-byte ring: end of round 6)
     "gemm288q_dma_kernel<1, 8, 64>": ["4096x4608x1152"],
-    "gemm288q_pair_kernel<1>": ["4096x3456x1152+1536x2304x768"],   # qkv + the next block's to_k / to_v riding on its idle CUs (ABI 25)
+    "gemm288q_pair_kernel<1>": ["4096x3456x1152+1536x2304x768"],
+    "gemm288q_pair_kernel<1, 64>": ["4096x3456x1152+1536x2304x768"],
+    "gemm288q_pair_kernel<1, 32>": ["4096x3456x1152+1536x2304x768"],   # qkv + the next block's to_k / to_v riding on its idle CUs (ABI 25)
     "gemm288p_dma_kernel<1, true>": ["4096x4608x1152"],      # (rounds 4 - 5 traces)
     "attn_kernel<1, 5, 3, 0, 0>": ["32x2048x1370x72", "32x2048x2048x72"],
     # --config decode (2048 primitives): one shape per kernel
@@ -47,6 +50,8 @@ CYCLES_B8 = {
 GRID_B8 = {   # kernel -> {workgroups: shape}
     "gemm288q_dma_kernel<1, 7, 32>": {1536: "32768x3456x1152", 512: "32768x1152x1152"},
     "gemm288q_dma_kernel<1, 2, 32>": {512: "32768x1152x1152", 10752: "12288x64512x768", 21504: "24576x64512x768"},
+    "gemm288q_dma_kernel<1, 7, 64>": {1536: "32768x3456x1152", 512: "32768x1152x1152"},
+    "gemm288q_dma_kernel<1, 2, 64>": {512: "32768x1152x1152", 10752: "12288x64512x768", 21504: "24576x64512x768"},
 }
 
 
@@ -64,7 +69,7 @@ def tag_of(kname, grid, seen, mode="ddim"):
             return f"{k} {GRID_B8[k].get(grid // 512, str(grid // 512) + ' workgroups')}"
         cyc = CYCLES_B8.get(k)
     else:
-        if k.startswith("gemm288q_dma_kernel<1, 2>") or k.startswith("gemm288q_dma_kernel<1, 2, 32>"):
+        if k.startswith("gemm288q_dma_kernel<1, 2>") or k.startswith("gemm288q_dma_kernel<1, 2, 32>") or k.startswith("gemm288q_dma_kernel<1, 2, 64>"):
             # (the batched K / V projection; block 0's projection alone on the riders' tile kernel - 48 workgroups, ABI 25; block 0's to_q)
             return k + (" 1536x64512x768" if grid > 512 * 400 else " 1536x2304x768" if grid == 512 * 48 else " 4096x3456x1152")
         cyc = CYCLES.get(k)
