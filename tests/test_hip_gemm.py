@@ -124,7 +124,7 @@ def test_linear_heads_repeated(ops, B, n, H, dh, K, n_rep):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("B,n,H,dh,K", [(2, 256, 16, 72, 1152), (3, 70, 4, 72, 64), (1, 1370, 16, 72, 768),
                                        (2, 64, 8, 32, 256), (1, 1, 6, 64, 128),
-                                       (2, 2048, 16, 72, 256), (1, 4096, 16, 72, 128),    # 256x288 tile, LDS-staged scatter
+                                       (2, 2048, 16, 72, 256), (1, 4096, 16, 72, 128), (1, 4096, 16, 72, 192),    # 256x288 tile, LDS-staged scatter (128-byte ring: 4, 2, 3 k-tiles)
                                        (1, 14336, 9, 32, 64), (1, 14336, 3, 96, 64),      # ... 9 and 3 heads per column tile
                                        (1, 14336, 12, 24, 64)])                           # dh < 32: stays on 128x144 tiles
 def test_linear_heads_layouts(ops, dtype, B, n, H, dh, K):
