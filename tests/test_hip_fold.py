@@ -46,6 +46,13 @@ def _fold_kernels_selectable(ops) -> bool:
 _HEADS_RING = ", 32>" if (os.environ.get("PRIMX_GEMM_HEADS_KT32", "0") not in ("", "0") or os.environ.get("PRIMX_GEMM_KT32", "0") not in ("", "0")) else ", 64>"
 
 
+def _folding_mode() -> bool:
+    """Do planned forwards fold under the environment's DiT switches?  (unplanned loops, the two-stream mode, LayerNorm launches that are not fused into the
+    gate-residual call and the LayerNorm-carried weight prefetch keep the LayerNorm launches: DiT._forward16)"""
+    return (os.environ.get("PRIMX_PLAN_TIMESTEPS", "1") != "0" and not os.environ.get("PRIMX_CFG_STREAMS") and os.environ.get("PRIMX_DIT_FUSE_LN") != "0"
+            and os.environ.get("PRIMX_WPREFETCH", "2") != "1" and os.environ.get("PRIMX_DIT_FOLD") != "0")
+
+
 def _last_kernel(ops):
     from topia_xl_amd import _lib
     return _lib.load().primx_last_gemm_kernel().decode()
@@ -493,7 +500,7 @@ def test_dit_with_the_fold_against_the_unfolded_path_and_the_oracle(ops, dtype, 
         assert sum(1 for nm in names if epi(nm) == "6") == 4 * (3 * 3 - 1), names   # producers: every gated add but the last
         assert sum(1 for nm in names if epi(nm) == "7") == 4 * (2 * 3 - 1 - riders), names      # to_q (blocks 1, 2) + qkv
         assert sum(1 for nm in names if nm.startswith("gemm288q_pair_kernel<")) == 4 * riders, names
-        fc1_ring = ", 8, 32>" if os.environ.get("PRIMX_GEMM_KT32", "0") not in ("", "0") else ", 8, 64>"
+        fc1_ring = ", 8, 32>" if (os.environ.get("PRIMX_GEMM_KT32", "0") not in ("", "0") or int(os.environ.get("PRIMX_GEMM_KT64_MIN", "1")) > 256) else ", 8, 64>"
         assert sum(1 for nm in names if nm.startswith("gemm288q_dma_kernel") and fc1_ring in nm) == 4 * 3
     # one planned forward against the fp32 oracle
     t = torch.tensor([520])
@@ -525,6 +532,8 @@ def test_dit_fold_with_massive_activation_channels(ops, dtype):
     import warnings
 
     import topia_xl_amd as pkg
+    if os.environ.get("PRIMX_CFG_STREAMS"):
+        pytest.skip("the two-stream route does not fill `block_probe`")
     cfg = dict(in_channels=68, condition_channels=768, hidden_size=1152, depth=2)
     sd = synth.dit_state_dict(83, **cfg)
     sd["x_embedder.bias"] = sd["x_embedder.bias"].clone()
@@ -547,10 +556,7 @@ def test_dit_fold_with_massive_activation_channels(ops, dtype):
     m.block_probe = []
     folded = loop()
     probe, m.block_probe = m.block_probe, None
-    # (unplanned loops - PRIMX_PLAN_TIMESTEPS=0 - never fold; neither do the two-stream, LayerNorm-in-the-tail and LayerNorm-carried-prefetch modes)
-    folds = (_fold_kernels_selectable(ops) and os.environ.get("PRIMX_PLAN_TIMESTEPS", "1") != "0" and not os.environ.get("PRIMX_CFG_STREAMS")
-             and os.environ.get("PRIMX_DIT_LN_TAIL") != "1" and os.environ.get("PRIMX_DIT_FUSE_LN") != "0" and os.environ.get("PRIMX_WPREFETCH", "2") != "1")
-    assert any(b["folded"] for b in probe) == folds
+    assert any(b["folded"] for b in probe) == (_fold_kernels_selectable(ops) and _folding_mode())
     assert max(b["residual_abs_max"] for b in probe) > 3e4 and all(b["next_operand_finite"] for b in probe)
     assert max(b["next_operand_abs_max"] for b in probe) < 200, max(b["next_operand_abs_max"] for b in probe)   # normalised, not 4e4
     tol = {torch.float16: 3e-3, torch.bfloat16: 2.5e-2}[dtype]
@@ -710,5 +716,5 @@ def test_fold_is_capped_by_the_loop_length(ops, monkeypatch):
         m.select_planned_timestep(1)
         m.forward_with_cfg(x.to(DEV), t[:1], y.to(DEV), 6.0, torch.float16, True)
         m.clear_timestep_plan()
-        if m._fold_ok(4096, 2048):
+        if m._fold_ok(4096, 2048) and _folding_mode():
             assert len(built) == want, (cap, built)
