@@ -669,6 +669,11 @@ def main() -> None:
                 res["config"]["null_cond_kv"] = (f"the unconditional half's {L_COND} identical conditioning rows are projected once "
                                                  f"({ln} rows) and addressed as the {L_COND}-key sequence by the attention kernel "
                                                  "(bit-identical results); `with_expanded_null_kv` times the expanded form")
+            if (not args.reuse_cond_kv and getattr(model, "kv_ride", False) and getattr(model, "fold_ln", False) and model._fold_ok(2 * B * N, N)
+                    and B == 1):
+                res["config"]["cond_kv_projection"] = ("every step projects the conditioning tokens of all blocks (to_k / to_v, attention.py:106-107); block "
+                                                       "i + 1's projection runs on the CUs block i's qkv launch leaves idle (primx_linear_heads_fold_pair), "
+                                                       "block 0's as a launch of its own; `with_batched_kv_projection` times the one-launch form")
         elif args.config == "decode":
             res.update({
                 "metric": "VAE decode samples/sec (2048 primitives per sample: latent de-normalise + vae3d_dib decode + inverse normalisation)",
